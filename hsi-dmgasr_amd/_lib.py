@@ -1,0 +1,104 @@
+"""ctypes binding of libhsidm.so (the C ABI declared in include/hsidm.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If it cannot be loaded,
+or a tensor is not on a ROCm device, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch  # must be imported first: the library resolves libamdhip64.so.7 to the copy torch loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhsidm.so")
+
+BF16, F32X3 = 0, 1
+XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
+ACT_NONE, ACT_LEAKY = 0, 1
+
+_vp, _i32, _i64, _u32, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+
+
+class ConvPhase(C.Structure):
+    _fields_ = [("src0", _vp), ("src1", _vp), ("gn_ab", _vp), ("C0", _i32), ("C1", _i32),
+                ("transform", _i32), ("ntaps", _i32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("ph", ConvPhase * 2), ("nphase", _i32), ("w_hi", _vp), ("w_lo", _vp), ("bias", _vp),
+                ("film", _vp), ("film_stride", _i32), ("res", _vp), ("res_scale", _f32), ("out", _vp),
+                ("stats", _vp), ("B", _i32), ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32),
+                ("Cout", _i32), ("ksize", _i32), ("stride", _i32), ("ups", _i32), ("act", _i32),
+                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32)]
+
+
+# name -> argtypes, exactly the prototypes of include/hsidm.h
+SIGNATURES = {
+    "hsidm_version": [],
+    "hsidm_conv_bk": [_i32],
+    "hsidm_conv2d": [C.POINTER(ConvDesc), _vp],
+    "hsidm_gn_partial": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "hsidm_gn_finalize": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
+    "hsidm_noise_film": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "hsidm_attention": [_i32, _vp, _vp, _i32, _i32, _i32, _vp],
+    "hsidm_nchw_to_nhwc": [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
+    "hsidm_nhwc_to_nchw": [_i32, _vp, _vp, _i32, _i32, _i32, _vp],
+    "hsidm_p_sample_update": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _u64, _i64, _vp, _i32, _vp],
+    "hsidm_step_advance": [_vp, _vp],
+    "hsidm_philox_normal": [_vp, _i64, _u64, _u32, _vp],
+    "hsidm_ca_vector": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hsidm_ca_apply": [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp],
+    "hsidm_overlap_average": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libhsidm.so once.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "hsidm: %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _i32
+        L.hsidm_error_string.argtypes = [_i32]
+        L.hsidm_error_string.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("hsidm %s failed: %s (code %d)" % (what, lib().hsidm_error_string(code).decode(), code))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the product has no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("hsidm: tensor is on %s; the HIP path needs a ROCm device tensor" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("hsidm: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def prec_id(precision):
+    if precision == "bf16":
+        return BF16
+    if precision in ("fp32", "f32x3"):
+        return F32X3
+    raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (precision,))
+
+
+def act_dtype(precision):
+    return torch.bfloat16 if prec_id(precision) == BF16 else torch.float32

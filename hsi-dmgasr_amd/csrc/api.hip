@@ -1,0 +1,88 @@
+// C-ABI entry points: argument validation, tile selection and dispatch for the convolution.
+#include "conv_igemm.h"
+#include "../../include/hsidm.h"
+
+namespace hsidm {
+#define HSIDM_DECL(tag) int tag(int tile_kind, int bn, const ConvParams& p, hipStream_t s);
+HSIDM_DECL(conv_run_bf16_k3s1)
+HSIDM_DECL(conv_run_bf16_k3s2)
+HSIDM_DECL(conv_run_bf16_k1s1)
+HSIDM_DECL(conv_run_bf16_k3s1nchw)
+HSIDM_DECL(conv_run_f32x3_k3s1)
+HSIDM_DECL(conv_run_f32x3_k3s2)
+HSIDM_DECL(conv_run_f32x3_k1s1)
+HSIDM_DECL(conv_run_f32x3_k3s1nchw)
+#undef HSIDM_DECL
+}  // namespace hsidm
+
+using namespace hsidm;
+
+extern "C" int hsidm_version(void) { return 1; }
+
+extern "C" const char* hsidm_error_string(int code) {
+    switch (code) {
+        case HSIDM_OK: return "ok";
+        case HSIDM_E_BADARG: return "hsidm: invalid argument";
+        case HSIDM_E_UNSUPPORTED: return "hsidm: unsupported shape or mode";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "hsidm: unknown error";
+    }
+}
+
+extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
+
+extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
+    if (!d || !d->out || !d->w_hi) return HSIDM_E_BADARG;
+    if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3) return HSIDM_E_BADARG;
+    if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
+    if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
+    if (d->ksize != 3 && d->ksize != 1) return HSIDM_E_BADARG;
+    if (d->stride != 1 && d->stride != 2) return HSIDM_E_BADARG;
+    if (d->bn != 32 && d->bn != 64 && d->bn != 128) return HSIDM_E_BADARG;
+    if (d->B <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cout <= 0) return HSIDM_E_BADARG;
+    // geometry the reference uses: 3x3 pad 1 (stride 1|2, optional nearest x2), 1x1 pad 0 stride 1
+    if (d->ksize == 1 && (d->stride != 1 || d->ups)) return HSIDM_E_UNSUPPORTED;
+    if (d->ups && d->stride != 1) return HSIDM_E_UNSUPPORTED;
+    if (d->out_nchw && (d->ksize != 3 || d->stride != 1 || d->bn == 64 || d->stats)) return HSIDM_E_UNSUPPORTED;
+    if (d->nphase == 2 && (d->ksize != 3 || d->stride != 1 || d->ups || d->ph[1].ntaps != 1)) return HSIDM_E_UNSUPPORTED;
+    const int Hout = d->ups ? 2 * d->Hin : (d->stride == 2 ? (d->Hin + 1) / 2 : d->Hin);
+    const int Wout = d->ups ? 2 * d->Win : (d->stride == 2 ? (d->Win + 1) / 2 : d->Win);
+    if (Hout != d->Hout || Wout != d->Wout) return HSIDM_E_BADARG;
+
+    const int bk = hsidm_conv_bk(d->prec);
+    ConvParams p;
+    p.nphase = d->nphase;
+    for (int i = 0; i < 2; ++i) {
+        ConvPhase& q = p.ph[i];
+        if (i < d->nphase) {
+            const hsidm_conv_phase& s = d->ph[i];
+            if (!s.src0 || s.C0 <= 0 || (s.C0 & 7) || s.C1 < 0 || (s.C1 & 7) || (s.C1 > 0 && !s.src1)) return HSIDM_E_BADARG;
+            if (s.transform != HSIDM_XF_NONE && !s.gn_ab) return HSIDM_E_BADARG;
+            if (s.ntaps != (i == 0 ? d->ksize * d->ksize : 1)) return HSIDM_E_BADARG;
+            q.src0 = s.src0; q.src1 = s.C1 > 0 ? s.src1 : nullptr;
+            q.gn_ab = reinterpret_cast<const float2*>(s.gn_ab);
+            q.C0 = s.C0; q.C1 = s.C1; q.transform = s.transform; q.ntaps = s.ntaps;
+            q.nchunks = (s.C0 + s.C1 + bk - 1) / bk;
+        } else {
+            q.src0 = q.src1 = nullptr; q.gn_ab = nullptr; q.C0 = q.C1 = 0; q.transform = 0; q.ntaps = 0; q.nchunks = 0;
+        }
+    }
+    p.w_hi = reinterpret_cast<const bf16*>(d->w_hi);
+    p.w_lo = reinterpret_cast<const bf16*>(d->w_lo);
+    p.bias = d->bias; p.film = d->film; p.film_stride = d->film_stride;
+    p.res = d->res; p.res_scale = d->res_scale; p.out = d->out;
+    p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = Hout; p.Wout = Wout; p.Cout = d->Cout;
+    p.Cout_pad = (d->Cout + d->bn - 1) / d->bn * d->bn;
+    p.ups = d->ups; p.act = d->act;
+    p.stats = reinterpret_cast<float2*>(d->stats);
+    // spatial tile: 8x16 pixels of one image, or 8x8 pixels of two images when the map is narrow
+    const int tile_kind = (Wout >= 16) ? 0 : 1;
+    const int TH = 8, TW = tile_kind == 0 ? 16 : 8;
+    p.tiles_x = (Wout + TW - 1) / TW;
+    p.tiles_y = (Hout + TH - 1) / TH;
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = d->prec == HSIDM_BF16;
+    if (d->out_nchw) return bf ? conv_run_bf16_k3s1nchw(tile_kind, d->bn, p, s) : conv_run_f32x3_k3s1nchw(tile_kind, d->bn, p, s);
+    if (d->ksize == 1) return bf ? conv_run_bf16_k1s1(tile_kind, d->bn, p, s) : conv_run_f32x3_k1s1(tile_kind, d->bn, p, s);
+    if (d->stride == 2) return bf ? conv_run_bf16_k3s2(tile_kind, d->bn, p, s) : conv_run_f32x3_k3s2(tile_kind, d->bn, p, s);
+    return bf ? conv_run_bf16_k3s1(tile_kind, d->bn, p, s) : conv_run_f32x3_k3s1(tile_kind, d->bn, p, s);
+}

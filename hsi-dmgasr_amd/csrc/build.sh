@@ -1,0 +1,24 @@
+#!/bin/bash
+# Build libhsidm.so (gfx950 only) in-tree: one hipcc per translation unit in parallel, then link.
+set -e
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../libhsidm.so"
+OBJ="$HERE/obj"
+mkdir -p "$OBJ"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable"
+JOBS="${JOBS:-6}"
+pids=()
+for src in "$HERE"/*.hip; do
+  o="$OBJ/$(basename "${src%.hip}").o"
+  if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ -n "$(find "$HERE" -maxdepth 1 \( -name '*.h' -o -name '*.inc' \) -newer "$o")" ] || [ "$HERE/../../include/hsidm.h" -nt "$o" ]; then
+    ( $HIPCC $FLAGS -c "$src" -o "$o" ) &
+    pids+=($!)
+    while [ "$(jobs -rp | wc -l)" -ge "$JOBS" ]; do sleep 0.2; done
+  fi
+done
+fail=0
+for p in "${pids[@]}"; do wait "$p" || fail=1; done
+[ $fail -eq 0 ] || { echo "hsidm build: compile failed" >&2; exit 1; }
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+echo "built $OUT"

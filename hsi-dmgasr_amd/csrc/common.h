@@ -1,0 +1,75 @@
+// Shared device helpers for the hsidm HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hsidm {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int kWave = 64;
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+// plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving) on gfx950
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+
+// 8 consecutive activations as fp32, from either storage type
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+        bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+        bf16x8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (bf16)v[i];
+        *reinterpret_cast<bf16x8*>(p) = r;
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+        *reinterpret_cast<f32x4*>(p) = a;
+        *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace hsidm

@@ -1,0 +1,228 @@
+// GroupNorm statistics, noise-level embedding / FiLM projections, channel attention vector.
+// All HBM-bound or tiny kernels: coalesced 16-B channel vectors, wave-shuffle / LDS reductions,
+// fp32 arithmetic throughout.
+#include "common.h"
+#include "../../include/hsidm.h"
+
+namespace hsidm {
+
+// ---------------------------------------------------------------------------------------------------
+// gn_partial: grid (nsplit, B).  Each workgroup streams a contiguous pixel range of one image,
+// thread t owns channel vector (t % nvec) of pixel rows t / nvec, t / nvec + rows, ...; per-channel
+// partial sums are combined across the rows through LDS in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------
+template <typename ActT>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const ActT* __restrict__ s0, const ActT* __restrict__ s1,
+                                                         int C0, int C1, int HW, int nsplit,
+                                                         float2* __restrict__ part) {
+    __shared__ float red[256 * 8 * 2];
+    const int C = C0 + C1;
+    const int nvec = C >> 3;
+    const int rows = 256 / nvec;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p_begin = split * per;
+    const int p_end = min(HW, p_begin + per);
+    const int t = threadIdx.x;
+    const int cvi = t % nvec, prow = t / nvec;
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
+    if (prow < rows) {
+        const int c = cvi * 8;
+        const ActT* src;
+        int cs, cl;
+        if (c < C0) { src = s0; cs = C0; cl = c; } else { src = s1; cs = C1; cl = c - C0; }
+        for (int p = p_begin + prow; p < p_end; p += rows) {
+            float v[8];
+            Vec8<ActT>::load(src + ((size_t)b * HW + p) * cs + cl, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[(prow * C + c + k) * 2] = s[k];
+            red[(prow * C + c + k) * 2 + 1] = q[k];
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float a = 0.f, d = 0.f;
+        for (int r = 0; r < rows; ++r) { a += red[(r * C + c) * 2]; d += red[(r * C + c) * 2 + 1]; }
+        part[((size_t)b * nsplit + split) * C + c] = make_float2(a, d);
+    }
+}
+
+// gn_finalize: grid (B).  part [B][nsplit][C] -> gn_ab [B][C] = (rstd*gamma, beta - mean*rstd*gamma)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict__ part, int nsplit, int C, int HW,
+                                                          int groups, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float2* __restrict__ ab) {
+    extern __shared__ float sm[];          // [C] sum, [C] sumsq, [groups] mean, [groups] rstd
+    float* cs = sm;
+    float* cq = sm + C;
+    float* gm = sm + 2 * C;
+    float* gr = gm + groups;
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        float a = 0.f, d = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            float2 v = part[((size_t)b * nsplit + s) * C + c];
+            a += v.x;
+            d += v.y;
+        }
+        cs[c] = a;
+        cq[c] = d;
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int g = t; g < groups; g += 256) {
+        double a = 0.0, d = 0.0;
+        for (int k = 0; k < cpg; ++k) { a += cs[g * cpg + k]; d += cq[g * cpg + k]; }
+        const double n = (double)cpg * HW;
+        const double mean = a / n;
+        double var = d / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        gm[g] = (float)mean;
+        gr[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = gr[g] * gamma[c];
+        ab[(size_t)b * C + c] = make_float2(sc, beta[c] - gm[g] * sc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// noise_film: grid (ceil(F/256), B).  Every workgroup recomputes the 64 -> 256 -> 64 MLP of its image
+// (32 K MACs) in LDS and then emits 256 FiLM outputs.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_film_kernel(const float* __restrict__ gamma, const float* __restrict__ level,
+                                                         const int32_t* __restrict__ t_ptr, const float* __restrict__ t_emb,
+                                                         float* __restrict__ t_out, int dim,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ wf, const float* __restrict__ bf,
+                                                         int F, float* __restrict__ film) {
+    extern __shared__ float sm[];          // [dim] pe, [4*dim] hidden, [dim] t
+    float* pe = sm;
+    float* hid = sm + dim;
+    float* te = hid + 4 * dim;
+    const int b = blockIdx.y, t = threadIdx.x;
+    if (t_emb) {                                  // embedding supplied by the caller (module-level API)
+        for (int k = t; k < dim; k += 256) te[k] = t_emb[(size_t)b * dim + k];
+        __syncthreads();
+    } else {
+    const float g = gamma ? gamma[b] : level[*t_ptr + 1];
+    const int half = dim >> 1;
+    for (int i = t; i < dim; i += 256) {
+        const int k = i < half ? i : i - half;
+        const float step = (float)k / (float)half;
+        const float e = g * expf(-9.210340371976184f * step);      // ln(1e4)
+        pe[i] = i < half ? sinf(e) : cosf(e);
+    }
+    __syncthreads();
+    for (int j = t; j < 4 * dim; j += 256) {
+        float a = b1[j];
+        for (int i = 0; i < dim; ++i) a = fmaf(w1[(size_t)j * dim + i], pe[i], a);
+        hid[j] = a / (1.0f + expf(-a));
+    }
+    __syncthreads();
+    for (int k = t; k < dim; k += 256) {
+        float a = b2[k];
+        for (int j = 0; j < 4 * dim; ++j) a = fmaf(w2[(size_t)k * 4 * dim + j], hid[j], a);
+        te[k] = a;
+        if (t_out && blockIdx.x == 0) t_out[(size_t)b * dim + k] = a;
+    }
+    __syncthreads();
+    }
+    const int f = blockIdx.x * 256 + t;
+    if (f < F) {
+        float a = bf[f];
+        for (int k = 0; k < dim; ++k) a = fmaf(wf[(size_t)f * dim + k], te[k], a);
+        film[(size_t)b * F + f] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ca_vector: grid (B).  CALayer squeeze-excite vector from per-channel sums.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ca_vector_kernel(const float2* __restrict__ part, int nsplit, int C, int HW, int R,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ ca) {
+    extern __shared__ float sm[];          // [C] mean, [R] hidden
+    float* mean = sm;
+    float* hid = sm + C;
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        float a = 0.f;
+        for (int s = 0; s < nsplit; ++s) a += part[((size_t)b * nsplit + s) * C + c].x;
+        mean[c] = a / (float)HW;
+    }
+    __syncthreads();
+    for (int r = t; r < R; r += 256) {
+        float a = b1[r];
+        for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)r * C + c], mean[c], a);
+        hid[r] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float a = b2[c];
+        for (int r = 0; r < R; ++r) a = fmaf(w2[(size_t)c * R + r], hid[r], a);
+        ca[(size_t)b * C + c] = 1.0f / (1.0f + expf(-a));
+    }
+}
+
+}  // namespace hsidm
+
+using namespace hsidm;
+
+extern "C" int hsidm_gn_partial(int prec, const void* src0, const void* src1, int C0, int C1, int B, int HW,
+                                int nsplit, float* part, void* stream) {
+    const int C = C0 + C1;
+    if (!src0 || !part || C0 <= 0 || (C0 & 7) || (C1 & 7) || C > 2048 || B <= 0 || HW <= 0 || nsplit <= 0) return HSIDM_E_BADARG;
+    if (C1 > 0 && !src1) return HSIDM_E_BADARG;
+    dim3 grid(nsplit, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == HSIDM_BF16)
+        hipLaunchKernelGGL(gn_partial_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src0, (const bf16*)src1, C0, C1, HW, nsplit, (float2*)part);
+    else if (prec == HSIDM_F32X3)
+        hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)src0, (const float*)src1, C0, C1, HW, nsplit, (float2*)part);
+    else
+        return HSIDM_E_BADARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int hsidm_gn_finalize(const float* part, int nsplit, int B, int C, int HW, int groups,
+                                 const float* gamma, const float* beta, float eps, float* gn_ab, void* stream) {
+    if (!part || !gamma || !beta || !gn_ab || groups <= 0 || C % groups || C > 8192 || nsplit <= 0) return HSIDM_E_BADARG;
+    const size_t lds = (size_t)(2 * C + 2 * groups) * sizeof(float);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float2*)part, nsplit, C, HW,
+                       groups, gamma, beta, eps, (float2*)gn_ab);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hsidm_noise_film(const float* gamma, const float* level_table, const int32_t* t_ptr, const float* t_emb,
+                                int B, int dim, const float* w1, const float* b1, const float* w2, const float* b2,
+                                const float* wf, const float* bf, int F, float* film, float* t_out, void* stream) {
+    if (!t_emb && ((!gamma && !(level_table && t_ptr)) || !w1 || !b1 || !w2 || !b2)) return HSIDM_E_BADARG;
+    if (!wf || !bf || !film) return HSIDM_E_BADARG;
+    if (dim <= 0 || (dim & 1) || dim > 1024 || F <= 0 || B <= 0) return HSIDM_E_BADARG;
+    dim3 grid((F + 255) / 256, B);
+    const size_t lds = (size_t)(6 * dim) * sizeof(float);
+    hipLaunchKernelGGL(noise_film_kernel, grid, dim3(256), lds, (hipStream_t)stream, gamma, level_table, t_ptr, t_emb, t_out, dim,
+                       w1, b1, w2, b2, wf, bf, F, film);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hsidm_ca_vector(const float* part, int nsplit, int B, int C, int HW, int R,
+                               const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* ca, void* stream) {
+    if (!part || !w1 || !b1 || !w2 || !b2 || !ca || C <= 0 || R <= 0 || C > 4096) return HSIDM_E_BADARG;
+    const size_t lds = (size_t)(C + R) * sizeof(float);
+    hipLaunchKernelGGL(ca_vector_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float2*)part, nsplit, C, HW, R,
+                       w1, b1, w2, b2, ca);
+    return (int)hipGetLastError();
+}

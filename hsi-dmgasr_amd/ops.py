@@ -1,0 +1,251 @@
+"""Host-side operator layer: weight packing and thin wrappers that enqueue the HIP kernels.
+
+Tensors here are the path's internal representation: NHWC activations (torch shape [B, H, W, C]) in
+the storage type of the precision mode (bf16 / fp32), fp32 everywhere else.  torch only supplies
+device memory and the current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, XF_AFFINE, XF_AFFINE_SILU, XF_NONE  # noqa: F401 (re-exported)
+
+
+# ------------------------------------------------------------------------------------------- packing
+def pick_bn(cout, out_nchw=False):
+    """Output-channel slice per workgroup (must match the packed weights)."""
+    if out_nchw:
+        return 32 if cout <= 32 else 128
+    if cout <= 32:
+        return 32
+    if cout <= 64:
+        return 64
+    return 128
+
+
+class PackedConv:
+    """Weights of one hsidm_conv2d launch in the kernel's streaming order.
+
+    Layout (include/hsidm.h): bf16 [step][Cout_pad][BK] with step = (phase, cin-chunk, tap); phase 1 is
+    the optional fused 1x1 projection (ResnetBlock.res_conv, reference unet.py:102-103).
+    """
+
+    def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False):
+        prec = _lib.prec_id(precision)
+        bk = 64 if prec == _lib.BF16 else 32
+        dev = weight.device
+        cout, cin, kh, kw = weight.shape
+        assert kh == kw and kh in (1, 3)
+        if cin % 8:     # NHWC tensors carry channels in 16-B vectors: pad the K axis with zero weights
+            weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 8 - cin % 8))
+            cin = weight.shape[1]
+        self.ksize, self.cin, self.cout, self.precision, self.prec = kh, cin, cout, precision, prec
+        self.out_nchw = out_nchw
+        self.bn = pick_bn(cout, out_nchw)
+        cpad = (cout + self.bn - 1) // self.bn * self.bn
+        parts = [self._steps(weight.detach().float(), cpad, bk)]
+        self.proj_cin = 0
+        b = None if bias is None else bias.detach().float().clone()
+        if proj_weight is not None:
+            assert proj_weight.shape[2] == 1 and proj_weight.shape[0] == cout
+            if proj_weight.shape[1] % 8:
+                proj_weight = torch.nn.functional.pad(proj_weight.detach(), (0, 0, 0, 0, 0, 8 - proj_weight.shape[1] % 8))
+            self.proj_cin = proj_weight.shape[1]
+            parts.append(self._steps(proj_weight.detach().float(), cpad, bk))
+            if proj_bias is not None:
+                b = proj_bias.detach().float().clone() if b is None else b + proj_bias.detach().float()
+        w = torch.cat(parts, dim=0).contiguous()
+        self.w_hi = w.to(torch.bfloat16).contiguous()
+        self.w_lo = (w - self.w_hi.float()).to(torch.bfloat16).contiguous() if prec == _lib.F32X3 else None
+        self.bias = None if b is None else b.to(dev).contiguous()
+
+    @staticmethod
+    def _steps(w, cpad, bk):
+        cout, cin, kh, kw = w.shape
+        taps = kh * kw
+        nch = (cin + bk - 1) // bk
+        wp = torch.zeros(cpad, nch * bk, taps, dtype=torch.float32, device=w.device)
+        wp[:cout, :cin] = w.reshape(cout, cin, taps)
+        # [cpad][chunk][k][tap] -> [chunk][tap][cpad][k]
+        return wp.reshape(cpad, nch, bk, taps).permute(1, 3, 0, 2).reshape(nch * taps, cpad, bk)
+
+
+# ------------------------------------------------------------------------------------------- kernels
+def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=None, res_scale=1.0,
+           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=None):
+    """out = res_scale * act(conv(T(cat(x0, x1))) [+ proj(cat(proj_x0, proj_x1))] + bias + film) + res."""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    assert C0 + C1 == pw.cin, "conv input channels %d+%d != packed %d" % (C0, C1, pw.cin)
+    Ho, Wo = (2 * H, 2 * W) if ups else (((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+    dt = x0.dtype
+    if pw.out_nchw:
+        out = torch.empty((B, pw.cout, Ho, Wo), dtype=torch.float32, device=x0.device)
+    else:
+        out = torch.empty((B, Ho, Wo, pw.cout), dtype=dt, device=x0.device)
+    d = _lib.ConvDesc()
+    p0 = d.ph[0]
+    p0.src0, p0.src1, p0.gn_ab = _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(gn_ab)
+    p0.C0, p0.C1, p0.transform, p0.ntaps = C0, C1, transform, pw.ksize * pw.ksize
+    d.nphase = 1
+    if pw.proj_cin:
+        assert proj_x0 is not None
+        q0 = proj_x0.shape[3]
+        q1 = 0 if proj_x1 is None else proj_x1.shape[3]
+        assert q0 + q1 == pw.proj_cin and proj_x0.shape[:3] == x0.shape[:3]
+        p1 = d.ph[1]
+        p1.src0, p1.src1, p1.gn_ab = _lib.ptr(proj_x0), _lib.ptr(proj_x1), None
+        p1.C0, p1.C1, p1.transform, p1.ntaps = q0, q1, XF_NONE, 1
+        d.nphase = 2
+    d.w_hi, d.w_lo, d.bias = _lib.ptr(pw.w_hi), _lib.ptr(pw.w_lo), _lib.ptr(pw.bias)
+    if film is not None:          # a column slice of the [B, F] FiLM table
+        assert film.stride(1) == 1 and film.shape == (B, pw.cout)
+        d.film, d.film_stride = film.data_ptr(), film.stride(0)
+    d.res, d.res_scale, d.out, d.stats = _lib.ptr(res), float(res_scale), _lib.ptr(out), _lib.ptr(stats)
+    d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
+    d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, int(bool(ups)), act
+    d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
+    _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
+    return out
+
+
+def gn_scale_shift(x0, x1, gamma, beta, groups, precision, eps=1e-5):
+    """GroupNorm statistics of cat(x0, x1) folded with (gamma, beta): [B, C, 2] (scale, shift)."""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    Cc, HW = C0 + C1, H * W
+    nsplit = max(1, min(32, HW // 512))
+    part = torch.empty((B, nsplit, Cc, 2), dtype=torch.float32, device=x0.device)
+    L, s = _lib.lib(), _lib.stream_ptr()
+    _lib.check(L.hsidm_gn_partial(_lib.prec_id(precision), _lib.ptr(x0), _lib.ptr(x1), C0, C1, B, HW, nsplit,
+                                  _lib.ptr(part), s), "gn_partial")
+    ab = torch.empty((B, Cc, 2), dtype=torch.float32, device=x0.device)
+    _lib.check(L.hsidm_gn_finalize(_lib.ptr(part), nsplit, B, Cc, HW, groups, _lib.ptr(gamma), _lib.ptr(beta),
+                                   float(eps), _lib.ptr(ab), s), "gn_finalize")
+    return ab
+
+
+def channel_partials(x, precision):
+    """Per-(image, split, channel) (sum, sumsq) of an NHWC tensor: [B, nsplit, C, 2]."""
+    B, H, W, Cc = x.shape
+    HW = H * W
+    nsplit = max(1, min(32, HW // 512))
+    part = torch.empty((B, nsplit, Cc, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsidm_gn_partial(_lib.prec_id(precision), _lib.ptr(x), None, Cc, 0, B, HW, nsplit,
+                                           _lib.ptr(part), _lib.stream_ptr()), "gn_partial")
+    return part, nsplit
+
+
+def noise_film(B, dim, mlp, wf, bf, *, gamma=None, level_table=None, t_ptr=None, t_emb=None, want_t=False):
+    """FiLM table [B, F] (+ optionally the noise embedding [B, dim]).  mlp = (w1, b1, w2, b2) or None."""
+    dev = wf.device
+    F = wf.shape[0]
+    film = torch.empty((B, F), dtype=torch.float32, device=dev)
+    t_out = torch.empty((B, dim), dtype=torch.float32, device=dev) if want_t else None
+    w1, b1, w2, b2 = mlp if mlp is not None else (None, None, None, None)
+    _lib.check(_lib.lib().hsidm_noise_film(_lib.ptr(gamma), _lib.ptr(level_table), _lib.ptr(t_ptr), _lib.ptr(t_emb),
+                                           B, dim, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+                                           _lib.ptr(wf), _lib.ptr(bf), F, _lib.ptr(film), _lib.ptr(t_out),
+                                           _lib.stream_ptr()), "noise_film")
+    return (film, t_out) if want_t else film
+
+
+def attention(qkv, precision):
+    B, H, W, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty((B, H, W, Cc), dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.lib().hsidm_attention(_lib.prec_id(precision), _lib.ptr(qkv), _lib.ptr(out), B, H * W, Cc,
+                                          _lib.stream_ptr()), "attention")
+    return out
+
+
+_offset_cache = {}
+
+
+def _offsets(n_img, img_stride, dev):
+    """Device int64 [n_img] = i * img_stride, cached (a host->device copy cannot be graph-captured)."""
+    key = (n_img, img_stride, str(dev))
+    off = _offset_cache.get(key)
+    if off is None:
+        off = (torch.arange(n_img, dtype=torch.int64) * img_stride).to(dev)
+        _offset_cache[key] = off
+    return off
+
+
+def to_nhwc(x, precision, x1=None, offsets0=None, offsets1=None, c0=None, n_out=None):
+    """NCHW fp32 -> NHWC storage type, channels zero-padded to a multiple of 8; optional concat (x, x1).
+
+    offsets0 / c0 / n_out allow channel slicing with a per-output-image element offset (GAE groups).
+    """
+    x = x.contiguous()
+    B, Cx, H, W = x.shape
+    HW = H * W
+    C0 = Cx if c0 is None else c0
+    n_out = B if n_out is None else n_out
+    if offsets0 is None:
+        offsets0 = _offsets(B, Cx * HW, x.device)
+    C1 = 0
+    if x1 is not None:
+        x1 = x1.contiguous()
+        C1 = x1.shape[1]
+        if offsets1 is None:
+            offsets1 = _offsets(B, C1 * HW, x.device)
+    cpad = (C0 + C1 + 7) // 8 * 8
+    out = torch.empty((n_out, H, W, cpad), dtype=_lib.act_dtype(precision), device=x.device)
+    _lib.check(_lib.lib().hsidm_nchw_to_nhwc(_lib.prec_id(precision), _lib.ptr(x), _lib.ptr(offsets0), C0,
+                                             _lib.ptr(x1), _lib.ptr(offsets1), C1, _lib.ptr(out), n_out, HW, cpad,
+                                             _lib.stream_ptr()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw(x, precision):
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsidm_nhwc_to_nchw(_lib.prec_id(precision), _lib.ptr(x), _lib.ptr(out), B, H * W, Cc,
+                                             _lib.stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+def ca_vector(part, nsplit, HW, w1, b1, w2, b2):
+    B, _, Cc, _ = part.shape
+    R = w1.shape[0]
+    ca = torch.empty((B, Cc), dtype=torch.float32, device=part.device)
+    _lib.check(_lib.lib().hsidm_ca_vector(_lib.ptr(part), nsplit, B, Cc, HW, R, _lib.ptr(w1), _lib.ptr(b1),
+                                          _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(ca), _lib.stream_ptr()), "ca_vector")
+    return ca
+
+
+def ca_apply(r, ca, skip, res_scale, precision, skip2=None):
+    B, H, W, Cc = r.shape
+    out = torch.empty_like(r)
+    _lib.check(_lib.lib().hsidm_ca_apply(_lib.prec_id(precision), _lib.ptr(r), _lib.ptr(ca), _lib.ptr(skip),
+                                         _lib.ptr(skip2), float(res_scale), _lib.ptr(out), B, H * W, Cc,
+                                         _lib.stream_ptr()), "ca_apply")
+    return out
+
+
+def overlap_average(dec, start, G, n_subs, B, Cc):
+    _, _, H, W = dec.shape
+    y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=dec.device)
+    _lib.check(_lib.lib().hsidm_overlap_average(_lib.ptr(dec), _lib.ptr(start), G, n_subs, B, Cc, H * W,
+                                                _lib.ptr(y), _lib.stream_ptr()), "overlap_average")
+    return y
+
+
+def philox_normal(shape, seed, stream_id, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().hsidm_philox_normal(_lib.ptr(out), out.numel(), int(seed), int(stream_id),
+                                              _lib.stream_ptr()), "philox_normal")
+    return out
+
+
+def p_sample_update(x, eps, coef, t_ptr, T, *, noise=None, noise_stride=0, seed=0, snap=None, inter=1):
+    _lib.check(_lib.lib().hsidm_p_sample_update(_lib.ptr(x), _lib.ptr(eps), _lib.ptr(coef), _lib.ptr(t_ptr), T,
+                                                _lib.ptr(noise), int(noise_stride), int(seed), x.numel(),
+                                                _lib.ptr(snap), int(inter),
+                                                _lib.stream_ptr()), "p_sample_update")
+
+
+def step_advance(t_ptr):
+    _lib.check(_lib.lib().hsidm_step_advance(_lib.ptr(t_ptr), _lib.stream_ptr()), "step_advance")

@@ -1,0 +1,170 @@
+/* hsidm.h - C ABI of libhsidm.so, the MI355X (gfx950) kernels behind the HSI-DMGASR denoising path.
+ *
+ * The reference (handsomewzy/HSI-DMGASR) is pure PyTorch: its "FFI" for this path is the set of
+ * torch.nn ops its nn.Modules call.  Each entry point below replaces one such op sequence; the
+ * reference file:line it stands in for is cited per function.  The Python modules in
+ * hsi-dmgasr_amd/ (same class names, constructor arguments and state_dict keys as the reference)
+ * bind these symbols with ctypes - see INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - the caller owns all memory (activations, packed weights, workspaces); nothing is allocated,
+ *     freed or synchronised inside; every call only enqueues kernels on `stream` (a hipStream_t
+ *     passed as void*), so calls can be captured into a hipGraph;
+ *   - return value: 0 on success, otherwise a negative HSIDM_E_* code or a positive hipError_t;
+ *   - internal activation tensors are NHWC ("pixel-major, channels contiguous") in the storage
+ *     type of the precision mode; module boundaries of the reference (NCHW fp32) are converted by
+ *     hsidm_nchw_to_nhwc / hsidm_nhwc_to_nchw.
+ */
+#ifndef HSIDM_H
+#define HSIDM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* precision modes */
+#define HSIDM_BF16  0   /* bf16 storage + bf16 MFMA operands, fp32 accumulate / statistics / softmax   */
+#define HSIDM_F32X3 1   /* fp32 storage; operands split bf16 hi+lo, 3 MFMA passes (fp32-grade parity) */
+
+/* error codes */
+#define HSIDM_OK             0
+#define HSIDM_E_BADARG      (-1)
+#define HSIDM_E_UNSUPPORTED (-2)
+
+/* input transforms fused into the convolution's operand staging */
+#define HSIDM_XF_NONE        0
+#define HSIDM_XF_AFFINE      1   /* y = scale[b,c]*x + shift[b,c]            (GroupNorm)            */
+#define HSIDM_XF_AFFINE_SILU 2   /* y = silu(scale*x + shift)                (GroupNorm + Swish)    */
+
+#define HSIDM_ACT_NONE  0
+#define HSIDM_ACT_LEAKY 1        /* LeakyReLU(0.01)                                                  */
+
+int hsidm_version(void);
+const char* hsidm_error_string(int code);
+
+/* ---- convolution ------------------------------------------------------------------------------
+ * One K-phase of hsidm_conv2d: an input tensor (optionally the channel concat of two tensors,
+ * replacing torch.cat((x, feats.pop()), 1), unet.py:259) with an optional fused GroupNorm(+Swish).
+ */
+typedef struct hsidm_conv_phase {
+    const void*  src0;        /* NHWC [B][Hin][Win][C0]                                             */
+    const void*  src1;        /* NHWC [B][Hin][Win][C1] or NULL                                     */
+    const float* gn_ab;       /* [B][C0+C1][2] (scale, shift) from hsidm_gn_finalize, or NULL       */
+    int32_t C0, C1;           /* multiples of 8                                                     */
+    int32_t transform;        /* HSIDM_XF_*                                                         */
+    int32_t ntaps;            /* 9 (3x3) or 1 (1x1)                                                 */
+} hsidm_conv_phase;
+
+/* Replaces, in one launch:
+ *   Block.forward            unet.py:83-91   GroupNorm -> Swish -> Conv2d 3x3          (phase 0)
+ *   FeatureWiseAffine        unet.py:42-50   h + Linear(t)[b,c]                         (film)
+ *   ResnetBlock tail         unet.py:105-111 block2(h) + res_conv(x) | + x             (phase 1 / res)
+ *   Upsample / Downsample    unet.py:58-74   nearest x2 folded into addressing / stride 2
+ *   SelfAttention qkv / out  unet.py:128,141 1x1 convs (+ residual)
+ *   common.ResBlock / ResAttentionBlock convs common.py:163-182,250-271 (LeakyReLU, 0.1*res + x)
+ * out = res_scale * act(conv + bias[c] + film[b,c]) + res.
+ */
+typedef struct hsidm_conv_desc {
+    hsidm_conv_phase ph[2];
+    int32_t nphase;           /* 1, or 2 = phase 1 is a fused 1x1 projection of a second input      */
+    const void*  w_hi;        /* packed bf16 [step][Cout_pad][BK], step = (phase, chunk, tap)       */
+    const void*  w_lo;        /* low halves (HSIDM_F32X3 only)                                      */
+    const float* bias;        /* [Cout] or NULL                                                     */
+    const float* film;        /* [B][film_stride], pre-offset to this layer's columns, or NULL      */
+    int32_t film_stride;
+    const void*  res;         /* residual in the layout/type of out, or NULL                        */
+    float        res_scale;
+    void*        out;         /* NHWC [B][Hout][Wout][Cout]; NCHW fp32 when out_nchw                */
+    float*       stats;       /* optional [B][Cout][2] (sum, sum of squares) of out, atomically
+                                 accumulated (must be zeroed by the caller), or NULL                */
+    int32_t B, Hin, Win, Hout, Wout, Cout;
+    int32_t ksize;            /* 3 or 1 (phase 0)                                                   */
+    int32_t stride;           /* 1 or 2                                                             */
+    int32_t ups;              /* 1: nearest x2 upsample folded in (Hout = 2*Hin)                    */
+    int32_t act;              /* HSIDM_ACT_*                                                        */
+    int32_t out_nchw;         /* 1: write NCHW fp32 (network outputs)                               */
+    int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3                                           */
+    int32_t bn;               /* cout slice the weights were packed for: 32, 64 or 128             */
+} hsidm_conv_desc;
+
+int hsidm_conv2d(const hsidm_conv_desc* d, void* stream);
+/* K-chunk (input channels per packed step) of a precision mode: 64 for BF16, 32 for F32X3. */
+int hsidm_conv_bk(int prec);
+
+/* ---- GroupNorm statistics (nn.GroupNorm inside Block / SelfAttention, unet.py:84,121) ----------
+ * partial: per-(image, split, channel) sum and sum of squares of a (concatenated) NHWC tensor;
+ * finalize: -> per-(image, channel) (scale, shift) = (rstd*gamma, beta - mean*rstd*gamma).
+ * `part` is [B][nsplit][C][2] floats.  hsidm_conv2d's `stats` output is a valid `part` with nsplit=1.
+ */
+int hsidm_gn_partial(int prec, const void* src0, const void* src1, int C0, int C1, int B, int HW,
+                     int nsplit, float* part, void* stream);
+int hsidm_gn_finalize(const float* part, int nsplit, int B, int C, int HW, int groups,
+                      const float* gamma, const float* beta, float eps, float* gn_ab, void* stream);
+
+/* ---- noise-level embedding + all FiLM projections of one UNet call ---------------------------------
+ * PositionalEncoding + noise_level_mlp (unet.py:23-31,182-187) and the Linear of every
+ * FeatureWiseAffine (unet.py:38-49) for all ResnetBlocks at once: film[b][f] = Wf[f,:]·t_b + bf[f].
+ * gamma: [B] noise levels, or NULL with (level_table, t_ptr): gamma = level_table[*t_ptr + 1]
+ * (diffusion.py:154-155) read on the device so that a captured graph can be replayed per step.
+ * t_emb (optional, [B][dim]): use this embedding instead of running the MLP (ResnetBlock.forward(x, time_emb)
+ * called on its own); t_out (optional, [B][dim]): also return the embedding.
+ */
+int hsidm_noise_film(const float* gamma, const float* level_table, const int32_t* t_ptr, const float* t_emb,
+                     int B, int dim, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* wf, const float* bf, int F, float* film, float* t_out, void* stream);
+
+/* ---- self-attention core (unet.py:130-140): softmax(q k^T / sqrt(C)) v, single head ---------------
+ * qkv: NHWC [B][N][3C] (q | k | v channel thirds, unet.py:129), out: [B][N][C].  N <= 1024.
+ */
+int hsidm_attention(int prec, const void* qkv, void* out, int B, int N, int C, void* stream);
+
+/* ---- layout conversion at the reference's module boundaries ----------------------------------------
+ * nchw_to_nhwc: out[e][p][c] for c < Cpad (multiple of 8): channel c comes from fp32 NCHW planes
+ * src0 + off0[e] + c*HW (c < C0), src1 + off1[e] + (c-C0)*HW (C0 <= c < C0+C1), else 0.
+ * off0/off1: per-output-image element offsets (device int64); this one call implements
+ * torch.cat([cond, x], 1) (diffusion.py:158) and the spectral-group slicing x[:, s:e]
+ * (AE.py:316-321) with all groups stacked on the batch axis.
+ */
+int hsidm_nchw_to_nhwc(int prec, const float* src0, const int64_t* off0, int C0,
+                       const float* src1, const int64_t* off1, int C1,
+                       void* out, int Bout, int HW, int Cpad, void* stream);
+int hsidm_nhwc_to_nchw(int prec, const void* src, float* out, int B, int HW, int C, void* stream);
+
+/* ---- reverse-diffusion update (diffusion.py:142-175) -------------------------------------------------
+ * x <- c1*clamp(a*x - b*eps, -1, 1) + c2*x + [t>0] * z * exp(0.5*logvar), t = *t_ptr.
+ * coef: [T][5] = (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1,
+ * posterior_mean_coef2, posterior_log_variance_clipped).  z = noise[(T-1-t)*noise_stride + i] when
+ * noise != NULL (stored noise; noise_stride = n for a [T-1][n] table, 0 for one buffer refilled by the
+ * caller before every step), otherwise Philox4x32-10(seed, stream = t) + Box-Muller.
+ * snap (optional): x is also copied to snap + slot*n when t % inter == 0 (slot counts snapshots,
+ * diffusion.py:196-197).
+ */
+int hsidm_p_sample_update(float* x, const float* eps, const float* coef, const int32_t* t_ptr, int T,
+                          const float* noise, int64_t noise_stride, uint64_t seed, int64_t n,
+                          float* snap, int32_t inter, void* stream);
+/* t <- t - 1 (one thread); separate launch so that every kernel of a step reads the same t. */
+int hsidm_step_advance(int32_t* t_ptr, void* stream);
+/* out[i] = N(0,1) from Philox4x32-10(seed, stream), i < n  (x_T: stream = T). */
+int hsidm_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* ---- group-autoencoder pieces (AE.py / common.py) -----------------------------------------------------
+ * CALayer (common.py:231-247): ca[b][c] = sigmoid(W2 relu(W1 mean_b + b1) + b2), mean from `part`.
+ */
+int hsidm_ca_vector(const float* part, int nsplit, int B, int C, int HW, int R,
+                    const float* w1, const float* b1, const float* w2, const float* b2,
+                    float* ca, void* stream);
+/* out = res_scale * r * ca[b][c] + skip (+ skip2)   (ResAttentionBlock tail common.py:267-271,
+ * plus the SSPN skip AE.py:137-139 when skip2 != NULL); NHWC tensors of the mode's storage type. */
+int hsidm_ca_apply(int prec, const void* r, const float* ca, const void* skip, const void* skip2,
+                   float res_scale, void* out, int B, int HW, int C, void* stream);
+/* Overlap-average of the decoded groups (AE.py:286-295): dec NCHW fp32 [B*G][n_subs][HW] ->
+ * y NCHW fp32 [B][C][HW]; start[g] device int32. */
+int hsidm_overlap_average(const float* dec, const int32_t* start, int G, int n_subs, int B, int C,
+                          int HW, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSIDM_H */

@@ -1,0 +1,43 @@
+"""Helpers for the GPU parity tests: build product modules with the synthetic weights of tests/golden/synth.py,
+compare with the oracle, and log every measured error to gpurun_out/parity.jsonl (kept by gpurun)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from helpers import rel_err
+from synth import synth_param
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# tolerances (relative Frobenius error vs the fp32 CPU oracle)
+TOL = {"fp32": 1e-3,    # north_star: 1e-3 relative for the fp32 path (measured ~1e-5)
+       "bf16": 4e-2}    # bf16 operands: gated on PSNR/SAM for whole pipelines, loose bound per op
+
+
+def fill_synth(module, prefix, seed=0):
+    sd = {k: torch.from_numpy(synth_param(prefix + k, tuple(v.shape), seed)) for k, v in module.state_dict().items()
+          if not k.startswith("_")}
+    module.load_state_dict(sd, strict=False)
+    return {k: v.clone() for k, v in sd.items()}
+
+
+def log_err(name, precision, err, extra=None):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    rec = {"test": name, "precision": precision, "rel_err": err}
+    if extra:
+        rec.update(extra)
+    with open(os.path.join(ROOT, "gpurun_out", "parity.jsonl"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+
+
+def check(name, precision, got, want, tol=None):
+    got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().float().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), "%s: non-finite output" % name
+    e = rel_err(got, want)
+    log_err(name, precision, e)
+    tol = TOL[precision] if tol is None else tol
+    assert e < tol, "%s [%s]: rel err %.3e >= %.1e" % (name, precision, e, tol)
+    return e

@@ -1,0 +1,215 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors,
+for every UNet building block, whole networks and the sampler."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import check, fill_synth
+from helpers import jload, load_npz, sub_shapes, synth_sd, synth_tensor
+
+pytestmark = pytest.mark.gpu
+PRECS = ["fp32", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops_npz():
+    return load_npz("ops.npz")
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_library_loaded_in_process(dev):
+    from hsi_dmgasr_amd import _lib
+    assert _lib.lib().hsidm_version() >= 1
+    assert any("libhsidm.so" in l for l in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_block(dev, ops_npz, prec):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    m = unet.Block(64, 48, groups=32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, "block.")
+    check("block", prec, m(G(ops_npz["block.x"], dev)), ops_npz["block.y"])
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("tag,cin,cout", [("res_same", 64, 64), ("res_proj", 32, 64), ("res_cat", 96, 32)])
+def test_resnet_block(dev, ops_npz, prec, tag, cin, cout):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    m = unet.ResnetBlock(cin, cout, noise_level_emb_dim=32, norm_groups=32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, tag + ".")
+    y = m(G(ops_npz[tag + ".x"], dev), G(ops_npz[tag + ".t"], dev))
+    check(tag, prec, y, ops_npz[tag + ".y"])
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_resnet_block_two_pointer_concat(dev, ops_npz, prec):
+    """Skip-concat input read in place from two tensors (GroupNorm group 21 straddles the seam at 64)."""
+    from hsi_dmgasr_amd import ops
+    from hsi_dmgasr_amd.sr3_modules import unet
+    m = unet.ResnetBlock(96, 32, noise_level_emb_dim=32, norm_groups=32).to(dev).eval()
+    fill_synth(m, "res_cat.")
+    x = G(ops_npz["res_cat.x"], dev)
+    t = G(ops_npz["res_cat.t"], dev).reshape(2, 32).contiguous()
+    lin = m.noise_func.noise_func[0]
+    film = ops.noise_film(2, 32, None, lin.weight, lin.bias, t_emb=t)
+    a = ops.to_nhwc(x[:, :64].contiguous(), prec)
+    b = ops.to_nhwc(x[:, 64:].contiguous(), prec)
+    y = ops.to_nchw(m._run(a, b, film, prec), prec)
+    check("res_cat_two_pointer", prec, y, ops_npz["res_cat.y"])
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_self_attention(dev, ops_npz, prec):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    m = unet.SelfAttention(64, norm_groups=32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, "attn.")
+    check("attn", prec, m(G(ops_npz["attn.x"], dev)), ops_npz["attn.y"])
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_up_down(dev, ops_npz, prec):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    m = unet.Upsample(32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, "up.")
+    check("up", prec, m(G(ops_npz["up.x"], dev)), ops_npz["up.y"])
+    m = unet.Downsample(32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, "down.")
+    check("down", prec, m(G(ops_npz["down.x"], dev)), ops_npz["down.y"])
+
+
+def test_noise_embedding(dev, ops_npz):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16).to(dev).eval()
+    sd = synth_sd(sub_shapes(jload(ops_npz["shapes_json"]), "mlp."), "mlp.")
+    u.load_state_dict(sd, strict=False)
+    t = u.noise_embedding(G(ops_npz["mlp.gamma"], dev))
+    check("noise_level_mlp", "fp32", t.reshape(3, 32), ops_npz["mlp.y"].reshape(3, 32), tol=1e-4)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(1, 40, 13, 21), (3, 64, 5, 5), (2, 72, 24, 40)])
+def test_block_ragged_shapes(dev, prec, shape):
+    """Edge cases: sizes that are not multiples of the 8x16 tile, partial tiles, odd batch (two-image tiles)."""
+    from hsi_dmgasr_amd.sr3_modules import unet
+    from oracle import sr3_unet
+    b, c, h, w = shape
+    m = unet.Block(c, 24, groups=8).to(dev).eval()
+    m.precision = prec
+    sd = fill_synth(m, "ragged.")
+    x = synth_tensor("ragged.x%s" % (shape,), shape)
+    want = sr3_unet.block(sd, "", torch.from_numpy(x), 8)
+    check("block_ragged%s" % (shape,), prec, m(G(x, dev)), want)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("hw", [(7, 9), (16, 16), (33, 18)])
+def test_down_up_ragged(dev, prec, hw):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    from oracle import sr3_unet
+    x = synth_tensor("du.x%s" % (hw,), (2, 32) + hw)
+    for cls, fn, tag in ((unet.Downsample, sr3_unet.downsample, "down"), (unet.Upsample, sr3_unet.upsample, "up")):
+        m = cls(32).to(dev).eval()
+        m.precision = prec
+        sd = fill_synth(m, "du_%s." % tag)
+        check("%s_ragged%s" % (tag, hw), prec, m(G(x, dev)), fn(sd, "", torch.from_numpy(x)))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_unet_forward_golden(dev, prec, name):
+    from hsi_dmgasr_amd.sr3_modules import unet
+    g = load_npz("unets.npz")
+    cfg = jload(g[name + ".cfg_json"])
+    u = unet.UNet(in_channel=cfg["in_channel"], out_channel=cfg["out_channel"], inner_channel=cfg["inner_channel"],
+                  norm_groups=cfg["norm_groups"], channel_mults=cfg["channel_mults"], attn_res=cfg["attn_res"],
+                  res_blocks=cfg["res_blocks"], dropout=0.2, image_size=cfg["image_size"], precision=prec).to(dev).eval()
+    fill_synth(u, "unet_%s." % name)
+    y = u(G(g[name + ".x"], dev), G(g[name + ".gamma"], dev))
+    check("unet_" + name, prec, y, g[name + ".y"], tol={"fp32": 1e-3, "bf16": 6e-2}[prec])
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_unet_full_size_golden(dev, prec):
+    """Shipped 97.8 M-parameter configuration, B=1, 6x128x128, against the output captured from the reference."""
+    from hsi_dmgasr_amd.sr3_modules import unet
+    g = load_npz("unets.npz")
+    cfg = jload(g["full.cfg_json"])
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=cfg["channel_mults"],
+                  attn_res=cfg["attn_res"], res_blocks=2, dropout=0.2, image_size=128, precision=prec).to(dev).eval()
+    fill_synth(u, "unet_full.")
+    x = G(synth_tensor("unet_full.x", (1, 6, 128, 128)), dev)
+    y = u(x, G(g["full.gamma"], dev))
+    check("unet_full", prec, y, g["full.y"], tol={"fp32": 1e-3, "bf16": 8e-2}[prec])
+
+
+def test_philox_matches_oracle(dev):
+    from hsi_dmgasr_amd import ops
+    from oracle import philox
+    for n, seed, stream in ((1000, 7, 3), (4097, (1 << 40) + 5, 999)):
+        z = ops.philox_normal((n,), seed, stream, dev).cpu().numpy()
+        ref = philox.normal(seed, stream, n)
+        assert np.max(np.abs(z - ref)) < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["fp32"])
+@pytest.mark.parametrize("name", ["T4", "T24"])
+def test_sampler_stored_noise_golden(dev, prec, name):
+    """p_sample_loop with the x_T / per-step noise captured from the reference run: continous frames and the
+    ret_img[-1] convention."""
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    g = load_npz("sampler.npz")
+    cfg = jload(load_npz("unets.npz")["tiny.cfg_json"])
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision=prec).to(dev).eval()
+    fill_synth(u, "unet_tiny.")
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(jload(g[name + ".opt_json"]), dev)
+    cond = G(g[name + ".cond"], dev)
+    x, snap, _ = gd._reverse(cond, tuple(cond.shape), True, x_T=G(g[name + ".x_T"], dev), noise=G(g[name + ".noise"], dev))
+    frames = torch.cat([cond, snap.reshape((-1,) + tuple(cond.shape[1:]))], dim=0)
+    check("sampler_%s_continous" % name, prec, frames, g[name + ".continous"], tol=2e-3)
+    check("sampler_%s_last" % name, prec, frames[-1], g[name + ".last"], tol=2e-3)
+
+
+def test_sampler_api_shapes_and_philox_mode(dev):
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import diffusion as odiff, sr3_unet
+    cfg = jload(load_npz("unets.npz")["tiny.cfg_json"])
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision="fp32").to(dev).eval()
+    sd = fill_synth(u, "unet_tiny.")
+    opt = dict(schedule="cosine", n_timestep=12, linear_start=1e-6, linear_end=1e-2)
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(opt, dev)
+    cond = G(synth_tensor("api.cond", (3, 3, 16, 16)), dev)
+    assert gd.super_resolution(cond, continous=False).shape == (3, 16, 16)
+    inter = 1 | (12 // 10)
+    assert gd.super_resolution(cond, continous=True).shape == ((1 + (11 // inter + 1)) * 3, 3, 16, 16)
+    # Philox mode: device noise == oracle noise, so the whole chain is comparable
+    gd.noise, gd.seed = "philox", 2024
+    got = gd.p_sample_loop_batched(cond)
+    sched = odiff.noise_schedule(opt)
+    den = lambda x, gam: sr3_unet.unet_forward(sd, cfg, x, gam)
+    nf = odiff.philox_noise_fn(2024, (3, 3, 16, 16))
+    x_T = nf(12)
+    xo = x_T
+    for i in reversed(range(12)):
+        xo = odiff.p_sample_step(den, sched, xo, cond.cpu(), i, nf(i) if i > 0 else None)
+    check("sampler_philox_T12", "fp32", got, xo, tol=2e-3)
