@@ -43,7 +43,7 @@ SIGNATURES = {
     "hsidm_nchw_to_nhwc": [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     "hsidm_nhwc_to_nchw": [_i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "hsidm_p_sample_update": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _u64, _i64, _vp, _i32, _vp],
-    "hsidm_step_advance": [_vp, _vp],
+    "hsidm_step_advance": [_vp, _i32, _vp],
     "hsidm_philox_normal": [_vp, _i64, _u64, _u32, _vp],
     "hsidm_ca_vector": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "hsidm_ca_apply": [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp],

@@ -88,7 +88,11 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* __restrict_
     }
 }
 
-__global__ void step_advance_kernel(int32_t* t_ptr) { *t_ptr = *t_ptr - 1; }
+__global__ void step_advance_kernel(int32_t* t_ptr, int32_t wrap_T) {
+    int32_t t = *t_ptr - 1;
+    if (t < 0 && wrap_T > 0) t = wrap_T - 1;
+    *t_ptr = t;
+}
 
 // ---- NCHW fp32 planes -> NHWC (storage type), with channel concat / slicing / zero padding -----------
 template <typename ActT>
@@ -202,9 +206,9 @@ extern "C" int hsidm_p_sample_update(float* x, const float* eps, const float* co
     return (int)hipGetLastError();
 }
 
-extern "C" int hsidm_step_advance(int32_t* t_ptr, void* stream) {
+extern "C" int hsidm_step_advance(int32_t* t_ptr, int32_t wrap_T, void* stream) {
     if (!t_ptr) return HSIDM_E_BADARG;
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_ptr);
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_ptr, wrap_T);
     return (int)hipGetLastError();
 }
 

@@ -106,8 +106,27 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
     d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, int(bool(ups)), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
-    _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
+    if _conv_probe is None:
+        _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
+    else:   # measurement hook (bench.py): HIP events on the launch stream around this one kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
+        e1.record()
+        k_total = pw.cin * pw.ksize * pw.ksize + pw.proj_cin
+        _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize,
+                                stride=stride, ups=bool(ups), cin=pw.cin, cout=pw.cout, hw=(Ho, Wo),
+                                out_nchw=pw.out_nchw, tile=0 if Wo >= 16 else 1))
     return out
+
+
+_conv_probe = None
+
+
+def set_conv_probe(records):
+    """records: a list to append per-launch {events, flops, shape} dicts to, or None to switch the hook off."""
+    global _conv_probe
+    _conv_probe = records
 
 
 def gn_scale_shift(x0, x1, gamma, beta, groups, precision, eps=1e-5):
@@ -247,5 +266,5 @@ def p_sample_update(x, eps, coef, t_ptr, T, *, noise=None, noise_stride=0, seed=
                                                 _lib.stream_ptr()), "p_sample_update")
 
 
-def step_advance(t_ptr):
-    _lib.check(_lib.lib().hsidm_step_advance(_lib.ptr(t_ptr), _lib.stream_ptr()), "step_advance")
+def step_advance(t_ptr, wrap_T=0):
+    _lib.check(_lib.lib().hsidm_step_advance(_lib.ptr(t_ptr), int(wrap_T), _lib.stream_ptr()), "step_advance")

@@ -50,6 +50,74 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2,
     raise NotImplementedError(schedule)
 
 
+class ReverseRun:
+    """State of one reverse-diffusion chain batch on the device: x_t, the step counter t (device int32),
+    noise source, optional snapshot buffer, and the captured HIP graph of one step.
+
+    step()  : enqueue one reverse step (graph replay once captured);
+    run_all(): the T steps of p_sample_loop.
+    With wrap=True the counter restarts at T-1 after t = 0 (benchmark loops longer than one chain)."""
+
+    def __init__(self, gd, cond, shape, continous, x_T, noise, precision, wrap):
+        dev = gd.betas.device
+        T = gd.num_timesteps
+        self.gd, self.T, self.precision, self.wrap = gd, T, precision, wrap
+        self.inter = 1 | (T // 10)
+        if x_T is not None:
+            self.x = x_T.to(dev, torch.float32).contiguous().clone()
+        elif gd.noise == "philox":
+            self.x = ops.philox_normal(shape, gd.seed, T, dev)
+        else:
+            self.x = torch.randn(shape, device=dev)
+        self.first = self.x.clone() if continous else None
+        n = self.x.numel()
+        # per-step noise: caller-supplied [T-1, *shape] (index k <-> t = T-1-k), the Philox generator inside the
+        # update kernel, or a fresh torch.randn draw per step (reference behaviour, diffusion.py:174)
+        self.stored, self.zbuf, self.stride = None, None, 0
+        if noise is not None:
+            self.stored = noise.to(dev, torch.float32).contiguous()
+            assert self.stored.shape[0] >= T - 1 and self.stored[0].numel() == n
+            self.stride = n
+        elif gd.noise != "philox":
+            self.zbuf = torch.empty_like(self.x)
+        nsnap = (T - 1) // self.inter + 1
+        self.snap = torch.empty((nsnap,) + tuple(shape), dtype=torch.float32, device=dev) if continous else None
+        self.t_ptr = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
+        self.cond = None if cond is None else cond.to(dev, torch.float32).contiguous()
+        self.fused = isinstance(gd.denoise_fn, UNet)
+        self.graph = None
+        self.steps_done = 0
+
+    def _enqueue(self):
+        gd = self.gd
+        eps = gd._denoise(self.cond, self.x, self.t_ptr, self.precision)
+        if self.zbuf is not None:
+            self.zbuf.normal_()
+        ops.p_sample_update(self.x, eps.contiguous(), gd._coef, self.t_ptr, self.T,
+                            noise=self.stored if self.stored is not None else self.zbuf, noise_stride=self.stride,
+                            seed=gd.seed, snap=self.snap, inter=self.inter)
+        ops.step_advance(self.t_ptr, self.T if self.wrap else 0)
+
+    def step(self):
+        if not (self.fused and self.gd.use_graph):
+            self._enqueue()
+        elif self.steps_done == 0:
+            self._enqueue()                              # eager first step: packs weights, warms the allocator
+        else:
+            if self.graph is None:
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._enqueue()                      # recorded, not executed
+            self.graph.replay()
+        self.steps_done += 1
+
+    def run_all(self):
+        for _ in range(self.T):
+            self.step()
+        return self.x
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, denoise_fn, image_size, channels=31, loss_type="l1", conditional=True, schedule_opt=None):
         super().__init__()
@@ -117,54 +185,16 @@ class GaussianDiffusion(nn.Module):
         inp = torch.cat([cond, x], dim=1) if cond is not None else x
         return fn(inp, lvl)
 
+    def make_run(self, cond, shape=None, continous=False, x_T=None, noise=None, precision=None, wrap=False):
+        """Device-resident reverse process over `cond` (see ReverseRun)."""
+        shape = tuple(cond.shape) if shape is None else tuple(shape)
+        return ReverseRun(self, cond, shape, continous, x_T, noise, precision, wrap)
+
     def _reverse(self, cond, shape, continous, x_T=None, noise=None, precision=None):
         """Runs t = T-1 .. 0.  Returns (final x [B,C,H,W], snapshots [K,B,C,H,W] or None, x_T or None)."""
-        dev = self.betas.device
-        T = self.num_timesteps
-        inter = 1 | (T // 10)
-        if x_T is not None:
-            x = x_T.to(dev, torch.float32).contiguous().clone()
-        elif self.noise == "philox":
-            x = ops.philox_normal(tuple(shape), self.seed, T, dev)
-        else:
-            x = torch.randn(tuple(shape), device=dev)
-        first = x.clone() if continous else None
-        n = x.numel()
-        # per-step noise: caller-supplied [T-1, *shape] (index k <-> t = T-1-k), the Philox generator inside the
-        # update kernel, or a fresh torch.randn draw per step (reference behaviour, diffusion.py:174)
-        stored, zbuf, stride = None, None, 0
-        if noise is not None:
-            stored = noise.to(dev, torch.float32).contiguous()
-            assert stored.shape[0] >= T - 1 and stored[0].numel() == n
-            stride = n
-        elif self.noise != "philox":
-            zbuf = torch.empty_like(x)
-        nsnap = (T - 1) // inter + 1
-        snap = torch.empty((nsnap,) + tuple(shape), dtype=torch.float32, device=dev) if continous else None
-        t_ptr = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
-        cond_c = None if cond is None else cond.to(dev, torch.float32).contiguous()
-        fused = isinstance(self.denoise_fn, UNet)
-
-        def one_step():
-            eps = self._denoise(cond_c, x, t_ptr, precision)
-            if zbuf is not None:
-                zbuf.normal_()
-            ops.p_sample_update(x, eps.contiguous(), self._coef, t_ptr, T, noise=stored if stored is not None else zbuf,
-                                noise_stride=stride, seed=self.seed, snap=snap, inter=inter)
-            ops.step_advance(t_ptr)
-
-        if fused and self.use_graph and T > 2:
-            one_step()                                   # eager first step: packs weights, warms the allocator
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                one_step()
-            for _ in range(T - 2):
-                g.replay()
-        else:
-            for _ in range(T):
-                one_step()
-        return x, snap, first
+        run = ReverseRun(self, cond, tuple(shape), continous, x_T, noise, precision, False)
+        run.run_all()
+        return run.x, run.snap, run.first
 
     @torch.no_grad()
     def p_sample_loop(self, x_in, continous=False):

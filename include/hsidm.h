@@ -144,8 +144,9 @@ int hsidm_nhwc_to_nchw(int prec, const void* src, float* out, int B, int HW, int
 int hsidm_p_sample_update(float* x, const float* eps, const float* coef, const int32_t* t_ptr, int T,
                           const float* noise, int64_t noise_stride, uint64_t seed, int64_t n,
                           float* snap, int32_t inter, void* stream);
-/* t <- t - 1 (one thread); separate launch so that every kernel of a step reads the same t. */
-int hsidm_step_advance(int32_t* t_ptr, void* stream);
+/* t <- t - 1 (one thread); separate launch so that every kernel of a step reads the same t.
+ * wrap_T > 0: restart at wrap_T - 1 after t = 0 (benchmark loops longer than one chain). */
+int hsidm_step_advance(int32_t* t_ptr, int32_t wrap_T, void* stream);
 /* out[i] = N(0,1) from Philox4x32-10(seed, stream), i < n  (x_T: stream = T). */
 int hsidm_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t stream_id, void* stream);
 

@@ -11,7 +11,20 @@ if GOLDEN not in sys.path:
     sys.path.insert(0, GOLDEN)
 
 
+def _usable_cpus():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(min(_usable_cpus(), 32))     # GPU boxes expose 256 CPUs behind a small cgroup quota
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
