@@ -1,0 +1,31 @@
+"""Per-image inference path: encode the low-resolution cube, denoise every spectral-group latent, decode.
+
+Counterpart of the reference's validation loop (sr_gae.py:436-494): there the G groups of one image are
+sampled by G sequential batch-1 p_sample_loop calls with a device->host->device round trip per group
+(sr_gae.py:458-465); here all groups of all patches of this rank form one batch that stays on the device.
+"""
+import torch
+
+from . import parallel
+
+
+@torch.no_grad()
+def super_resolve(gae, gd, sr_cubes, x_T=None, noise=None, precision=None):
+    """sr_cubes [P, C, H, W] in [0,1] (bicubic-upsampled LR cubes) -> (SR cubes [P, C, H, W] clamped to [0,1],
+    denoised latents [P, G, 3, H, W]).  x_T / noise (optional): [P*G,3,H,W] / [T-1, P*G,3,H,W] injected noise."""
+    P, C, H, W = sr_cubes.shape
+    z = gae.encode_batched(sr_cubes)                               # [P, G, 3, H, W]
+    G = z.shape[1]
+    cond = z.reshape(P * G, 3, H, W).contiguous()
+    x0 = gd.p_sample_loop_batched(cond, x_T=x_T, noise=noise, precision=precision)
+    lat = x0.view(P, G, 3, H, W)
+    y = gae.decode_batched(lat, C)
+    return y.clamp_(0.0, 1.0), lat
+
+
+@torch.no_grad()
+def super_resolve_sharded(gae, gd, sr_cubes_all, precision=None):
+    """Patches sharded contiguously over the ranks of the default process group; every rank returns all cubes.
+    (weights are expected to have been broadcast once with parallel.broadcast_module_)."""
+    fn = lambda cubes: super_resolve(gae, gd, cubes, precision=precision)[0]
+    return parallel.run_sharded(sr_cubes_all, fn)

@@ -1,0 +1,176 @@
+"""CPU: the host side of the product - C-ABI surface, ctypes mirror, weight packing, module schemas, schedule
+buffers, fail-loud behaviour without a GPU, and the N>1 sharding path on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import jload, load_npz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hsi_dmgasr_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "hsidm.h")).read()
+    declared = set(re.findall(r"\b(hsidm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 16
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), "libhsidm.so does not export %s" % name
+    assert declared - {"hsidm_error_string"} == set(_lib.SIGNATURES), "ctypes table out of sync with hsidm.h"
+    assert _lib.lib().hsidm_version() == 1
+    assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32
+    assert b"invalid" in _lib.lib().hsidm_error_string(-1)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    from hsi_dmgasr_amd import _lib
+    exe = str(tmp_path / "abi_probe")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_probe.c"), "-o", exe])
+    rows = [list(map(int, l.split())) for l in subprocess.check_output([exe]).decode().strip().splitlines()]
+    assert rows[0] == [ctypes.sizeof(_lib.ConvPhase), ctypes.sizeof(_lib.ConvDesc)]
+    P, D = _lib.ConvPhase, _lib.ConvDesc
+    assert rows[1] == [P.src0.offset, P.src1.offset, P.gn_ab.offset, P.C0.offset, P.C1.offset, P.transform.offset, P.ntaps.offset]
+    assert rows[2] == [D.nphase.offset, D.w_hi.offset, D.w_lo.offset, D.bias.offset, D.film.offset, D.film_stride.offset,
+                       D.res.offset, D.res_scale.offset, D.out.offset, D.stats.offset, D.B.offset, D.ksize.offset,
+                       D.prec.offset, D.bn.offset]
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from hsi_dmgasr_amd import _lib
+    L = _lib.lib()
+    assert L.hsidm_conv2d(None, None) == -1
+    d = _lib.ConvDesc()
+    assert L.hsidm_conv2d(ctypes.byref(d), None) == -1
+    assert L.hsidm_attention(0, None, None, 1, 64, 64, None) == -1
+    assert L.hsidm_gn_partial(0, None, None, 64, 0, 1, 64, 1, None, None) == -1
+    assert L.hsidm_philox_normal(None, 10, 0, 0, None) == -1
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from hsi_dmgasr_amd import gae
+    from hsi_dmgasr_amd.sr3_modules import unet
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1, image_size=16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        u(torch.zeros(1, 6, 16, 16), torch.zeros(1, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        unet.Block(32, 32)(torch.zeros(1, 32, 8, 8))
+    g = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g.encode(torch.zeros(1, 31, 8, 8))
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    from hsi_dmgasr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhsidm.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.lib()
+
+
+@pytest.mark.parametrize("prec,bk", [("bf16", 64), ("fp32", 32)])
+def test_packed_conv_layout_roundtrip(prec, bk):
+    """[step][Cout_pad][BK] with step = (chunk, tap) then the fused 1x1 projection steps; hi+lo reassemble to fp32."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(40, 70, 3, 3, generator=g)
+    pw = torch.randn(40, 24, 1, 1, generator=g)
+    b, pb = torch.randn(40, generator=g), torch.randn(40, generator=g)
+    pk = ops.PackedConv(w, b, prec, proj_weight=pw, proj_bias=pb)
+    assert pk.bn == 64 and pk.cin == 72 and pk.proj_cin == 24
+    nch = (72 + bk - 1) // bk
+    npj = (24 + bk - 1) // bk
+    assert pk.w_hi.shape == (nch * 9 + npj, 64, bk)
+    full = pk.w_hi.float() + (pk.w_lo.float() if pk.w_lo is not None else 0)
+    tol = 2e-5 if prec == "fp32" else 1e-2      # bf16 hi+lo carries ~16 mantissa bits
+    for (n, c, ky, kx) in [(0, 0, 0, 0), (39, 69, 2, 2), (17, 33, 1, 2), (5, 64, 0, 1)]:
+        step = (c // bk) * 9 + ky * 3 + kx
+        assert abs(float(full[step, n, c % bk]) - float(w[n, c, ky, kx])) <= tol * max(1.0, abs(float(w[n, c, ky, kx])))
+    assert float(full[nch * 9 + 0, 3, 7]) == pytest.approx(float(pw[3, 7, 0, 0]), abs=tol * 4)
+    assert torch.all(full[:, 40:, :] == 0) and torch.all(full[(70 // bk) * 9, :, 70 % bk:] == 0)
+    assert torch.allclose(pk.bias, b + pb)
+
+
+def test_unet_and_gae_schema_match_the_reference_checkpoints():
+    from hsi_dmgasr_amd import gae
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import gae as ogae, sr3_unet
+    cfg = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8],
+               attn_res=[16], res_blocks=2, image_size=128)
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, channel_mults=[1, 2, 4, 8, 8], attn_res=[16],
+                  res_blocks=2, dropout=0.2, image_size=128)
+    shp = sr3_unet.unet_param_shapes(cfg)
+    sd = u.state_dict()
+    assert set(sd) == set(shp) and all(tuple(sd[k].shape) == tuple(shp[k]) for k in shp)
+    gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, conditional=True)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), "cpu")
+    keys = set(gd.state_dict())
+    assert len(keys) == 374 and all(k.startswith("denoise_fn.") or k in keys for k in keys)
+    g = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in load_npz("gae_cav_state.npz").items()})   # pretrained CAVE weights
+    assert set(g.state_dict()) == set(ogae.gae_param_shapes(8, 31, 64))
+
+
+@pytest.mark.parametrize("name", ["cos20", "cos1000", "lin2000", "quad50", "warm50"])
+def test_product_schedule_buffers_match_reference(name):
+    from hsi_dmgasr_amd.sr3_modules import diffusion
+    g = load_npz("schedules.npz")
+    gd = diffusion.GaussianDiffusion(torch.nn.Identity(), image_size=16, channels=3, conditional=True)
+    gd.set_new_noise_schedule(jload(g[name + ".opt_json"]), "cpu")
+    for k, v in gd.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g["%s.%s" % (name, k)], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(gd.sqrt_alphas_cumprod_prev, g[name + ".sqrt_alphas_cumprod_prev"], rtol=1e-14)
+    assert gd.num_timesteps == jload(g[name + ".opt_json"])["n_timestep"]
+    with pytest.raises(NotImplementedError):
+        diffusion.make_beta_schedule("bogus", 10)
+
+
+def test_shard_ranges_partition_the_patches():
+    from hsi_dmgasr_amd import parallel
+    for n in (0, 1, 7, 8, 9, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from hsi_dmgasr_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different weights per rank before the broadcast
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.GroupNorm(4, 8), torch.nn.Linear(8, 8))
+    net.register_buffer("tab", torch.randn(5))
+    parallel.broadcast_module_(net, src=0, bucket_bytes=256)      # tiny buckets: exercises the flush logic
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [net.tab])
+    patches = torch.arange(5 * 2 * 3, dtype=torch.float32).reshape(5, 2, 3)       # 5 patches over 2 ranks: 3 + 2
+    calls = []
+
+    def fn(x):
+        calls.append(x.shape[0])
+        return x * 2 + 1
+    got = parallel.run_sharded(patches, fn)
+    torch.save({"flat": flat, "got": got, "calls": calls}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_shard_gather(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])                      # weights identical after the broadcast
+    want = torch.arange(30, dtype=torch.float32).reshape(5, 2, 3) * 2 + 1
+    assert torch.equal(r0["got"], want) and torch.equal(r1["got"], want)     # every rank holds all patches, in order
+    assert r0["calls"] == [3] and r1["calls"] == [2]
