@@ -24,7 +24,7 @@ class ConvPhase(C.Structure):
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [("ph", ConvPhase * 2), ("nphase", _i32), ("w_hi", _vp), ("w_lo", _vp), ("bias", _vp),
+    _fields_ = [("ph", ConvPhase * 2), ("nphase", _i32), ("w_hi", _vp), ("w_lo", _vp), ("w_v2", _vp), ("bias", _vp),
                 ("film", _vp), ("film_stride", _i32), ("res", _vp), ("res_scale", _f32), ("out", _vp),
                 ("stats", _vp), ("B", _i32), ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32),
                 ("Cout", _i32), ("ksize", _i32), ("stride", _i32), ("ups", _i32), ("act", _i32),
@@ -36,8 +36,9 @@ SIGNATURES = {
     "hsidm_version": [],
     "hsidm_conv_bk": [_i32],
     "hsidm_conv2d": [C.POINTER(ConvDesc), _vp],
+    "hsidm_conv_stats_nsplit": [C.POINTER(ConvDesc)],
     "hsidm_gn_partial": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
-    "hsidm_gn_finalize": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
+    "hsidm_gn_finalize": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "hsidm_noise_film": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "hsidm_attention": [_i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "hsidm_nchw_to_nhwc": [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],

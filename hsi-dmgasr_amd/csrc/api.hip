@@ -1,5 +1,5 @@
 // C-ABI entry points: argument validation, tile selection and dispatch for the convolution.
-#include "conv_igemm.h"
+#include "conv_v2.h"
 #include "../../include/hsidm.h"
 
 namespace hsidm {
@@ -13,6 +13,8 @@ HSIDM_DECL(conv_run_f32x3_k3s2)
 HSIDM_DECL(conv_run_f32x3_k1s1)
 HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 #undef HSIDM_DECL
+int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
+int conv_v2_subs(int tile_kind, int bn);
 }  // namespace hsidm
 
 using namespace hsidm;
@@ -30,10 +32,9 @@ extern "C" const char* hsidm_error_string(int code) {
 
 extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
 
-extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
-    if (!d || !d->out || !d->w_hi) return HSIDM_E_BADARG;
+static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, bool& use_v2) {
+    if (!d) return HSIDM_E_BADARG;
     if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3) return HSIDM_E_BADARG;
-    if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
     if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
     if (d->ksize != 3 && d->ksize != 1) return HSIDM_E_BADARG;
     if (d->stride != 1 && d->stride != 2) return HSIDM_E_BADARG;
@@ -44,13 +45,47 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     if (d->ups && d->stride != 1) return HSIDM_E_UNSUPPORTED;
     if (d->out_nchw && (d->ksize != 3 || d->stride != 1 || d->bn == 64 || d->stats)) return HSIDM_E_UNSUPPORTED;
     if (d->nphase == 2 && (d->ksize != 3 || d->stride != 1 || d->ups || d->ph[1].ntaps != 1)) return HSIDM_E_UNSUPPORTED;
-    const int Hout = d->ups ? 2 * d->Hin : (d->stride == 2 ? (d->Hin + 1) / 2 : d->Hin);
-    const int Wout = d->ups ? 2 * d->Win : (d->stride == 2 ? (d->Win + 1) / 2 : d->Win);
+    Hout = d->ups ? 2 * d->Hin : (d->stride == 2 ? (d->Hin + 1) / 2 : d->Hin);
+    Wout = d->ups ? 2 * d->Win : (d->stride == 2 ? (d->Win + 1) / 2 : d->Win);
     if (Hout != d->Hout || Wout != d->Wout) return HSIDM_E_BADARG;
+    // spatial tile: 8x16 pixels of one image, or 8x8 pixels of two images when the map is narrow
+    tile_kind = (Wout >= 16) ? 0 : 1;
+    const int xf = d->ph[0].transform;
+    use_v2 = d->prec == HSIDM_BF16 && d->w_v2 && d->ksize == 3 && d->stride == 1 && !d->out_nchw &&
+             (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU) &&
+             (d->nphase == 1 || d->ph[1].transform == HSIDM_XF_NONE);
+    return HSIDM_OK;
+}
 
+extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
+    int Hout, Wout, tile_kind;
+    bool use_v2;
+    const int rc = conv_validate(d, Hout, Wout, tile_kind, use_v2);
+    if (rc != HSIDM_OK) return rc;
+    if (d->out_nchw) return HSIDM_E_UNSUPPORTED;
+    const int TW = tile_kind == 0 ? 16 : 8;
+    const int tiles = ((Wout + TW - 1) / TW) * ((Hout + 7) / 8);
+    // v1 and v2 use the same wave grid rule per cout slice: WN = 2 (v1, bn >= 64) / bn/32 (v2)
+    int subs;
+    if (use_v2) subs = conv_v2_subs(tile_kind, d->bn);
+    else {
+        const int wm = d->bn >= 64 ? 2 : 4;
+        subs = tile_kind == 0 ? wm : (wm >= 2 ? wm / 2 : 1);
+    }
+    return tiles * subs;
+}
+
+extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
+    int Hout, Wout, tile_kind;
+    bool use_v2;
+    const int rc = conv_validate(d, Hout, Wout, tile_kind, use_v2);
+    if (rc != HSIDM_OK) return rc;
+    if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
+    if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
     const int bk = hsidm_conv_bk(d->prec);
     ConvParams p;
     p.nphase = d->nphase;
+    int steps = 0;
     for (int i = 0; i < 2; ++i) {
         ConvPhase& q = p.ph[i];
         if (i < d->nphase) {
@@ -62,24 +97,37 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
             q.gn_ab = reinterpret_cast<const float2*>(s.gn_ab);
             q.C0 = s.C0; q.C1 = s.C1; q.transform = s.transform; q.ntaps = s.ntaps;
             q.nchunks = (s.C0 + s.C1 + bk - 1) / bk;
+            steps += q.nchunks * q.ntaps;
         } else {
             q.src0 = q.src1 = nullptr; q.gn_ab = nullptr; q.C0 = q.C1 = 0; q.transform = 0; q.ntaps = 0; q.nchunks = 0;
         }
+    }
+    const int TH = 8, TW = tile_kind == 0 ? 16 : 8;
+    const int tiles_x = (Wout + TW - 1) / TW, tiles_y = (Hout + TH - 1) / TH;
+    const int cout_pad = (d->Cout + d->bn - 1) / d->bn * d->bn;
+    hipStream_t s = (hipStream_t)stream;
+    if (use_v2) {
+        ConvV2Params v;
+        v.ph[0] = p.ph[0]; v.ph[1] = p.ph[1]; v.nphase = p.nphase;
+        v.w = reinterpret_cast<const bf16*>(d->w_v2);
+        v.bias = d->bias; v.film = d->film; v.film_stride = d->film_stride;
+        v.res = reinterpret_cast<const bf16*>(d->res); v.res_scale = d->res_scale;
+        v.out = reinterpret_cast<bf16*>(d->out); v.stats = reinterpret_cast<float2*>(d->stats);
+        v.B = d->B; v.Hin = d->Hin; v.Win = d->Win; v.Hout = Hout; v.Wout = Wout; v.Cout = d->Cout; v.Cout_pad = cout_pad;
+        v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
+        v.steps_per_item = steps;
+        return conv_v2_run(tile_kind, d->bn, d->ph[0].transform, v, s);
     }
     p.w_hi = reinterpret_cast<const bf16*>(d->w_hi);
     p.w_lo = reinterpret_cast<const bf16*>(d->w_lo);
     p.bias = d->bias; p.film = d->film; p.film_stride = d->film_stride;
     p.res = d->res; p.res_scale = d->res_scale; p.out = d->out;
     p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = Hout; p.Wout = Wout; p.Cout = d->Cout;
-    p.Cout_pad = (d->Cout + d->bn - 1) / d->bn * d->bn;
+    p.Cout_pad = cout_pad;
     p.ups = d->ups; p.act = d->act;
     p.stats = reinterpret_cast<float2*>(d->stats);
-    // spatial tile: 8x16 pixels of one image, or 8x8 pixels of two images when the map is narrow
-    const int tile_kind = (Wout >= 16) ? 0 : 1;
-    const int TH = 8, TW = tile_kind == 0 ? 16 : 8;
-    p.tiles_x = (Wout + TW - 1) / TW;
-    p.tiles_y = (Hout + TH - 1) / TH;
-    hipStream_t s = (hipStream_t)stream;
+    p.tiles_x = tiles_x;
+    p.tiles_y = tiles_y;
     const bool bf = d->prec == HSIDM_BF16;
     if (d->out_nchw) return bf ? conv_run_bf16_k3s1nchw(tile_kind, d->bn, p, s) : conv_run_f32x3_k3s1nchw(tile_kind, d->bn, p, s);
     if (d->ksize == 1) return bf ? conv_run_bf16_k1s1(tile_kind, d->bn, p, s) : conv_run_f32x3_k1s1(tile_kind, d->bn, p, s);

@@ -53,7 +53,7 @@ struct ConvParams {
     int ups;               // 1: input is nearest-x2 upsampled on the fly (Hout = 2*Hin)
     int act;               // ACT_*
     int tiles_x, tiles_y;
-    float2* stats;         // optional [B][Cout] (sum, sumsq) accumulated with fp32 atomics, or null
+    float2* stats;         // optional [B][tiles_per_img*SUBS][Cout] (sum, sumsq) slab, each entry written once, or null
 };
 
 template <typename ActT, bool SPLIT_, int BN_, int BK_, int TH_, int TW_, int NI_, int KS_, int S_, bool OUT_NCHW_>
@@ -82,6 +82,8 @@ struct ConvCfg {
     static constexpr int HALO_ELEMS = NI * HPIX * PSTR;
     static constexpr int WT_ELEMS = BN * WSTR;
     static constexpr size_t LDS_BYTES = (size_t)(NPART * HALO_ELEMS + 2 * NPART * WT_ELEMS) * 2;
+    // statistics slab: entries per (image, spatial tile) = one per wave row that covers that image
+    static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
 
 template <typename ActT> struct RawVec;     // 8 activations as loaded from memory
@@ -356,21 +358,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // ---- epilogue ----------------------------------------------------------------------------------
     ActT* out = reinterpret_cast<ActT*>(p.out);
     const ActT* res = reinterpret_cast<const ActT*>(p.res);
+    const int trem_e = trem;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int n = n0 + wn * (BN / C::WN) + nr * 32 + lr;
         const bool nok = n < p.Cout;
         const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-        int sb = -1;
+        float s1[NI], s2[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) s1[q] = s2[q] = 0.f;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
+            const int pbase = wm * (C::BM / C::WM) + mr * 32;
+            const int img = pbase / (TH * TW);             // a 32-row MFMA tile never straddles two images
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
-                const int pm = wm * (C::BM / C::WM) + mr * 32 + row;
-                const int img = pm / (TH * TW);
-                const int q = pm - img * (TH * TW);
+                const int q = pbase + row - img * (TH * TW);
                 const int ty = q / TW, tx = q - ty * TW;
                 const int b = b0 + img, oy = oy0 + ty, ox = ox0 + tx;
                 if (!(nok && b < p.B && oy < p.Hout && ox < p.Wout)) continue;
@@ -387,23 +391,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     if (p.res) v = p.res_scale * v + to_f32<ActT>(res[o]);
                     const ActT st = from_f32<ActT>(v);
                     out[o] = st;
-                    if (p.stats) {      // statistics of the tensor exactly as stored
-                        const float sv = to_f32<ActT>(st);
-                        if (NI > 1 && sb >= 0 && sb != b) {
-                            atomicAdd(&p.stats[(size_t)sb * p.Cout + n].x, s1);
-                            atomicAdd(&p.stats[(size_t)sb * p.Cout + n].y, s2);
-                            s1 = s2 = 0.f;
-                        }
-                        sb = b;
-                        s1 += sv;
-                        s2 += sv * sv;
-                    }
+                    const float sv = to_f32<ActT>(st);      // statistics of the tensor exactly as stored
+                    s1[NI == 1 ? 0 : img] += sv;
+                    s2[NI == 1 ? 0 : img] += sv * sv;
                 }
             }
         }
-        if (!C::OUT_NCHW && p.stats && sb >= 0) {
-            atomicAdd(&p.stats[(size_t)sb * p.Cout + n].x, s1);
-            atomicAdd(&p.stats[(size_t)sb * p.Cout + n].y, s2);
+        if (!C::OUT_NCHW && p.stats) {
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const float a = s1[q] + __shfl_xor(s1[q], 32, 64);
+                const float d = s2[q] + __shfl_xor(s2[q], 32, 64);
+                int img, sub;
+                if (NI == 1) { img = 0; sub = wm; }
+                else if (C::WM == 1) { img = q; sub = 0; }
+                else { img = (wm * (C::BM / C::WM)) / (TH * TW); sub = wm % (C::WM / 2 > 0 ? C::WM / 2 : 1); if (q != img) continue; }
+                const int b = b0 + img;
+                if (lh == 0 && nok && b < p.B)
+                    p.stats[((size_t)b * (tiles_per_img * C::SUBS) + trem_e * C::SUBS + sub) * p.Cout + n] = make_float2(a, d);
+            }
         }
     }
 }

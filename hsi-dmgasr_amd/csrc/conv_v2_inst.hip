@@ -1,0 +1,63 @@
+// Instantiations + launcher of the persistent bf16 3x3 convolution (conv_v2.h).
+#include "conv_v2.h"
+
+namespace hsidm {
+
+static int g_slots = 0;      // co-resident workgroups: 2 per CU
+
+template <typename C>
+static int run_v2(ConvV2Params& p, hipStream_t s) {
+    constexpr size_t lds = C::LDS_BYTES;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v2_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    if (g_slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g_slots = 2 * cus;
+    }
+    const int imgs = (p.B + C::NI - 1) / C::NI;
+    p.m_tiles = imgs * p.tiles_x * p.tiles_y;
+    p.n_slices = p.Cout_pad / C::BN;
+    p.total_items = p.m_tiles * p.n_slices;
+    int lcm = 8;
+    while (lcm % p.n_slices) lcm += 8;
+    int G = (p.total_items < g_slots ? p.total_items : g_slots) / lcm * lcm;
+    if (G == 0) G = p.total_items;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v2_kernel<C>), dim3(G), dim3(256), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+int conv_v2_subs(int tile_kind, int bn) {
+    const int wm = 4 / (bn / 32);
+    return tile_kind == 0 ? wm : (wm >= 2 ? wm / 2 : 1);
+}
+
+#define V2(BN, TH, TW, NI, XF) run_v2<V2Cfg<BN, TH, TW, NI, XF>>(p, s)
+
+int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s) {
+    if (xf != XF_NONE && xf != XF_AFFINE_SILU) return -2;
+    const bool x = xf == XF_AFFINE_SILU;
+    if (tile_kind == 0) {
+        switch (bn) {
+            case 128: return x ? V2(128, 8, 16, 1, XF_AFFINE_SILU) : V2(128, 8, 16, 1, XF_NONE);
+            case 64: return x ? V2(64, 8, 16, 1, XF_AFFINE_SILU) : V2(64, 8, 16, 1, XF_NONE);
+            case 32: return x ? V2(32, 8, 16, 1, XF_AFFINE_SILU) : V2(32, 8, 16, 1, XF_NONE);
+        }
+    } else {
+        switch (bn) {
+            case 128: return x ? V2(128, 8, 8, 2, XF_AFFINE_SILU) : V2(128, 8, 8, 2, XF_NONE);
+            case 64: return x ? V2(64, 8, 8, 2, XF_AFFINE_SILU) : V2(64, 8, 8, 2, XF_NONE);
+            case 32: return x ? V2(32, 8, 8, 2, XF_AFFINE_SILU) : V2(32, 8, 8, 2, XF_NONE);
+        }
+    }
+    return -2;
+}
+
+}  // namespace hsidm

@@ -53,12 +53,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const ActT* __restrict_
     }
 }
 
-// gn_finalize: grid (B).  part [B][nsplit][C] -> gn_ab [B][C] = (rstd*gamma, beta - mean*rstd*gamma)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict__ part, int nsplit, int C, int HW,
-                                                          int groups, const float* __restrict__ gamma,
+// gn_finalize: grid (B).  part0 [B][nsplit0][C0] (+ part1 [B][nsplit1][C1] for a channel concat)
+//              -> gn_ab [B][C0+C1] = (rstd*gamma, beta - mean*rstd*gamma)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict__ part0, int nsplit0, int C0,
+                                                          const float2* __restrict__ part1, int nsplit1, int C1,
+                                                          int HW, int groups, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           float2* __restrict__ ab) {
     extern __shared__ float sm[];          // [C] sum, [C] sumsq, [groups] mean, [groups] rstd
+    const int C = C0 + C1;
     float* cs = sm;
     float* cq = sm + C;
     float* gm = sm + 2 * C;
@@ -66,10 +69,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
     const int b = blockIdx.x, t = threadIdx.x;
     for (int c = t; c < C; c += 256) {
         float a = 0.f, d = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-            float2 v = part[((size_t)b * nsplit + s) * C + c];
-            a += v.x;
-            d += v.y;
+        if (c < C0) {
+            for (int s = 0; s < nsplit0; ++s) {
+                const float2 v = part0[((size_t)b * nsplit0 + s) * C0 + c];
+                a += v.x;
+                d += v.y;
+            }
+        } else {
+            for (int s = 0; s < nsplit1; ++s) {
+                const float2 v = part1[((size_t)b * nsplit1 + s) * C1 + (c - C0)];
+                a += v.x;
+                d += v.y;
+            }
         }
         cs[c] = a;
         cq[c] = d;
@@ -195,12 +206,15 @@ extern "C" int hsidm_gn_partial(int prec, const void* src0, const void* src1, in
     return (int)hipGetLastError();
 }
 
-extern "C" int hsidm_gn_finalize(const float* part, int nsplit, int B, int C, int HW, int groups,
-                                 const float* gamma, const float* beta, float eps, float* gn_ab, void* stream) {
-    if (!part || !gamma || !beta || !gn_ab || groups <= 0 || C % groups || C > 8192 || nsplit <= 0) return HSIDM_E_BADARG;
+extern "C" int hsidm_gn_finalize(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
+                                 int B, int HW, int groups, const float* gamma, const float* beta, float eps,
+                                 float* gn_ab, void* stream) {
+    const int C = C0 + C1;
+    if (!part0 || !gamma || !beta || !gn_ab || groups <= 0 || C0 <= 0 || C1 < 0 || C % groups || C > 8192 || nsplit0 <= 0) return HSIDM_E_BADARG;
+    if (C1 > 0 && (!part1 || nsplit1 <= 0)) return HSIDM_E_BADARG;
     const size_t lds = (size_t)(2 * C + 2 * groups) * sizeof(float);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float2*)part, nsplit, C, HW,
-                       groups, gamma, beta, eps, (float2*)gn_ab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float2*)part0, nsplit0, C0,
+                       (const float2*)part1, nsplit1, C1, HW, groups, gamma, beta, eps, (float2*)gn_ab);
     return (int)hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ class CALayer(nn.Module):
 
     def vector(self, r, precision):
         """Squeeze-excite vector [B, C] of an NHWC tensor r."""
-        part, nsplit = ops.channel_partials(r, precision)
+        part, nsplit = ops._partials(r, precision)
         c0, c2 = self.conv_du[0], self.conv_du[2]
         return ops.ca_vector(part, nsplit, r.shape[1] * r.shape[2],
                              c0.weight.reshape(c0.weight.shape[0], -1), c0.bias,
@@ -97,7 +97,7 @@ class ResAttentionBlock(_ConvPair):
 
     def _run(self, x, precision, skip2=None):
         h = ops.conv2d(x, self._pk(0, precision), act=ops.ACT_LEAKY)
-        r = ops.conv2d(h, self._pk(2, precision))
+        r = ops.conv2d(h, self._pk(2, precision), stats=True)
         ca = self.body[3].vector(r, precision)
         return ops.ca_apply(r, ca, x, self.res_scale, precision, skip2=skip2)
 

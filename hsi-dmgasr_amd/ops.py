@@ -59,6 +59,13 @@ class PackedConv:
         self.w_hi = w.to(torch.bfloat16).contiguous()
         self.w_lo = (w - self.w_hi.float()).to(torch.bfloat16).contiguous() if prec == _lib.F32X3 else None
         self.bias = None if b is None else b.to(dev).contiguous()
+        # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
+        # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
+        self.w_v2 = None
+        if prec == _lib.BF16 and kh == 3 and not out_nchw:
+            st = self.w_hi.shape[0]
+            v = self.w_hi.reshape(st, cpad // 32, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5)
+            self.w_v2 = v.contiguous()
 
     @staticmethod
     def _steps(w, cpad, bk):
@@ -73,8 +80,11 @@ class PackedConv:
 
 # ------------------------------------------------------------------------------------------- kernels
 def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=None, res_scale=1.0,
-           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=None):
-    """out = res_scale * act(conv(T(cat(x0, x1))) [+ proj(cat(proj_x0, proj_x1))] + bias + film) + res."""
+           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=False):
+    """out = res_scale * act(conv(T(cat(x0, x1))) [+ proj(cat(proj_x0, proj_x1))] + bias + film) + res.
+
+    stats=True: the kernel also writes per-(image, tile part, channel) sums of `out`; they ride on the returned
+    tensor as ``out._hsidm_stats = (slab [B, nsplit, C, 2], nsplit)`` and feed gn_scale_shift / ca_vector."""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     assert C0 + C1 == pw.cin, "conv input channels %d+%d != packed %d" % (C0, C1, pw.cin)
@@ -99,13 +109,21 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         p1.C0, p1.C1, p1.transform, p1.ntaps = q0, q1, XF_NONE, 1
         d.nphase = 2
     d.w_hi, d.w_lo, d.bias = _lib.ptr(pw.w_hi), _lib.ptr(pw.w_lo), _lib.ptr(pw.bias)
+    d.w_v2 = _lib.ptr(pw.w_v2) if _use_v2 else None
     if film is not None:          # a column slice of the [B, F] FiLM table
         assert film.stride(1) == 1 and film.shape == (B, pw.cout)
         d.film, d.film_stride = film.data_ptr(), film.stride(0)
-    d.res, d.res_scale, d.out, d.stats = _lib.ptr(res), float(res_scale), _lib.ptr(out), _lib.ptr(stats)
+    d.res, d.res_scale, d.out, d.stats = _lib.ptr(res), float(res_scale), _lib.ptr(out), None
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
     d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, int(bool(ups)), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
+    if stats and not pw.out_nchw:
+        nsplit = _lib.lib().hsidm_conv_stats_nsplit(C.byref(d))
+        if nsplit <= 0:
+            _lib.check(nsplit, "conv_stats_nsplit")
+        slab = torch.empty((B, nsplit, pw.cout, 2), dtype=torch.float32, device=x0.device)
+        d.stats = _lib.ptr(slab)
+        out._hsidm_stats = (slab, nsplit)
     if _conv_probe is None:
         _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
     else:   # measurement hook (bench.py): HIP events on the launch stream around this one kernel
@@ -121,6 +139,12 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
 
 
 _conv_probe = None
+_use_v2 = True          # set False to force the v1 kernel everywhere (A/B measurements)
+
+
+def set_use_v2(flag):
+    global _use_v2
+    _use_v2 = bool(flag)
 
 
 def set_conv_probe(records):
@@ -129,19 +153,25 @@ def set_conv_probe(records):
     _conv_probe = records
 
 
+def _partials(x, precision):
+    """(slab [B, nsplit, C, 2], nsplit) of an NHWC tensor: from its producer's epilogue when present, else one
+    streaming pass (tensors that did not come out of hsidm_conv2d)."""
+    st = getattr(x, "_hsidm_stats", None)
+    if st is not None:
+        return st
+    return channel_partials(x, precision)
+
+
 def gn_scale_shift(x0, x1, gamma, beta, groups, precision, eps=1e-5):
     """GroupNorm statistics of cat(x0, x1) folded with (gamma, beta): [B, C, 2] (scale, shift)."""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
-    Cc, HW = C0 + C1, H * W
-    nsplit = max(1, min(32, HW // 512))
-    part = torch.empty((B, nsplit, Cc, 2), dtype=torch.float32, device=x0.device)
-    L, s = _lib.lib(), _lib.stream_ptr()
-    _lib.check(L.hsidm_gn_partial(_lib.prec_id(precision), _lib.ptr(x0), _lib.ptr(x1), C0, C1, B, HW, nsplit,
-                                  _lib.ptr(part), s), "gn_partial")
-    ab = torch.empty((B, Cc, 2), dtype=torch.float32, device=x0.device)
-    _lib.check(L.hsidm_gn_finalize(_lib.ptr(part), nsplit, B, Cc, HW, groups, _lib.ptr(gamma), _lib.ptr(beta),
-                                   float(eps), _lib.ptr(ab), s), "gn_finalize")
+    p0, n0 = _partials(x0, precision)
+    p1, n1 = _partials(x1, precision) if x1 is not None else (None, 0)
+    ab = torch.empty((B, C0 + C1, 2), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.lib().hsidm_gn_finalize(_lib.ptr(p0), n0, C0, _lib.ptr(p1), n1, C1, B, H * W, groups,
+                                            _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(ab),
+                                            _lib.stream_ptr()), "gn_finalize")
     return ab
 
 

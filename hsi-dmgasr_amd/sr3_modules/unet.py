@@ -116,7 +116,7 @@ class Upsample(_HipModule):
                                lambda: ops.PackedConv(self.conv.weight, self.conv.bias, precision))
 
     def _run(self, x, precision):
-        return ops.conv2d(x, self._packed(precision), ups=True)
+        return ops.conv2d(x, self._packed(precision), ups=True, stats=True)
 
     def forward(self, x):
         self._check_input(x)
@@ -135,7 +135,7 @@ class Downsample(_HipModule):
                                lambda: ops.PackedConv(self.conv.weight, self.conv.bias, precision))
 
     def _run(self, x, precision):
-        return ops.conv2d(x, self._packed(precision), stride=2)
+        return ops.conv2d(x, self._packed(precision), stride=2, stats=True)
 
     def forward(self, x):
         self._check_input(x)
@@ -170,7 +170,7 @@ class Block(_HipModule):
         gn = self.block[0]
         ab = ops.gn_scale_shift(x0, x1, gn.weight, gn.bias, gn.num_groups, precision, gn.eps)
         return ops.conv2d(x0, self._packed(precision, out_nchw, proj), x1=x1, gn_ab=ab, transform=ops.XF_AFFINE_SILU,
-                          film=film, res=res, proj_x0=proj_x0, proj_x1=proj_x1)
+                          film=film, res=res, proj_x0=proj_x0, proj_x1=proj_x1, stats=not out_nchw)
 
     def forward(self, x):
         self._check_input(x)
@@ -221,7 +221,7 @@ class SelfAttention(_HipModule):
         ab = ops.gn_scale_shift(x, None, self.norm.weight, self.norm.bias, self.norm.num_groups, precision, self.norm.eps)
         qkv = ops.conv2d(x, pq, gn_ab=ab, transform=ops.XF_AFFINE)
         o = ops.attention(qkv, precision)
-        return ops.conv2d(o, po, res=x)
+        return ops.conv2d(o, po, res=x, stats=True)
 
     def forward(self, input):
         self._check_input(input)
@@ -350,7 +350,7 @@ class UNet(_HipModule):
             elif isinstance(layer, Downsample):
                 x = layer._run(x, precision)
             else:
-                x = ops.conv2d(stem_in, self._stem_pack(precision))
+                x = ops.conv2d(stem_in, self._stem_pack(precision), stats=True)
             skips.append(x)
         for layer in self.mid:
             lo, hi = offs[k]

@@ -71,14 +71,18 @@ typedef struct hsidm_conv_desc {
     int32_t nphase;           /* 1, or 2 = phase 1 is a fused 1x1 projection of a second input      */
     const void*  w_hi;        /* packed bf16 [step][Cout_pad][BK], step = (phase, chunk, tap)       */
     const void*  w_lo;        /* low halves (HSIDM_F32X3 only)                                      */
+    const void*  w_v2;        /* optional (HSIDM_BF16, 3x3 stride 1): the same weights in the register-
+                                 streaming order [step][Cout_pad/32][4][64 lanes][8]; enables the
+                                 persistent kernel (csrc/conv_v2.h)                                   */
     const float* bias;        /* [Cout] or NULL                                                     */
     const float* film;        /* [B][film_stride], pre-offset to this layer's columns, or NULL      */
     int32_t film_stride;
     const void*  res;         /* residual in the layout/type of out, or NULL                        */
     float        res_scale;
     void*        out;         /* NHWC [B][Hout][Wout][Cout]; NCHW fp32 when out_nchw                */
-    float*       stats;       /* optional [B][Cout][2] (sum, sum of squares) of out, atomically
-                                 accumulated (must be zeroed by the caller), or NULL                */
+    float*       stats;       /* optional [B][hsidm_conv_stats_nsplit(d)][Cout][2]: per-(image, tile part,
+                                 channel) sum and sum of squares of `out` as stored, every entry
+                                 written exactly once (no atomics, no zeroing); feeds hsidm_gn_finalize */
     int32_t B, Hin, Win, Hout, Wout, Cout;
     int32_t ksize;            /* 3 or 1 (phase 0)                                                   */
     int32_t stride;           /* 1 or 2                                                             */
@@ -90,18 +94,23 @@ typedef struct hsidm_conv_desc {
 } hsidm_conv_desc;
 
 int hsidm_conv2d(const hsidm_conv_desc* d, void* stream);
+/* Number of partial entries per image that hsidm_conv2d(d) writes into d->stats (>0), or an error code. */
+int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d);
 /* K-chunk (input channels per packed step) of a precision mode: 64 for BF16, 32 for F32X3. */
 int hsidm_conv_bk(int prec);
 
 /* ---- GroupNorm statistics (nn.GroupNorm inside Block / SelfAttention, unet.py:84,121) ----------
  * partial: per-(image, split, channel) sum and sum of squares of a (concatenated) NHWC tensor;
  * finalize: -> per-(image, channel) (scale, shift) = (rstd*gamma, beta - mean*rstd*gamma).
- * `part` is [B][nsplit][C][2] floats.  hsidm_conv2d's `stats` output is a valid `part` with nsplit=1.
+ * `part` is [B][nsplit][C][2] floats; hsidm_conv2d's `stats` output has this layout, so a tensor produced by
+ * a convolution needs no statistics pass.  finalize takes the two halves of a channel concat separately
+ * (part1 may be NULL): GroupNorm groups may straddle the seam (e.g. 192 = 128 + 64 channels, 6 per group).
  */
 int hsidm_gn_partial(int prec, const void* src0, const void* src1, int C0, int C1, int B, int HW,
                      int nsplit, float* part, void* stream);
-int hsidm_gn_finalize(const float* part, int nsplit, int B, int C, int HW, int groups,
-                      const float* gamma, const float* beta, float eps, float* gn_ab, void* stream);
+int hsidm_gn_finalize(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
+                      int B, int HW, int groups, const float* gamma, const float* beta, float eps,
+                      float* gn_ab, void* stream);
 
 /* ---- noise-level embedding + all FiLM projections of one UNet call ---------------------------------
  * PositionalEncoding + noise_level_mlp (unet.py:23-31,182-187) and the Linear of every

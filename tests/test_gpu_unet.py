@@ -213,3 +213,46 @@ def test_sampler_api_shapes_and_philox_mode(dev):
     for i in reversed(range(12)):
         xo = odiff.p_sample_step(den, sched, xo, cond.cpu(), i, nf(i) if i > 0 else None)
     check("sampler_philox_T12", "fp32", got, xo, tol=2e-3)
+
+
+CONV_CASES = [  # B, H, W, C0, C1, Cout, ups, proj_cin, xf
+    (3, 16, 32, 64, 0, 128, False, 0, True),      # 8x16 tiles, BN=128, several items per block
+    (2, 24, 40, 64, 32, 64, False, 0, True),      # concat input, BN=64, partial tiles
+    (5, 8, 8, 128, 0, 96, False, 64, True),       # two-image tiles (odd batch), fused 1x1 projection
+    (2, 8, 16, 32, 0, 24, True, 0, False),        # nearest-x2 folded in, BN=32, no transform
+    (40, 16, 16, 64, 0, 64, False, 0, True),      # many items: persistent loop over tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
+    """The persistent bf16 kernel (conv_v2) against the v1 kernel on identical inputs, and the statistics slab
+    of both against sums of the stored output."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, C0, C1, Co, ups, pj, xf = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    w = torch.randn(Co, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5
+    pwt = (torch.randn(Co, pj, 1, 1, generator=g) / pj ** 0.5).to(dev) if pj else None
+    pk = ops.PackedConv(w.to(dev), torch.randn(Co, generator=g).to(dev), "bf16", proj_weight=pwt,
+                        proj_bias=None if pwt is None else torch.zeros(Co, device=dev))
+    assert pk.w_v2 is not None
+    x0 = torch.randn(B, H, W, C0, generator=g).to(dev, torch.bfloat16)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
+    px = torch.randn(B, H, W, pj, generator=g).to(dev, torch.bfloat16) if pj else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, C0 + C1, generator=g), 0.1 * torch.randn(B, C0 + C1, generator=g)], 2).contiguous().to(dev)
+    film = torch.randn(B, Co, generator=g).to(dev)
+    outs = []
+    for use_v2 in (False, True):
+        ops.set_use_v2(use_v2)
+        y = ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=ops.XF_AFFINE_SILU if xf else ops.XF_NONE,
+                       film=film, ups=ups, proj_x0=px, stats=True)
+        torch.cuda.synchronize()
+        slab, nsplit = y._hsidm_stats
+        yf = y.float()
+        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)         # [B, C, 2]
+        got = slab.sum(dim=1)
+        assert slab.shape == (B, nsplit, Co, 2)
+        assert torch.allclose(got, want, rtol=2e-3, atol=2e-2), (use_v2, (got - want).abs().max().item())
+        outs.append(yf.cpu())
+    ops.set_use_v2(True)
+    check("conv_v2_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=2e-3)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of representative hsidm_conv2d launches (bf16, batch 40) for kernel tuning.
+
+    python tools/conv_bench.py [--reps 5] [--only NAME]
+Prints one line per shape: name, microseconds (best of reps), TFLOP/s.  Used under rocprofv3 --pmc.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hsi_dmgasr_amd import ops  # noqa: E402
+
+SHAPES = [  # name, H, C0, C1, Cout, ksize, stride, ups, proj_cin
+    ("l128_64_64", 128, 64, 0, 64, 3, 1, 0, 0),
+    ("l128_192_64", 128, 128, 64, 64, 3, 1, 0, 0),
+    ("l128_64_64_proj128", 128, 64, 0, 64, 3, 1, 0, 128),
+    ("l64_128_128", 64, 128, 0, 128, 3, 1, 0, 0),
+    ("l64_384_128", 64, 256, 128, 128, 3, 1, 0, 0),
+    ("l32_256_256", 32, 256, 0, 256, 3, 1, 0, 0),
+    ("l32_768_256", 32, 512, 256, 256, 3, 1, 0, 0),
+    ("l16_512_512", 16, 512, 0, 512, 3, 1, 0, 0),
+    ("l16_1024_512", 16, 512, 512, 512, 3, 1, 0, 0),
+    ("l8_512_512", 8, 512, 0, 512, 3, 1, 0, 0),
+    ("l8_1024_512", 8, 512, 512, 512, 3, 1, 0, 0),
+    ("up_128_to128", 64, 128, 0, 128, 3, 1, 1, 0),
+    ("up_256_to64", 32, 256, 0, 256, 3, 1, 1, 0),
+    ("down_128_64", 128, 64, 0, 64, 3, 2, 0, 0),
+    ("qkv_16_512", 16, 512, 0, 1536, 1, 1, 0, 0),
+    ("stem_128_8_64", 128, 8, 0, 64, 3, 1, 0, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=40)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--v1", action="store_true", help="force the v1 kernel (A/B against conv_v2)")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ops.set_use_v2(not args.v1)
+    prec = args.precision
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    g = torch.Generator(device="cpu").manual_seed(0)
+    B = args.batch
+    for name, H, C0, C1, Co, ks, st, up, pj in SHAPES:
+        if args.only and args.only != name:
+            continue
+        w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
+        pwt = torch.randn(Co, pj, 1, 1, generator=g) / pj ** 0.5 if pj else None
+        pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), prec, proj_weight=None if pwt is None else pwt.to(dev),
+                            proj_bias=None if pwt is None else torch.zeros(Co, device=dev))
+        x0 = torch.randn(B, H, H, C0, generator=g).to(dev, dt)
+        x1 = torch.randn(B, H, H, C1, generator=g).to(dev, dt) if C1 else None
+        px = torch.randn(B, H, H, pj, generator=g).to(dev, dt) if pj else None
+        ab = torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev)
+        xf = ops.XF_AFFINE_SILU if (ks == 3 and st == 1 and not up) else ops.XF_NONE
+        best = 1e9
+        for _ in range(args.reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=xf, stride=st, ups=bool(up), proj_x0=px)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        Ho = y.shape[1]
+        flops = 2.0 * B * Ho * Ho * Co * ((C0 + C1) * ks * ks + pj)
+        print("%-22s %9.1f us %8.1f TFLOP/s" % (name, best * 1e3, flops / (best * 1e-3) / 1e12), flush=True)
+        del x0, x1, px, y, pk
+
+
+if __name__ == "__main__":
+    main()
