@@ -52,8 +52,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     tile_kind = (Wout >= 16) ? 0 : 1;
     const int xf = d->ph[0].transform;
     use_v2 = d->prec == HSIDM_BF16 && d->w_v2 && d->ksize == 3 && d->stride == 1 && !d->out_nchw &&
-             (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU) &&
-             (d->nphase == 1 || d->ph[1].transform == HSIDM_XF_NONE);
+             (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU) && d->nphase == 1;
     return HSIDM_OK;
 }
 
@@ -108,7 +107,10 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (use_v2) {
         ConvV2Params v;
-        v.ph[0] = p.ph[0]; v.ph[1] = p.ph[1]; v.nphase = p.nphase;
+        v.src0 = reinterpret_cast<const bf16*>(p.ph[0].src0);
+        v.src1 = reinterpret_cast<const bf16*>(p.ph[0].src1);
+        v.gn_ab = reinterpret_cast<const f32x4*>(p.ph[0].gn_ab);
+        v.C0 = p.ph[0].C0; v.C1 = p.ph[0].C1; v.nchunks = p.ph[0].nchunks;
         v.w = reinterpret_cast<const bf16*>(d->w_v2);
         v.bias = d->bias; v.film = d->film; v.film_stride = d->film_stride;
         v.res = reinterpret_cast<const bf16*>(d->res); v.res_scale = d->res_scale;

@@ -57,7 +57,8 @@ template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
 
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (~1e-6 relative), 5 VALU instead of an IEEE division
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ---- wave / block reductions -----------------------------------------------------------------

@@ -1,22 +1,24 @@
 // conv_v2: persistent implicit-GEMM 3x3 convolution (stride 1, optional nearest-x2 input) for the
 // bf16 throughput mode.  Successor of conv_igemm.h for the shapes that carry ~90 % of the UNet's time.
 //
-// What changed against v1, and the measurement that motivated it (profiles/r01_baseline):
-//   v1 spent 15 VALU + 5 SALU instructions per MFMA and its waves were parked 43 % of the time
-//   (SQ_WAIT_ANY) behind one barrier + one LDS weight-tile commit per K step and an in-order vmcnt
-//   that chained the short L2 weight loads to the long HBM halo loads.
+// What changed against v1, and the measurements that motivated it (profiles/r01_baseline, r01_pmc):
+//   v1: 15 VALU + 5 SALU instructions per MFMA, waves parked 43 % of the time (SQ_WAIT_ANY) behind one
+//   barrier + one LDS weight-tile commit per K step; MFMA pipe 15 % busy.
 //   * weights never touch LDS: each wave owns a 32-wide cout slice and streams its MFMA B-fragments
 //     straight from L2 into registers (pre-packed so that one wave-load is one contiguous 1 KiB),
 //     through a 3-deep register ring issued two K steps ahead -> no per-step barrier, no LDS writes;
-//   * the input halo tile is double-buffered in LDS; the next chunk's tile is fetched at tap 0 and
-//     normalised / SiLU'd / packed one 16-B vector per tap, in the shadow of the MFMAs; one LDS
-//     barrier per chunk (9 K steps) instead of per step;
-//   * the workgroup is persistent: it walks (pixel tile, cout slice) work items round-robin, so the
-//     pipeline (weight ring, halo prefetch) runs across tile boundaries and tile-count quantisation
-//     costs a fraction of a tile, not a launch wave; a block always works on the same cout slice, and
-//     blocks that share an XCD (blockIdx % 8) share that slice -> each L2 streams 1/Nslices of W;
-//   * the epilogue also emits per-(image, tile, channel) sum / sum-of-squares of what it stored, so
-//     the consumer's GroupNorm needs no extra pass over the tensor (hsidm_gn_finalize reads the slab).
+//   * the input halo tile is double-buffered in LDS; the 9 taps of a chunk are fully unrolled with a
+//     STATIC schedule: tap 0 issues the next chunk's halo + GroupNorm-parameter loads, taps 2..8 each
+//     normalise / SiLU / pack one 16-B vector into the other buffer in the shadow of that tap's MFMAs
+//     (nothing is consumed right after its load, so no wait drains the weight ring); one LDS-only
+//     barrier per chunk; A fragments are double-buffered across the four k-slices of a tap;
+//   * SiLU uses v_exp + v_rcp (5 VALU per element instead of an IEEE division);
+//   * the workgroup is persistent: it walks (pixel tile, cout slice) work items round-robin so the
+//     weight ring and the halo prefetch run across tile boundaries; a block always works on the same
+//     cout slice, and blocks sharing an XCD (blockIdx % 8) share that slice -> each L2 streams
+//     1/Nslices of the weights;
+//   * the epilogue emits per-(image, tile part, channel) sum / sum-of-squares of what it stored, so
+//     the consumer's GroupNorm needs no pass over the tensor (hsidm_gn_finalize reads the slab).
 //
 // Tile: 128 output pixels (8x16 of one image, or 8x8 of two) x BN couts, 4 waves; wave tile =
 // (128/WM) pixels x 32 couts, WM x WN = 4, WN = BN/32.  K step = 64 input channels of one tap.
@@ -26,9 +28,11 @@
 namespace hsidm {
 
 struct ConvV2Params {
-    ConvPhase ph[2];
-    int nphase;
-    const bf16* w;          // packed [step][Cout_pad/32][kk 4][lane 64][8]
+    const bf16* src0;       // NHWC [B][Hin][Win][C0]
+    const bf16* src1;       // NHWC [B][Hin][Win][C1] or null (channel concat)
+    const f32x4* gn_ab;     // [B][Ctot/2] = (scale, shift) pairs of two channels, or null
+    int C0, C1, nchunks;
+    const bf16* w;          // packed [step][Cout_pad/32][kk 4][lane 64][8], step = chunk*9 + tap
     const float* bias;
     const float* film;
     int film_stride;
@@ -52,13 +56,12 @@ struct V2Cfg {
     static constexpr int PSTR = BK + 8, VPP = BK / 8;
     static constexpr int HVEC = NI * HPIX * VPP;
     static constexpr int MAXHV = (HVEC + 255) / 256;
+    static_assert(MAXHV <= 7, "one staged vector per tap 2..8");
     static constexpr int HALO_ELEMS = NI * HPIX * PSTR;
     static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2;
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
-
-template <int V> struct SlotTag { static constexpr int value = V; };
 
 __device__ __forceinline__ void lds_barrier() {
     // LDS-only ordering: keeps the register-ring weight loads in flight across the barrier
@@ -67,10 +70,16 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+__device__ __forceinline__ float silu_fast(float y) {
+    // y * sigmoid(y) with v_exp_f32 / v_rcp_f32 (about 1e-6 relative; the result is rounded to bf16)
+    return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+}
+
 template <typename C>
 __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
     constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK;
+    constexpr int MAXHV = C::MAXHV;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* halo = reinterpret_cast<bf16*>(smem_raw);          // [2][HALO_ELEMS]
@@ -82,12 +91,12 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     const int lr = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ctot = p.C0 + p.C1;
 
-    int item = blockIdx.x;                                     // items: item = m_tile * n_slices + n_slice
+    int item = blockIdx.x;                                     // item = m_tile * n_slices + n_slice
     const int ns = item % p.n_slices;                          // constant for this block (G % n_slices == 0)
     const int n0 = ns * BN;
     const int n_items_blk = (p.total_items - item + G - 1) / G;
-    const int total_steps = n_items_blk * p.steps_per_item;
 
     // ---- weight stream: one contiguous 1 KiB per (step, 32-cout slice, kk) --------------------------------
     const int nsw = p.Cout_pad >> 5;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
     bf16x8 ring[3][4];
     int wnext = 0;                                              // step (within an item) of the next weight fetch
-    auto b_issue = [&](bf16x8 (&dst)[4]) {
+    auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
         const bf16* src = wlane + (size_t)wnext * wstep_stride;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
@@ -104,13 +113,10 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 
     // ---- halo staging state ---------------------------------------------------------------------------------
     const int cv = tid % VPP;
-    int hv_lds[C::MAXHV];
-#pragma unroll
-    for (int i = 0; i < C::MAXHV; ++i) {
-        const int v = tid + i * 256;
-        hv_lds[i] = (v < C::HVEC) ? (v / VPP) * PSTR + cv * 8 : -1;
-    }
-    int hv_pix[C::MAXHV];                                       // for the tile being STAGED
+    const int hv_lds0 = (tid / VPP) * PSTR + cv * 8;           // vector i lives at hv_lds0 + i * (256/VPP) * PSTR
+    constexpr int HV_LDS_STEP = (256 / VPP) * PSTR;
+    const bool last_live = tid + (MAXHV - 1) * 256 < C::HVEC;  // the last vector slot is partial
+    int hv_pix[MAXHV];                                          // for the tile being STAGED
     int st_b0 = 0;
     auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {
         const int mt = it / p.n_slices;
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         tile_coords(it, b0, oy0, ox0);
         st_b0 = b0;
 #pragma unroll
-        for (int i = 0; i < C::MAXHV; ++i) {
+        for (int i = 0; i < MAXHV; ++i) {
             const int v = tid + i * 256;
             int pix = -1;
-            if (v < C::HVEC) {
+            if (i < MAXHV - 1 || last_live) {
                 const int hp = v / VPP;
                 const int img = hp / HPIX;
                 const int r = hp - img * HPIX;
@@ -143,56 +149,62 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             hv_pix[i] = pix;
         }
     };
-    u32x4 hreg[C::MAXHV];
-    float2 abreg[8];
-    bool st_xf = false;
-    int st_ctot = 0, st_c = 0;
-    auto halo_issue = [&](const ConvPhase& ph, int chunk) __attribute__((always_inline)) {
+    u32x4 hreg[MAXHV];
+    f32x4 abv[4];                  // (scale, shift) of this thread's 8 channels: abv[q] = {sc(2q), sh(2q), sc(2q+1), sh(2q+1)}
+    bool st_cok = true;
+    int st_c = 0;
+    auto halo_issue = [&](int chunk) __attribute__((always_inline)) {
+        // Loads are UNCONDITIONAL (clamped addresses): a predicated load would be merged with its zero
+        // alternative right away, and that use would wait for the load (draining the weight ring).
+        // Out-of-image pixels / channels past the end are zeroed at commit time instead.
         const int c = chunk * BK + cv * 8;
+        st_cok = c < ctot;
+        const int cc = st_cok ? c : 0;
         const bf16* src;
         int cs, cl;
-        if (c < ph.C0) { src = (const bf16*)ph.src0; cs = ph.C0; cl = c; }
-        else           { src = (const bf16*)ph.src1; cs = ph.C1; cl = c - ph.C0; }
-        st_ctot = ph.C0 + ph.C1;
-        st_c = c;
-        const bool cok = c < st_ctot;
+        if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; }
+        else           { src = p.src1; cs = p.C1; cl = cc - p.C0; }
+        st_c = cc;
 #pragma unroll
-        for (int i = 0; i < C::MAXHV; ++i) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            hreg[i] = (hv_pix[i] >= 0 && cok) ? *reinterpret_cast<const u32x4*>(src + (size_t)hv_pix[i] * cs + cl) : z;
+        for (int i = 0; i < MAXHV; ++i) {
+            const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
+            hreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)pix * cs + cl);
         }
-        st_xf = (C::XF != XF_NONE) && ph.transform != XF_NONE && cok;
-        if (NI == 1 && st_xf) {
-            const float2* ab = ph.gn_ab + (size_t)st_b0 * st_ctot + c;
+        if (C::XF != XF_NONE && NI == 1) {
+            const f32x4* ab = p.gn_ab + (((size_t)st_b0 * ctot + cc) >> 1);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) abreg[k] = ab[k];
+            for (int q = 0; q < 4; ++q) abv[q] = ab[q];
         }
     };
-    const ConvPhase* st_ph = &p.ph[0];
     auto halo_commit_one = [&](int i, int buf) __attribute__((always_inline)) {
-        if (hv_lds[i] < 0) return;
+        if (i == MAXHV - 1 && !last_live) return;
         float v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[2 * k] = __uint_as_float(hreg[i][k] << 16);
             v[2 * k + 1] = __uint_as_float(hreg[i][k] & 0xffff0000u);
         }
+        const bool live = st_cok && hv_pix[i] >= 0;             // zero padding stays zero (pad AFTER activation)
         if (C::XF != XF_NONE) {
-            if (st_xf && hv_pix[i] >= 0) {
-                if (NI > 1) {
-                    const int img = (hv_lds[i] / PSTR) / HPIX;
-                    const float2* ab = st_ph->gn_ab + (size_t)(st_b0 + img) * st_ctot + st_c;
+            if (NI > 1) {
+                const int img = ((hv_lds0 + i * HV_LDS_STEP) / PSTR) / HPIX;
+                const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
+                const f32x4* ab = p.gn_ab + (((size_t)bb * ctot + st_c) >> 1);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) abreg[k] = ab[k];
-                }
+                for (int q = 0; q < 4; ++q) abv[q] = ab[q];
+            }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = silu(fmaf(v[k], abreg[k].x, abreg[k].y));
+            for (int q = 0; q < 4; ++q) {
+                v[2 * q] = silu_fast(fmaf(v[2 * q], abv[q][0], abv[q][1]));
+                v[2 * q + 1] = silu_fast(fmaf(v[2 * q + 1], abv[q][2], abv[q][3]));
             }
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = live ? v[k] : 0.f;
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
-        *reinterpret_cast<bf16x8*>(halo + buf * C::HALO_ELEMS + hv_lds[i]) = o;
+        *reinterpret_cast<bf16x8*>(halo + buf * C::HALO_ELEMS + hv_lds0 + i * HV_LDS_STEP) = o;
     };
 
     // ---- MFMA fragment bases --------------------------------------------------------------------------------------
@@ -211,38 +223,64 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
 
-    // ---- chunk bookkeeping -------------------------------------------------------------------------------------------
-    const int nch0 = p.ph[0].nchunks;
-    const int nch = nch0 + (p.nphase > 1 ? p.ph[1].nchunks : 0);
+    // ---- staging cursor: the (item, chunk) whose halo tile is fetched next -------------------------------------------
+    const int nch = p.nchunks;
     int cur = 0;                 // halo buffer being consumed
-    int chunk = 0, tap = 0;      // position inside the current item
-    int ntaps = p.ph[0].ntaps;
-    int st_item = item;          // item whose chunks are being staged
-    int st_chunk = 0;
-    bool st_valid = true;        // a chunk is pending in hreg / being staged
-
-    // prologue: first weights, first halo tile (synchronously)
-    b_issue(ring[0]);
-    b_issue(ring[1]);
-    describe(item);
-    st_ph = &p.ph[0];
-    halo_issue(*st_ph, 0);
-#pragma unroll
-    for (int i = 0; i < C::MAXHV; ++i) halo_commit_one(i, 0);
-    lds_barrier();
-    // advance the staging cursor to the chunk after (item, 0)
+    int st_item = item, st_chunk = 0;
+    bool st_valid = true;
     auto stage_advance = [&]() __attribute__((always_inline)) {
         if (st_chunk + 1 < nch) { st_chunk += 1; }
         else { st_chunk = 0; st_item += G; }
         st_valid = st_item < p.total_items;
     };
+
+    // prologue: first two weight steps, first halo tile (synchronously)
+    b_issue(ring[0]);
+    b_issue(ring[1]);
+    describe(item);
+    halo_issue(0);
+#pragma unroll
+    for (int i = 0; i < MAXHV; ++i) halo_commit_one(i, 0);
+    lds_barrier();
     stage_advance();
 
-    auto epilogue = [&](int it) __attribute__((always_inline)) {
+    for (int it = 0; it < n_items_blk; ++it, item += G) {
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bf16* hb = halo + cur * C::HALO_ELEMS;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                b_issue(ring[(tap + 2) % 3]);                  // weights two K steps ahead
+                if (tap == 0 && st_valid) {                    // next chunk's halo vectors + GroupNorm parameters
+                    if (st_chunk == 0) describe(st_item);
+                    halo_issue(st_chunk);
+                }
+                const int aoff = ((tap / 3) * HCOLS + (tap % 3)) * PSTR;
+                // A fragments double-buffered over the four k-slices of this tap
+                bf16x8 a[2][MR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[0][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + aoff);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk < 3) {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+                            a[(kk + 1) & 1][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + aoff + (kk + 1) * 16);
+                    }
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                }
+                if (tap >= 2 && tap - 2 < MAXHV && st_valid) halo_commit_one(tap - 2, cur ^ 1);
+            }
+            lds_barrier();                                     // next halo tile complete; this one free for re-use
+            cur ^= 1;
+            if (st_valid) stage_advance();
+        }
+
+        // ---- epilogue of this item ------------------------------------------------------------------------------------
         int b0, oy0, ox0;
-        tile_coords(it, b0, oy0, ox0);
-        const int mt = it / p.n_slices;
-        const int trem = mt % tiles_per_img;
+        tile_coords(item, b0, oy0, ox0);
+        const int trem = (item / p.n_slices) % tiles_per_img;
         const int n = n0 + wn * 32 + lr;
         const bool nok = n < p.Cout;
         const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
@@ -279,9 +317,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             // wave partial over its pixels: combine the two lane halves, lanes 0..31 write one entry each
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
-                float a = s1[q] + __shfl_xor(s1[q], 32, 64);
-                float d = s2[q] + __shfl_xor(s2[q], 32, 64);
-                // which (image, sub-entry) this wave's sum belongs to
+                const float a = s1[q] + __shfl_xor(s1[q], 32, 64);
+                const float d = s2[q] + __shfl_xor(s2[q], 32, 64);
                 int img, sub;
                 if (NI == 1) { img = 0; sub = wm; }
                 else if (WM == 1) { img = q; sub = 0; }
@@ -291,66 +328,6 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     p.stats[((size_t)b * (tiles_per_img * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n] = make_float2(a, d);
             }
         }
-    };
-
-    // ---- one K step; SLOT = position in the weight ring (compile-time) ------------------------------------------------
-    auto step = [&](auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_tag)::value;
-        b_issue(ring[(SLOT + 2) % 3]);
-        if (tap == 0 && st_valid) {                      // fetch the next chunk's halo vectors (and its GN params)
-            if (st_chunk == 0) describe(st_item);
-            st_ph = (st_chunk < nch0) ? &p.ph[0] : &p.ph[1];
-            halo_issue(*st_ph, st_chunk < nch0 ? st_chunk : st_chunk - nch0);
-        }
-        int aoff = PSTR * (HCOLS + 1);                   // centre tap (fused 1x1 projection)
-        if (ntaps == 9) {
-            const int dy = tap / 3;
-            aoff = (dy * HCOLS + (tap - 3 * dy)) * PSTR;
-        }
-        const bf16* hb = halo + cur * C::HALO_ELEMS + aoff;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[MR];
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) a[mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + kk * 16);
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-                acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], ring[SLOT][kk], acc[mr], 0, 0, 0);
-        }
-        // staging work in the shadow of the MFMAs: vector (tap-2) now, everything left at the last tap
-        if (st_valid) {
-            const bool last_tap = tap == ntaps - 1;
-#pragma unroll
-            for (int i = 0; i < C::MAXHV; ++i) {
-                const bool mine = (ntaps == 9) ? (tap == i + 2 || (last_tap && i + 2 > tap)) : true;
-                if (mine) halo_commit_one(i, cur ^ 1);
-            }
-        }
-        // advance
-        tap += 1;
-        if (tap == ntaps) {
-            tap = 0;
-            chunk += 1;
-            lds_barrier();                               // next halo tile complete; this one free for re-use
-            cur ^= 1;
-            if (st_valid) stage_advance();
-            if (chunk == nch) {
-                epilogue(item);
-                chunk = 0;
-                item += G;
-                ntaps = p.ph[0].ntaps;
-            } else if (chunk == nch0) {
-                ntaps = p.ph[1].ntaps;
-            }
-        }
-    };
-
-    for (int s = 0; s < total_steps; s += 3) {
-        step(SlotTag<0>{});
-        if (s + 1 >= total_steps) break;
-        step(SlotTag<1>{});
-        if (s + 2 >= total_steps) break;
-        step(SlotTag<2>{});
     }
 }
 

@@ -147,6 +147,10 @@ def set_use_v2(flag):
     _use_v2 = bool(flag)
 
 
+def use_v2():
+    return _use_v2
+
+
 def set_conv_probe(records):
     """records: a list to append per-launch {events, flops, shape} dicts to, or None to switch the hook off."""
     global _conv_probe

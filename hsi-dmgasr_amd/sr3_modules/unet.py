@@ -185,11 +185,19 @@ class ResnetBlock(_HipModule):
         self.block1 = Block(dim, dim_out, groups=norm_groups)
         self.block2 = Block(dim_out, dim_out, groups=norm_groups, dropout=dropout)
         self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+        self._cache = _PackCache()
 
     def _run(self, x0, x1, film, precision):
         """x = cat(x0, x1) on channels (x1 may be None); film: [B, dim_out] slice of the FiLM table."""
         h = self.block1._run(x0, precision, x1=x1, film=film)
         if isinstance(self.res_conv, nn.Conv2d):
+            if precision == "bf16" and ops.use_v2():
+                # throughput mode: the persistent 3x3 kernel is single-phase; the 1x1 projection is its own
+                # launch and enters block2's epilogue as the residual
+                rc = self.res_conv
+                pk = self._cache.get(("proj", precision), [rc.weight, rc.bias], lambda: ops.PackedConv(rc.weight, rc.bias, precision))
+                r = ops.conv2d(x0, pk, x1=x1)
+                return self.block2._run(h, precision, res=r)
             return self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1)
         assert x1 is None
         return self.block2._run(h, precision, res=x0)
