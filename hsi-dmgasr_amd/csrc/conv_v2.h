@@ -8,8 +8,8 @@
 //     straight from L2 into registers (pre-packed so that one wave-load is one contiguous 1 KiB),
 //     through a 3-deep register ring issued two K steps ahead -> no per-step barrier, no LDS writes;
 //   * the input halo tile is double-buffered in LDS; the 9 taps of a chunk are fully unrolled with a
-//     STATIC schedule: tap 0 issues the next chunk's halo + GroupNorm-parameter loads, taps 2..8 each
-//     normalise / SiLU / pack one 16-B vector into the other buffer in the shadow of that tap's MFMAs
+//     STATIC schedule: tap i issues the load of the next chunk's i-th halo vector, tap i+3 normalises /
+//     SiLUs / packs it into the other buffer in the shadow of that tap's MFMAs
 //     (nothing is consumed right after its load, so no wait drains the weight ring); one LDS-only
 //     barrier per chunk; A fragments are double-buffered across the four k-slices of a tap;
 //   * SiLU uses v_exp + v_rcp (5 VALU per element instead of an IEEE division);
@@ -44,6 +44,7 @@ struct ConvV2Params {
     int ups, act;
     int tiles_x, tiles_y;
     int m_tiles, n_slices, total_items, steps_per_item;
+    int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };
 
 template <int BN_, int TH_, int TW_, int NI_, int XF_>
@@ -62,6 +63,14 @@ struct V2Cfg {
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
+
+template <int V> struct SlotTag { static constexpr int value = V; };
+
+#ifdef HSIDM_V2_ABLATE
+#define HSIDM_ABL(mask) (p.abl & (mask))
+#else
+#define HSIDM_ABL(mask) false
+#endif
 
 __device__ __forceinline__ void lds_barrier() {
     // LDS-only ordering: keeps the register-ring weight loads in flight across the barrier
@@ -106,8 +115,10 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     int wnext = 0;                                              // step (within an item) of the next weight fetch
     auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
         const bf16* src = wlane + (size_t)wnext * wstep_stride;
+        if (!(HSIDM_ABL(8))) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
+            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
+        }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
 
@@ -117,6 +128,15 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int HV_LDS_STEP = (256 / VPP) * PSTR;
     const bool last_live = tid + (MAXHV - 1) * 256 < C::HVEC;  // the last vector slot is partial
     int hv_pix[MAXHV];                                          // for the tile being STAGED
+    int hv_pos[MAXHV];                                          // tile-independent: img<<16 | hy<<8 | hx, or -1 (dead slot)
+#pragma unroll
+    for (int i = 0; i < MAXHV; ++i) {
+        const int hp = (tid + i * 256) / VPP;
+        const int img = hp / HPIX;
+        const int r = hp - img * HPIX;
+        const int hy = r / HCOLS, hx = r - hy * HCOLS;
+        hv_pos[i] = (i < MAXHV - 1 || last_live) ? ((img << 16) | (hy << 8) | hx) : -1;
+    }
     int st_b0 = 0;
     auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {
         const int mt = it / p.n_slices;
@@ -130,62 +150,53 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         int b0, oy0, ox0;
         tile_coords(it, b0, oy0, ox0);
         st_b0 = b0;
+        const int hlim = p.ups ? 2 * p.Hin : p.Hin, wlim = p.ups ? 2 * p.Win : p.Win;
+        const int sh = p.ups ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int v = tid + i * 256;
-            int pix = -1;
-            if (i < MAXHV - 1 || last_live) {
-                const int hp = v / VPP;
-                const int img = hp / HPIX;
-                const int r = hp - img * HPIX;
-                const int hy = r / HCOLS, hx = r - hy * HCOLS;
-                int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-                const int b = b0 + img;
-                bool ok = b < p.B && iy >= 0 && ix >= 0;
-                if (p.ups) { ok = ok && iy < 2 * p.Hin && ix < 2 * p.Win; iy >>= 1; ix >>= 1; }
-                else       { ok = ok && iy < p.Hin && ix < p.Win; }
-                if (ok) pix = (b * p.Hin + iy) * p.Win + ix;
-            }
-            hv_pix[i] = pix;
+            const int pos = hv_pos[i];
+            const int b = b0 + (pos >> 16);
+            const int iy = oy0 + ((pos >> 8) & 255) - 1, ix = ox0 + (pos & 255) - 1;
+            const bool ok = pos >= 0 && b < p.B && iy >= 0 && ix >= 0 && iy < hlim && ix < wlim;
+            hv_pix[i] = ok ? (b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh) : -1;
         }
     };
-    u32x4 hreg[MAXHV];
+    u32x4 hreg[4];                 // staged raw vectors: vector i lives in slot i % 4 from tap i (issue) to tap min(i+3, 8) (commit)
     f32x4 abv[4];                  // (scale, shift) of this thread's 8 channels: abv[q] = {sc(2q), sh(2q), sc(2q+1), sh(2q+1)}
     bool st_cok = true;
-    int st_c = 0;
-    auto halo_issue = [&](int chunk) __attribute__((always_inline)) {
-        // Loads are UNCONDITIONAL (clamped addresses): a predicated load would be merged with its zero
-        // alternative right away, and that use would wait for the load (draining the weight ring).
-        // Out-of-image pixels / channels past the end are zeroed at commit time instead.
+    int st_c = 0, st_cs = 0, st_cl = 0;
+    const bf16* st_src = p.src0;
+    auto halo_begin = [&](int chunk) __attribute__((always_inline)) {
+        // channel slice of the chunk being staged (+ its GroupNorm parameters).  Loads are UNCONDITIONAL (clamped
+        // addresses): a predicated load would be merged with its zero alternative right away and that use would
+        // wait for the load, draining the weight ring; out-of-range data is zeroed at commit time instead.
         const int c = chunk * BK + cv * 8;
         st_cok = c < ctot;
         const int cc = st_cok ? c : 0;
-        const bf16* src;
-        int cs, cl;
-        if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; }
-        else           { src = p.src1; cs = p.C1; cl = cc - p.C0; }
+        if (cc < p.C0) { st_src = p.src0; st_cs = p.C0; st_cl = cc; }
+        else           { st_src = p.src1; st_cs = p.C1; st_cl = cc - p.C0; }
         st_c = cc;
-#pragma unroll
-        for (int i = 0; i < MAXHV; ++i) {
-            const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
-            hreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)pix * cs + cl);
-        }
         if (C::XF != XF_NONE && NI == 1) {
             const f32x4* ab = p.gn_ab + (((size_t)st_b0 * ctot + cc) >> 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) abv[q] = ab[q];
         }
     };
+    auto halo_issue_one = [&](int i) __attribute__((always_inline)) {
+        if (HSIDM_ABL(4)) return;
+        const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
+        hreg[i & 3] = *reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
+    };
     auto halo_commit_one = [&](int i, int buf) __attribute__((always_inline)) {
         if (i == MAXHV - 1 && !last_live) return;
         float v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[2 * k] = __uint_as_float(hreg[i][k] << 16);
-            v[2 * k + 1] = __uint_as_float(hreg[i][k] & 0xffff0000u);
+            v[2 * k] = __uint_as_float(hreg[i & 3][k] << 16);
+            v[2 * k + 1] = __uint_as_float(hreg[i & 3][k] & 0xffff0000u);
         }
         const bool live = st_cok && hv_pix[i] >= 0;             // zero padding stays zero (pad AFTER activation)
-        if (C::XF != XF_NONE) {
+        if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
             if (NI > 1) {
                 const int img = ((hv_lds0 + i * HV_LDS_STEP) / PSTR) / HPIX;
                 const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
@@ -238,39 +249,52 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     b_issue(ring[0]);
     b_issue(ring[1]);
     describe(item);
-    halo_issue(0);
+    halo_begin(0);
 #pragma unroll
-    for (int i = 0; i < MAXHV; ++i) halo_commit_one(i, 0);
+    for (int i = 0; i < MAXHV; ++i) {
+        halo_issue_one(i);
+        halo_commit_one(i, 0);
+    }
     lds_barrier();
     stage_advance();
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bf16* hb = halo + cur * C::HALO_ELEMS;
+            // A fragments: 3-deep register ring over the 36 (tap, k-slice) sub-steps of the chunk, fetched two
+            // sub-steps ahead (measured: with one sub-step of lookahead every k-slice waited ~300 cycles on LDS)
+            bf16x8 a[3][MR];
+            auto a_fetch = [&](int u) __attribute__((always_inline)) {
+                const int tp = u >> 2, kq = u & 3;
+                const int off = ((tp / 3) * HCOLS + (tp % 3)) * PSTR + kq * 16;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + off);
+            };
+            a_fetch(0);
+            a_fetch(1);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 b_issue(ring[(tap + 2) % 3]);                  // weights two K steps ahead
-                if (tap == 0 && st_valid) {                    // next chunk's halo vectors + GroupNorm parameters
-                    if (st_chunk == 0) describe(st_item);
-                    halo_issue(st_chunk);
+                if (st_valid) {                                // staging of the next chunk, one vector per tap
+                    if (tap == 0) {
+                        if (st_chunk == 0) describe(st_item);
+                        halo_begin(st_chunk);
+                    }
+                    if (tap < MAXHV) halo_issue_one(tap);
                 }
-                const int aoff = ((tap / 3) * HCOLS + (tap % 3)) * PSTR;
-                // A fragments double-buffered over the four k-slices of this tap
-                bf16x8 a[2][MR];
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[0][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + aoff);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    if (kk < 3) {
-#pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            a[(kk + 1) & 1][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + aoff + (kk + 1) * 16);
-                    }
+                    const int u = tap * 4 + kk;
+                    if (u + 2 < 36) a_fetch(u + 2);
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);         // keep the two-sub-step LDS lookahead the source expresses
                 }
-                if (tap >= 2 && tap - 2 < MAXHV && st_valid) halo_commit_one(tap - 2, cur ^ 1);
+                if (st_valid && !(HSIDM_ABL(16))) {
+                    if (tap >= 3 && tap - 3 < MAXHV) halo_commit_one(tap - 3, cur ^ 1);
+                    if (tap == 8 && MAXHV == 7) halo_commit_one(6, cur ^ 1);
+                }
             }
             lds_barrier();                                     // next halo tile complete; this one free for re-use
             cur ^= 1;
@@ -287,6 +311,40 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         float s1[NI], s2[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) s1[q] = s2[q] = 0.f;
+        const bool full = oy0 + TH <= p.Hout && ox0 + TW <= p.Wout && b0 + NI <= p.B && n0 + BN <= p.Cout;
+        if (full) {
+            // whole tile inside the image: no per-element predicates; addresses = uniform row base (SALU) + a
+            // per-lane element offset that is the same for all 16*MR values (tx = (c & (TW-1)) + 4*lh never carries)
+            constexpr int LTW = (TW == 16) ? 4 : 3;
+            const unsigned lane_b = (unsigned)(4 * lh * p.Cout + wn * 32 + lr) * 2u;     // byte offset, fits 32 bits
+            auto run = [&](auto leaky_tag) __attribute__((always_inline)) {
+                constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    const int pbase = wm * (C::BM / WM) + mr * 32;
+                    const int img = pbase / (TH * TW);
+                    const int qimg = pbase - img * (TH * TW);
+                    const int b = b0 + img;
+                    const float add = bias + (p.film ? p.film[(size_t)b * p.film_stride + n] : 0.f);
+                    const size_t img_base = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.Cout + n0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int q = qimg + (j & 3) + 8 * (j >> 2);                 // uniform (lh adds 4 to tx)
+                        const size_t row_el = img_base + (size_t)((q >> LTW) * p.Wout + (q & (TW - 1))) * p.Cout;
+                        float v = acc[mr][j] + add;
+                        acc[mr][j] = 0.f;
+                        if (LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        if (p.res) v = fmaf(p.res_scale, v, (float)*reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(p.res + row_el) + lane_b));
+                        const bf16 st = (bf16)v;
+                        if (!(HSIDM_ABL(1))) *reinterpret_cast<bf16*>(reinterpret_cast<char*>(p.out + row_el) + lane_b) = st;
+                        const float sv = (float)st;
+                        s1[NI == 1 ? 0 : img] += sv;
+                        s2[NI == 1 ? 0 : img] = fmaf(sv, sv, s2[NI == 1 ? 0 : img]);
+                    }
+                }
+            };
+            if (p.act == ACT_LEAKY) run(SlotTag<1>{}); else run(SlotTag<0>{});
+        } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             const int pbase = wm * (C::BM / WM) + mr * 32;
@@ -307,11 +365,12 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;
                 if (p.res) v = p.res_scale * v + (float)p.res[o];
                 const bf16 st = (bf16)v;
-                p.out[o] = st;
+                if (!(HSIDM_ABL(1))) p.out[o] = st;
                 const float sv = (float)st;
                 s1[NI == 1 ? 0 : img] += sv;
                 s2[NI == 1 ? 0 : img] += sv * sv;
             }
+        }
         }
         if (p.stats) {
             // wave partial over its pixels: combine the two lane halves, lanes 0..31 write one entry each

@@ -1,5 +1,6 @@
 // Instantiations + launcher of the persistent bf16 3x3 convolution (conv_v2.h).
 #include "conv_v2.h"
+#include <cstdlib>
 
 namespace hsidm {
 
@@ -22,6 +23,9 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
             cus = 256;
         g_slots = 2 * cus;
     }
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("HSIDM_V2_ABL"); abl = e ? atoi(e) : 0; }
+    p.abl = abl;
     const int imgs = (p.B + C::NI - 1) / C::NI;
     p.m_tiles = imgs * p.tiles_x * p.tiles_y;
     p.n_slices = p.Cout_pad / C::BN;
