@@ -15,11 +15,15 @@ HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 #undef HSIDM_DECL
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
+void conv_v2_set_stamps(unsigned long long* p);
 }  // namespace hsidm
 
 using namespace hsidm;
 
 extern "C" int hsidm_version(void) { return 1; }
+
+// Diagnostic builds (-DHSIDM_V2_STAMPS): device buffer [blocks][4][8][16] of s_memtime stamps; not part of hsidm.h.
+extern "C" void hsidm_debug_set_stamps(void* p) { conv_v2_set_stamps(reinterpret_cast<unsigned long long*>(p)); }
 
 extern "C" const char* hsidm_error_string(int code) {
     switch (code) {

@@ -6,7 +6,10 @@ OUT="$HERE/../libhsidm.so"
 OBJ="$HERE/obj"
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable ${HSIDM_EXTRA_FLAGS:-}"
+OUT="${HSIDM_OUT:-$OUT}"
+OBJ="${HSIDM_OBJ:-$OBJ}"
+mkdir -p "$OBJ"
 JOBS="${JOBS:-6}"
 pids=()
 for src in "$HERE"/*.hip; do

@@ -44,6 +44,7 @@ struct ConvV2Params {
     int ups, act;
     int tiles_x, tiles_y;
     int m_tiles, n_slices, total_items, steps_per_item;
+    unsigned long long* stamps;   // diagnostic build (HSIDM_V2_STAMPS): [block][wave][item<8][slot<16] s_memtime
     int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };
 
@@ -66,6 +67,19 @@ struct V2Cfg {
 
 template <int V> struct SlotTag { static constexpr int value = V; };
 
+#ifdef HSIDM_V2_STAMPS
+#define HSIDM_STAMP(it_, slot_)                                                                             \
+    do {                                                                                                     \
+        if (p.stamps && (it_) < 8 && lane == 0) {                                                            \
+            unsigned long long t_;                                                                           \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+            p.stamps[(((size_t)blockIdx.x * 4 + wave) * 8 + (it_)) * 16 + (slot_)] = t_;                     \
+        }                                                                                                    \
+    } while (0)
+#else
+#define HSIDM_STAMP(it_, slot_) do {} while (0)
+#endif
+
 #ifdef HSIDM_V2_ABLATE
 #define HSIDM_ABL(mask) (p.abl & (mask))
 #else
@@ -78,6 +92,14 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+    h16x2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float h2_lo(unsigned u) { return (float)__builtin_bit_cast(h16x2, u)[0]; }
+__device__ __forceinline__ float h2_hi(unsigned u) { return (float)__builtin_bit_cast(h16x2, u)[1]; }
 
 __device__ __forceinline__ float silu_fast(float y) {
     // y * sigmoid(y) with v_exp_f32 / v_rcp_f32 (about 1e-6 relative; the result is rounded to bf16)
@@ -128,15 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int HV_LDS_STEP = (256 / VPP) * PSTR;
     const bool last_live = tid + (MAXHV - 1) * 256 < C::HVEC;  // the last vector slot is partial
     int hv_pix[MAXHV];                                          // for the tile being STAGED
-    int hv_pos[MAXHV];                                          // tile-independent: img<<16 | hy<<8 | hx, or -1 (dead slot)
-#pragma unroll
-    for (int i = 0; i < MAXHV; ++i) {
-        const int hp = (tid + i * 256) / VPP;
+    auto hv_pos = [&](int i) __attribute__((always_inline)) -> int {   // img<<16 | hy<<8 | hx, or -1 (dead slot); recomputed, not kept
+        const int hp = tid / VPP + i * (256 / VPP);
         const int img = hp / HPIX;
         const int r = hp - img * HPIX;
         const int hy = r / HCOLS, hx = r - hy * HCOLS;
-        hv_pos[i] = (i < MAXHV - 1 || last_live) ? ((img << 16) | (hy << 8) | hx) : -1;
-    }
+        return (i < MAXHV - 1 || last_live) ? ((img << 16) | (hy << 8) | hx) : -1;
+    };
     int st_b0 = 0;
     auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {
         const int mt = it / p.n_slices;
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const int sh = p.ups ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int pos = hv_pos[i];
+            const int pos = hv_pos(i);
             const int b = b0 + (pos >> 16);
             const int iy = oy0 + ((pos >> 8) & 255) - 1, ix = ox0 + (pos & 255) - 1;
             const bool ok = pos >= 0 && b < p.B && iy >= 0 && ix >= 0 && iy < hlim && ix < wlim;
@@ -162,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         }
     };
     u32x4 hreg[4];                 // staged raw vectors: vector i lives in slot i % 4 from tap i (issue) to tap min(i+3, 8) (commit)
-    f32x4 abv[4];                  // (scale, shift) of this thread's 8 channels: abv[q] = {sc(2q), sh(2q), sc(2q+1), sh(2q+1)}
+    unsigned abh[8];               // (scale, shift) of this thread's 8 channels, packed fp16x2: 11-bit significands, the
+                                   // transformed value is rounded to bf16 (8 bits) anyway; halves the registers held across taps
     bool st_cok = true;
     int st_c = 0, st_cs = 0, st_cl = 0;
     const bf16* st_src = p.src0;
@@ -179,7 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         if (C::XF != XF_NONE && NI == 1) {
             const f32x4* ab = p.gn_ab + (((size_t)st_b0 * ctot + cc) >> 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) abv[q] = ab[q];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = ab[q];
+                abh[2 * q] = pack_h2(t[0], t[1]);
+                abh[2 * q + 1] = pack_h2(t[2], t[3]);
+            }
         }
     };
     auto halo_issue_one = [&](int i) __attribute__((always_inline)) {
@@ -202,13 +227,14 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
                 const f32x4* ab = p.gn_ab + (((size_t)bb * ctot + st_c) >> 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) abv[q] = ab[q];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = ab[q];
+                    abh[2 * q] = pack_h2(t[0], t[1]);
+                    abh[2 * q + 1] = pack_h2(t[2], t[3]);
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[2 * q] = silu_fast(fmaf(v[2 * q], abv[q][0], abv[q][1]));
-                v[2 * q + 1] = silu_fast(fmaf(v[2 * q + 1], abv[q][2], abv[q][3]));
-            }
+            for (int k = 0; k < 8; ++k) v[k] = silu_fast(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = live ? v[k] : 0.f;
@@ -229,10 +255,6 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         abase[mr] = (img * HPIX + ty * HCOLS + tx) * PSTR + 8 * lh;
     }
     f32x16 acc[MR];
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
 
     // ---- staging cursor: the (item, chunk) whose halo tile is fetched next -------------------------------------------
     const int nch = p.nchunks;
@@ -258,7 +280,35 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     lds_barrier();
     stage_advance();
 
+    // per-lane output channel and its bias are fixed for the whole block; the FiLM term depends on the item's
+    // image and is fetched ONE ITEM AHEAD.  bias + FiLM is the accumulators' start value, so the epilogue neither adds
+    // nor waits for them.
+    const int n = n0 + wn * 32 + lr;
+    const bool nok = n < p.Cout;
+    const int nn = nok ? n : 0;
+    const float bias = p.bias ? p.bias[nn] : 0.f;
+    float film_nx[NI];
+    auto film_fetch = [&](int it_item) __attribute__((always_inline)) {
+        const int itc = it_item < p.total_items ? it_item : blockIdx.x;       // past the end: any valid item
+        const int fb0 = ((itc / p.n_slices) / tiles_per_img) * NI;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
+            film_nx[q] = p.film ? p.film[(size_t)fb * p.film_stride + nn] : 0.f;
+        }
+    };
+    film_fetch(item);
+
     for (int it = 0; it < n_items_blk; ++it, item += G) {
+        HSIDM_STAMP(it, 0);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int img = (wm * (C::BM / WM) + mr * 32) / (TH * TW);
+            const float start = nok ? bias + film_nx[NI == 1 ? 0 : img] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mr][j] = start;
+        }
+        film_fetch(item + G);
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bf16* hb = halo + cur * C::HALO_ELEMS;
             // A fragments: 3-deep register ring over the 36 (tap, k-slice) sub-steps of the chunk, fetched two
@@ -296,70 +346,135 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     if (tap == 8 && MAXHV == 7) halo_commit_one(6, cur ^ 1);
                 }
             }
+            HSIDM_STAMP(it, 10);                               // (last chunk's) MFMAs + commits issued
             lds_barrier();                                     // next halo tile complete; this one free for re-use
+            if (chunk < 8) HSIDM_STAMP(it, 1 + chunk);
             cur ^= 1;
             if (st_valid) stage_advance();
         }
 
         // ---- epilogue of this item ------------------------------------------------------------------------------------
+        HSIDM_STAMP(it, 12);
         int b0, oy0, ox0;
         tile_coords(item, b0, oy0, ox0);
         const int trem = (item / p.n_slices) % tiles_per_img;
-        const int n = n0 + wn * 32 + lr;
-        const bool nok = n < p.Cout;
-        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
         float s1[NI], s2[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) s1[q] = s2[q] = 0.f;
         const bool full = oy0 + TH <= p.Hout && ox0 + TW <= p.Wout && b0 + NI <= p.B && n0 + BN <= p.Cout;
         if (full) {
-            // whole tile inside the image: no per-element predicates; addresses = uniform row base (SALU) + a
-            // per-lane element offset that is the same for all 16*MR values (tx = (c & (TW-1)) + 4*lh never carries)
+            // Whole tile inside the image.  2-byte stores straight from the accumulator layout cost ~200 cycles each
+            // (in-kernel stamps: the epilogue took as long as 9 K steps), so the wave transposes its 64-pixel x 32-cout
+            // half tiles through a private patch of the just-freed halo buffer and moves 16-byte vectors (8 couts of one
+            // pixel): residual add, statistics and the store happen on those vectors.  All residual vectors of the item
+            // are requested up front so that their latency hides behind the transposition.
             constexpr int LTW = (TW == 16) ? 4 : 3;
-            const unsigned lane_b = (unsigned)(4 * lh * p.Cout + wn * 32 + lr) * 2u;     // byte offset, fits 32 bits
-            auto run = [&](auto leaky_tag) __attribute__((always_inline)) {
+            constexpr int SCR_STR = 40;                                       // bf16 per pixel row: 32 couts + 16 B pad
+            constexpr int NV = 2 * MR;                                        // 16-B vectors per lane and item
+            bf16* scr = halo + (cur ^ 1) * C::HALO_ELEMS + wave * (64 * SCR_STR);
+            // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));                                 // keep these lane constants out of the main loop's registers
+            const int pl0 = lane_e >> 2, cq = lane_e & 3;
+            const unsigned lane_el = (unsigned)(((pl0 >> LTW) * p.Wout + (pl0 & (TW - 1))) * p.Cout + cq * 8);
+            auto vec_base = [&](int g, int v4) __attribute__((always_inline)) -> size_t {
+                const int pbase = wm * (C::BM / WM) + g * 32;
+                const int img = pbase / (TH * TW);
+                const int qimg = pbase - img * (TH * TW);
+                const int ty = (qimg >> LTW) + v4 * (16 >> LTW);
+                return (((size_t)(b0 + img) * p.Hout + oy0 + ty) * p.Wout + ox0) * p.Cout + n0 + wn * 32;
+            };
+            auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
                 constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
+                constexpr bool RES = decltype(res_tag)::value != 0;
+                bf16x8 rv[RES ? NV : 1];
+                if (RES) {
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    const int pbase = wm * (C::BM / WM) + mr * 32;
-                    const int img = pbase / (TH * TW);
-                    const int qimg = pbase - img * (TH * TW);
+                    for (int g = 0; g < MR; g += 2)
+#pragma unroll
+                        for (int v4 = 0; v4 < 4; ++v4)
+                            if (v4 < 2 * (MR - g < 2 ? MR - g : 2))
+                                rv[g * 2 + v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(g, v4) + lane_el);
+                }
+                float vs1[8], vs2[8];
+#pragma unroll
+                for (int g = 0; g < MR; g += 2) {
+                    const int nm = (MR - g) < 2 ? (MR - g) : 2;                // 32-row MFMA tiles in this pass
+                    const int pbase = wm * (C::BM / WM) + g * 32;
+                    const int img = pbase / (TH * TW);                         // a pass never straddles two images
                     const int b = b0 + img;
-                    const float add = bias + (p.film ? p.film[(size_t)b * p.film_stride + n] : 0.f);
-                    const size_t img_base = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.Cout + n0;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int q = qimg + (j & 3) + 8 * (j >> 2);                 // uniform (lh adds 4 to tx)
-                        const size_t row_el = img_base + (size_t)((q >> LTW) * p.Wout + (q & (TW - 1))) * p.Cout;
-                        float v = acc[mr][j] + add;
-                        acc[mr][j] = 0.f;
-                        if (LEAKY) v = v > 0.f ? v : 0.01f * v;
-                        if (p.res) v = fmaf(p.res_scale, v, (float)*reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(p.res + row_el) + lane_b));
-                        const bf16 st = (bf16)v;
-                        if (!(HSIDM_ABL(1))) *reinterpret_cast<bf16*>(reinterpret_cast<char*>(p.out + row_el) + lane_b) = st;
-                        const float sv = (float)st;
-                        s1[NI == 1 ? 0 : img] += sv;
-                        s2[NI == 1 ? 0 : img] = fmaf(sv, sv, s2[NI == 1 ? 0 : img]);
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        if (m2 >= nm) break;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
+                            float v = acc[g + m2][j];                          // bias + FiLM are the accumulator's start value
+                            if (LEAKY) v = v > 0.f ? v : 0.01f * v;
+                            scr[(m2 * 32 + row) * SCR_STR + lr] = (bf16)v;
+                        }
+                    }
+                    if (NI == 2 || g == 0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
+                    }
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4) {
+                        if (v4 >= 2 * nm) break;
+                        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                        float f[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
+                        bf16x8 o = raw;
+                        if (RES) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                o[k] = (bf16)fmaf(p.res_scale, f[k], (float)rv[g * 2 + v4][k]);
+                                f[k] = (float)o[k];
+                            }
+                        }
+                        if (!HSIDM_ABL(1)) *reinterpret_cast<bf16x8*>(p.out + vec_base(g, v4) + lane_el) = o;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                    }
+                    if (p.stats && (NI == 2 || g + 2 >= MR)) {
+                        // lanes with equal (lane & 3) hold the same 8 couts: fold the 16 of them together
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                            for (int o2 = 4; o2 < 64; o2 <<= 1) {
+                                vs1[k] += __shfl_xor(vs1[k], o2, 64);
+                                vs2[k] += __shfl_xor(vs2[k], o2, 64);
+                            }
+                        }
+                        int sub;
+                        if (NI == 1) sub = wm;
+                        else if (WM == 1) sub = 0;
+                        else sub = wm % (WM / 2 > 0 ? WM / 2 : 1);
+                        if (lane < 4) {
+                            float2* dst = p.stats + ((size_t)b * (tiles_per_img * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n0 + wn * 32 + lane * 8;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) dst[k] = make_float2(vs1[k], vs2[k]);
+                        }
                     }
                 }
             };
-            if (p.act == ACT_LEAKY) run(SlotTag<1>{}); else run(SlotTag<0>{});
+            if (p.act == ACT_LEAKY) { if (p.res) run(SlotTag<1>{}, SlotTag<1>{}); else run(SlotTag<1>{}, SlotTag<0>{}); }
+            else                    { if (p.res) run(SlotTag<0>{}, SlotTag<1>{}); else run(SlotTag<0>{}, SlotTag<0>{}); }
+            lds_barrier();                                                   // the patch is part of the next staging buffer
         } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             const int pbase = wm * (C::BM / WM) + mr * 32;
             const int img = pbase / (TH * TW);                       // a 32-row MFMA tile never straddles images
             const int b = b0 + img;
-            float film = 0.f;
-            if (p.film && nok && b < p.B) film = p.film[(size_t)b * p.film_stride + n];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
                 const int q = pbase + row - img * (TH * TW);
                 const int ty = q / TW, tx = q - ty * TW;
                 const int oy = oy0 + ty, ox = ox0 + tx;
-                float v = acc[mr][j] + bias + film;
-                acc[mr][j] = 0.f;
+                float v = acc[mr][j];
                 if (!(nok && b < p.B && oy < p.Hout && ox < p.Wout)) continue;
                 if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;
@@ -372,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             }
         }
         }
-        if (p.stats) {
+        if (p.stats && !full) {
             // wave partial over its pixels: combine the two lane halves, lanes 0..31 write one entry each
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
@@ -387,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     p.stats[((size_t)b * (tiles_per_img * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n] = make_float2(a, d);
             }
         }
+        HSIDM_STAMP(it, 13);
     }
 }
 

@@ -5,6 +5,7 @@
 namespace hsidm {
 
 static int g_slots = 0;      // co-resident workgroups: 2 per CU
+unsigned long long* g_stamps = nullptr;   // diagnostic builds only
 
 template <typename C>
 static int run_v2(ConvV2Params& p, hipStream_t s) {
@@ -26,6 +27,7 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("HSIDM_V2_ABL"); abl = e ? atoi(e) : 0; }
     p.abl = abl;
+    p.stamps = g_stamps;
     const int imgs = (p.B + C::NI - 1) / C::NI;
     p.m_tiles = imgs * p.tiles_x * p.tiles_y;
     p.n_slices = p.Cout_pad / C::BN;
@@ -37,6 +39,8 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v2_kernel<C>), dim3(G), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }
+
+void conv_v2_set_stamps(unsigned long long* p) { g_stamps = p; }
 
 int conv_v2_subs(int tile_kind, int bn) {
     const int wm = 4 / (bn / 32);

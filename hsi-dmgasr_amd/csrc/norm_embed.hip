@@ -60,30 +60,47 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
                                                           int HW, int groups, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           float2* __restrict__ ab) {
-    extern __shared__ float sm[];          // [C] sum, [C] sumsq, [groups] mean, [groups] rstd
+    extern __shared__ float sm[];          // [C] sum, [C] sumsq, [groups] mean, [groups] rstd, [256*2] scratch
     const int C = C0 + C1;
     float* cs = sm;
     float* cq = sm + C;
     float* gm = sm + 2 * C;
     float* gr = gm + groups;
+    float* scr = gr + groups;
     const int b = blockIdx.x, t = threadIdx.x;
-    for (int c = t; c < C; c += 256) {
+    // The slab of a 128x128 map has 256 partial entries per channel: spread them over all 256 threads
+    // (thread = (channel, row); row r sums entries r, r+R, ...) and finish through LDS in a fixed order.
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int cw = min(256, C - cbase);            // channels handled in this pass
+        const int R = 256 / cw;                        // rows of threads per channel (>= 1)
+        const int cl = t % cw, r = t / cw;
         float a = 0.f, d = 0.f;
-        if (c < C0) {
-            for (int s = 0; s < nsplit0; ++s) {
-                const float2 v = part0[((size_t)b * nsplit0 + s) * C0 + c];
-                a += v.x;
-                d += v.y;
-            }
-        } else {
-            for (int s = 0; s < nsplit1; ++s) {
-                const float2 v = part1[((size_t)b * nsplit1 + s) * C1 + (c - C0)];
-                a += v.x;
-                d += v.y;
+        if (r < R) {
+            const int c = cbase + cl;
+            if (c < C0) {
+                for (int s = r; s < nsplit0; s += R) {
+                    const float2 v = part0[((size_t)b * nsplit0 + s) * C0 + c];
+                    a += v.x;
+                    d += v.y;
+                }
+            } else {
+                for (int s = r; s < nsplit1; s += R) {
+                    const float2 v = part1[((size_t)b * nsplit1 + s) * C1 + (c - C0)];
+                    a += v.x;
+                    d += v.y;
+                }
             }
         }
-        cs[c] = a;
-        cq[c] = d;
+        scr[2 * t] = a;
+        scr[2 * t + 1] = d;
+        __syncthreads();
+        if (t < cw) {
+            float sa = 0.f, sd = 0.f;
+            for (int rr = 0; rr < R; ++rr) { sa += scr[2 * (rr * cw + t)]; sd += scr[2 * (rr * cw + t) + 1]; }
+            cs[cbase + t] = sa;
+            cq[cbase + t] = sd;
+        }
+        __syncthreads();
     }
     __syncthreads();
     const int cpg = C / groups;
@@ -212,7 +229,7 @@ extern "C" int hsidm_gn_finalize(const float* part0, int nsplit0, int C0, const 
     const int C = C0 + C1;
     if (!part0 || !gamma || !beta || !gn_ab || groups <= 0 || C0 <= 0 || C1 < 0 || C % groups || C > 8192 || nsplit0 <= 0) return HSIDM_E_BADARG;
     if (C1 > 0 && (!part1 || nsplit1 <= 0)) return HSIDM_E_BADARG;
-    const size_t lds = (size_t)(2 * C + 2 * groups) * sizeof(float);
+    const size_t lds = (size_t)(2 * C + 2 * groups + 512) * sizeof(float);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float2*)part0, nsplit0, C0,
                        (const float2*)part1, nsplit1, C1, HW, groups, gamma, beta, eps, (float2*)gn_ab);
     return (int)hipGetLastError();

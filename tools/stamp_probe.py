@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of conv_v2 (diagnostic build with -DHSIDM_V2_STAMPS -> libhsidm_stamps.so).
+
+    HSIDM_LIB=.../libhsidm_stamps.so python tools/stamp_probe.py SHAPE_NAME
+Prints, per item index, the median cycles of: chunk loop, barrier waits, epilogue; over all blocks/waves.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hsi_dmgasr_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.environ.get("HSIDM_LIB", _lib.LIB_PATH)
+from hsi_dmgasr_amd import ops  # noqa: E402
+import tools.conv_bench as cb  # noqa: E402
+
+
+def main():
+    name = sys.argv[1]
+    shp = [s for s in cb.SHAPES if s[0] == name][0]
+    _, H, C0, C1, Co, ks, st, up, pj = shp
+    dev = torch.device("cuda:0")
+    B = 40
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
+    pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), "bf16")
+    x0 = torch.randn(B, H, H, C0, generator=g).to(dev, torch.bfloat16)
+    x1 = torch.randn(B, H, H, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
+    ab = torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev)
+    xf = ops.XF_AFFINE_SILU if not up else ops.XF_NONE
+    stamps = torch.zeros(512 * 4 * 8 * 16, dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    L.hsidm_debug_set_stamps.argtypes = [ctypes.c_void_p]
+    L.hsidm_debug_set_stamps.restype = None
+    for rep in range(3):
+        stamps.zero_()
+        L.hsidm_debug_set_stamps(stamps.data_ptr())
+        y = ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=xf, ups=bool(up), stats=True)
+        torch.cuda.synchronize()
+    L.hsidm_debug_set_stamps(None)
+    s = stamps.cpu().numpy().reshape(512, 4, 8, 16).astype(np.float64)
+    t0 = s[:, :, 0, 0].min()
+    print("shape", name, "kernel span (cycles of the 100 MHz memtime clock x? ) first->last stamp:",
+          (s[s > 0].max() - t0))
+    for it in range(8):
+        a = s[:, :, it, :]
+        ok = a[:, :, 0] > 0
+        if not ok.any():
+            break
+        start = a[:, :, 0][ok]
+        ep0 = a[:, :, 12][ok]
+        ep1 = a[:, :, 13][ok]
+        pre = a[:, :, 10][ok]
+        ch = [a[:, :, 1 + c][ok] for c in range(8) if (a[:, :, 1 + c][ok] > 0).all()]
+        line = "item %d: n=%4d  start@%8.0f  loop=%7.0f  (last pre-barrier->barrier %6.0f)  epilogue=%7.0f" % (
+            it, ok.sum(), np.median(start - t0), np.median(ep0 - start), np.median(ep0 - pre), np.median(ep1 - ep0))
+        if len(ch) > 1:
+            line += "  chunks=" + " ".join("%.0f" % np.median(ch[i] - (ch[i - 1] if i else start)) for i in range(len(ch)))
+        print(line)
+
+
+if __name__ == "__main__":
+    main()
