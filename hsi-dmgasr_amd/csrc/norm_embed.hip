@@ -53,70 +53,65 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const ActT* __restrict_
     }
 }
 
-// gn_finalize: grid (B).  part0 [B][nsplit0][C0] (+ part1 [B][nsplit1][C1] for a channel concat)
+// gn_finalize: grid (groups / GPB, B).  part0 [B][nsplit0][C0] (+ part1 [B][nsplit1][C1] for a channel concat)
 //              -> gn_ab [B][C0+C1] = (rstd*gamma, beta - mean*rstd*gamma)
+// A workgroup owns GPB consecutive groups (= CW consecutive channels) of one image.  The slab of a 128x128 map has
+// 256 partial entries per channel, so the entries are spread over all 256 threads (thread = (channel, row); row r sums
+// entries r, r+R, ...) and combined through LDS in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict__ part0, int nsplit0, int C0,
                                                           const float2* __restrict__ part1, int nsplit1, int C1,
-                                                          int HW, int groups, const float* __restrict__ gamma,
+                                                          int HW, int groups, int gpb, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           float2* __restrict__ ab) {
-    extern __shared__ float sm[];          // [C] sum, [C] sumsq, [groups] mean, [groups] rstd, [256*2] scratch
+    __shared__ float scr[512];
+    __shared__ float cs[256], cq[256], gm[256], gr[256];
     const int C = C0 + C1;
-    float* cs = sm;
-    float* cq = sm + C;
-    float* gm = sm + 2 * C;
-    float* gr = gm + groups;
-    float* scr = gr + groups;
-    const int b = blockIdx.x, t = threadIdx.x;
-    // The slab of a 128x128 map has 256 partial entries per channel: spread them over all 256 threads
-    // (thread = (channel, row); row r sums entries r, r+R, ...) and finish through LDS in a fixed order.
-    for (int cbase = 0; cbase < C; cbase += 256) {
-        const int cw = min(256, C - cbase);            // channels handled in this pass
-        const int R = 256 / cw;                        // rows of threads per channel (>= 1)
-        const int cl = t % cw, r = t / cw;
-        float a = 0.f, d = 0.f;
-        if (r < R) {
-            const int c = cbase + cl;
-            if (c < C0) {
-                for (int s = r; s < nsplit0; s += R) {
-                    const float2 v = part0[((size_t)b * nsplit0 + s) * C0 + c];
-                    a += v.x;
-                    d += v.y;
-                }
-            } else {
-                for (int s = r; s < nsplit1; s += R) {
-                    const float2 v = part1[((size_t)b * nsplit1 + s) * C1 + (c - C0)];
-                    a += v.x;
-                    d += v.y;
-                }
+    const int cpg = C / groups;
+    const int cw = gpb * cpg;                      // channels of this workgroup (<= 256)
+    const int c0 = blockIdx.x * cw;
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int R = 256 / cw;
+    const int cl = t % cw, r = t / cw;
+    float a = 0.f, d = 0.f;
+    if (r < R) {
+        const int c = c0 + cl;
+        if (c < C0) {
+            for (int s = r; s < nsplit0; s += R) {
+                const float2 v = part0[((size_t)b * nsplit0 + s) * C0 + c];
+                a += v.x;
+                d += v.y;
+            }
+        } else {
+            for (int s = r; s < nsplit1; s += R) {
+                const float2 v = part1[((size_t)b * nsplit1 + s) * C1 + (c - C0)];
+                a += v.x;
+                d += v.y;
             }
         }
-        scr[2 * t] = a;
-        scr[2 * t + 1] = d;
-        __syncthreads();
-        if (t < cw) {
-            float sa = 0.f, sd = 0.f;
-            for (int rr = 0; rr < R; ++rr) { sa += scr[2 * (rr * cw + t)]; sd += scr[2 * (rr * cw + t) + 1]; }
-            cs[cbase + t] = sa;
-            cq[cbase + t] = sd;
-        }
-        __syncthreads();
+    }
+    scr[2 * t] = a;
+    scr[2 * t + 1] = d;
+    __syncthreads();
+    if (t < cw) {
+        float sa = 0.f, sd = 0.f;
+        for (int rr = 0; rr < R; ++rr) { sa += scr[2 * (rr * cw + t)]; sd += scr[2 * (rr * cw + t) + 1]; }
+        cs[t] = sa;
+        cq[t] = sd;
     }
     __syncthreads();
-    const int cpg = C / groups;
-    for (int g = t; g < groups; g += 256) {
-        double a = 0.0, d = 0.0;
-        for (int k = 0; k < cpg; ++k) { a += cs[g * cpg + k]; d += cq[g * cpg + k]; }
+    if (t < gpb) {
+        double sa = 0.0, sd = 0.0;
+        for (int k = 0; k < cpg; ++k) { sa += cs[t * cpg + k]; sd += cq[t * cpg + k]; }
         const double n = (double)cpg * HW;
-        const double mean = a / n;
-        double var = d / n - mean * mean;
+        const double mean = sa / n;
+        double var = sd / n - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        gm[g] = (float)mean;
-        gr[g] = (float)(1.0 / sqrt(var + (double)eps));
+        gm[t] = (float)mean;
+        gr[t] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
-    for (int c = t; c < C; c += 256) {
-        const int g = c / cpg;
+    if (t < cw) {
+        const int c = c0 + t, g = t / cpg;
         const float sc = gr[g] * gamma[c];
         ab[(size_t)b * C + c] = make_float2(sc, beta[c] - gm[g] * sc);
     }
@@ -227,11 +222,16 @@ extern "C" int hsidm_gn_finalize(const float* part0, int nsplit0, int C0, const 
                                  int B, int HW, int groups, const float* gamma, const float* beta, float eps,
                                  float* gn_ab, void* stream) {
     const int C = C0 + C1;
-    if (!part0 || !gamma || !beta || !gn_ab || groups <= 0 || C0 <= 0 || C1 < 0 || C % groups || C > 8192 || nsplit0 <= 0) return HSIDM_E_BADARG;
+    if (!part0 || !gamma || !beta || !gn_ab || groups <= 0 || C0 <= 0 || C1 < 0 || C % groups || nsplit0 <= 0) return HSIDM_E_BADARG;
     if (C1 > 0 && (!part1 || nsplit1 <= 0)) return HSIDM_E_BADARG;
-    const size_t lds = (size_t)(2 * C + 2 * groups + 512) * sizeof(float);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float2*)part0, nsplit0, C0,
-                       (const float2*)part1, nsplit1, C1, HW, groups, gamma, beta, eps, (float2*)gn_ab);
+    const int cpg = C / groups;
+    if (cpg > 256) return HSIDM_E_UNSUPPORTED;
+    // groups per workgroup: as few as possible (more workgroups) while a workgroup's channels fit 256 threads
+    int gpb = 1;
+    while (groups % (gpb * 2) == 0 && groups / (gpb * 2) >= 8 && gpb * 2 * cpg <= 256) gpb *= 2;
+    if (groups / gpb > 8 && gpb * cpg < 8) { while (groups % (gpb * 2) == 0 && gpb * 2 * cpg <= 8) gpb *= 2; }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups / gpb, B), dim3(256), 0, (hipStream_t)stream, (const float2*)part0, nsplit0,
+                       C0, (const float2*)part1, nsplit1, C1, HW, groups, gpb, gamma, beta, eps, (float2*)gn_ab);
     return (int)hipGetLastError();
 }
 
