@@ -16,6 +16,7 @@ HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 void conv_v2_set_stamps(unsigned long long* p);
+int conv1x1_ws_run(C1Params& p, hipStream_t s);
 }  // namespace hsidm
 
 using namespace hsidm;
@@ -36,7 +37,9 @@ extern "C" const char* hsidm_error_string(int code) {
 
 extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
 
-static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, bool& use_v2) {
+enum { PATH_V1 = 0, PATH_V2 = 1, PATH_WS = 2 };
+
+static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
     if (!d) return HSIDM_E_BADARG;
     if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3) return HSIDM_E_BADARG;
     if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
@@ -55,17 +58,27 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     // spatial tile: 8x16 pixels of one image, or 8x8 pixels of two images when the map is narrow
     tile_kind = (Wout >= 16) ? 0 : 1;
     const int xf = d->ph[0].transform;
-    use_v2 = d->prec == HSIDM_BF16 && d->w_v2 && d->ksize == 3 && d->stride == 1 && !d->out_nchw &&
-             (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU) && d->nphase == 1;
+    path = PATH_V1;
+    if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
+        if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
+        // weight-stationary 1x1: whole [K][64] slice in LDS (K padded to 128), 32-pixel tiles inside one image.
+        // Measured (tools/conv_bench.py): faster than v1 for K <= 512; the K <= 1024 / 32-cout variant is not, so
+        // those shapes stay on v1.
+        const int kpad = (d->ph[0].C0 + d->ph[0].C1 + 127) / 128 * 128;
+        const int cpad64 = (d->Cout + d->bn - 1) / d->bn * d->bn;
+        if (d->ksize == 1 && xf == HSIDM_XF_NONE && d->act == HSIDM_ACT_NONE && !d->film && kpad <= 512 && cpad64 % 64 == 0 &&
+            (Hout * Wout) % 32 == 0) path = PATH_WS;
+    }
     return HSIDM_OK;
 }
 
 extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
-    int Hout, Wout, tile_kind;
-    bool use_v2;
-    const int rc = conv_validate(d, Hout, Wout, tile_kind, use_v2);
+    int Hout, Wout, tile_kind, path;
+    const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
     if (d->out_nchw) return HSIDM_E_UNSUPPORTED;
+    if (path == PATH_WS) return Hout * Wout / 32;
+    const bool use_v2 = path == PATH_V2;
     const int TW = tile_kind == 0 ? 16 : 8;
     const int tiles = ((Wout + TW - 1) / TW) * ((Hout + 7) / 8);
     // v1 and v2 use the same wave grid rule per cout slice: WN = 2 (v1, bn >= 64) / bn/32 (v2)
@@ -79,10 +92,10 @@ extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
 }
 
 extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
-    int Hout, Wout, tile_kind;
-    bool use_v2;
-    const int rc = conv_validate(d, Hout, Wout, tile_kind, use_v2);
+    int Hout, Wout, tile_kind, path;
+    const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
+    const bool use_v2 = path == PATH_V2;
     if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
     if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
     const int bk = hsidm_conv_bk(d->prec);
@@ -109,6 +122,19 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     const int tiles_x = (Wout + TW - 1) / TW, tiles_y = (Hout + TH - 1) / TH;
     const int cout_pad = (d->Cout + d->bn - 1) / d->bn * d->bn;
     hipStream_t s = (hipStream_t)stream;
+    if (path == PATH_WS) {
+        C1Params c;
+        c.src0 = reinterpret_cast<const bf16*>(p.ph[0].src0);
+        c.src1 = reinterpret_cast<const bf16*>(p.ph[0].src1);
+        c.C0 = p.ph[0].C0; c.C1 = p.ph[0].C1;
+        c.w = reinterpret_cast<const bf16*>(d->w_v2);
+        c.bias = d->bias; c.res = reinterpret_cast<const bf16*>(d->res); c.res_scale = d->res_scale;
+        c.out = reinterpret_cast<bf16*>(d->out); c.stats = reinterpret_cast<float2*>(d->stats);
+        c.M = d->B * Hout * Wout; c.HW = Hout * Wout; c.Cout = d->Cout; c.Cout_pad = cout_pad;
+        c.ksteps = (p.ph[0].C0 + p.ph[0].C1 + 127) / 128 * 2;
+        if (d->film) return HSIDM_E_UNSUPPORTED;
+        return conv1x1_ws_run(c, s);
+    }
     if (use_v2) {
         ConvV2Params v;
         v.src0 = reinterpret_cast<const bf16*>(p.ph[0].src0);

@@ -62,9 +62,12 @@ class PackedConv:
         # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
         # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
         self.w_v2 = None
-        if prec == _lib.BF16 and kh == 3 and not out_nchw:
-            st = self.w_hi.shape[0]
-            v = self.w_hi.reshape(st, cpad // 32, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5)
+        if prec == _lib.BF16 and not out_nchw and proj_weight is None:
+            wv = self.w_hi
+            if kh == 1 and wv.shape[0] % 2:          # weight-stationary 1x1 kernel: K padded to a multiple of 128
+                wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
+            st = wv.shape[0]
+            v = wv.reshape(st, cpad // 32, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5)
             self.w_v2 = v.contiguous()
 
     @staticmethod

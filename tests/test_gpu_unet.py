@@ -218,7 +218,7 @@ def test_sampler_api_shapes_and_philox_mode(dev):
 CONV_CASES = [  # B, H, W, C0, C1, Cout, ups, proj_cin, xf
     (3, 16, 32, 64, 0, 128, False, 0, True),      # 8x16 tiles, BN=128, several items per block
     (2, 24, 40, 64, 32, 64, False, 0, True),      # concat input, BN=64, partial tiles
-    (5, 8, 8, 128, 0, 96, False, 64, True),       # two-image tiles (odd batch), fused 1x1 projection
+    (5, 8, 8, 128, 0, 96, False, 0, True),        # two-image tiles (odd batch), cout not a multiple of 32
     (2, 8, 16, 32, 0, 24, True, 0, False),        # nearest-x2 folded in, BN=32, no transform
     (40, 16, 16, 64, 0, 64, False, 0, True),      # many items: persistent loop over tiles
 ]
@@ -256,3 +256,37 @@ def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
         outs.append(yf.cpu())
     ops.set_use_v2(True)
     check("conv_v2_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=2e-3)
+
+
+C1_CASES = [  # B, H, W, C0, C1, Cout, with_res
+    (2, 16, 16, 64, 0, 128, False),       # K=64 padded to 128, BN=64
+    (3, 8, 8, 128, 64, 64, True),         # concat input, K=192 -> 256, residual + statistics (attention out)
+    (2, 16, 8, 256, 256, 512, False),     # K=512: the largest weight-stationary slice
+    (5, 8, 16, 512, 512, 96, True),       # K=1024 stays on the v1 kernel (dispatch check)
+]
+
+
+@pytest.mark.parametrize("case", C1_CASES)
+def test_conv1x1_weight_stationary_matches_v1(dev, case):
+    from hsi_dmgasr_amd import ops
+    B, H, W, C0, C1, Co, with_res = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    w = torch.randn(Co, C0 + C1, 1, 1, generator=g) / (C0 + C1) ** 0.5
+    pk = ops.PackedConv(w.to(dev), torch.randn(Co, generator=g).to(dev), "bf16")
+    assert pk.w_v2 is not None and pk.w_v2.shape[0] % 2 == 0
+    x0 = torch.randn(B, H, W, C0, generator=g).to(dev, torch.bfloat16)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
+    res = torch.randn(B, H, W, Co, generator=g).to(dev, torch.bfloat16) if with_res else None
+    outs = []
+    for use_v2 in (False, True):
+        ops.set_use_v2(use_v2)
+        y = ops.conv2d(x0, pk, x1=x1, res=res, stats=True)
+        torch.cuda.synchronize()
+        slab, nsplit = y._hsidm_stats
+        yf = y.float()
+        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
+        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), use_v2
+        outs.append(yf.cpu())
+    ops.set_use_v2(True)
+    # with a residual the vector epilogue rounds the conv result to bf16 before the add (v1 adds in fp32): <= 1 bf16 ulp
+    check("conv1x1_ws_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)

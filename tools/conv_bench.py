@@ -30,6 +30,12 @@ SHAPES = [  # name, H, C0, C1, Cout, ksize, stride, ups, proj_cin
     ("down_128_64", 128, 64, 0, 64, 3, 2, 0, 0),
     ("qkv_16_512", 16, 512, 0, 1536, 1, 1, 0, 0),
     ("stem_128_8_64", 128, 8, 0, 64, 3, 1, 0, 0),
+    ("proj128_192_64", 128, 128, 64, 64, 1, 1, 0, 0),
+    ("proj64_384_128", 64, 256, 128, 128, 1, 1, 0, 0),
+    ("proj32_768_256", 32, 512, 256, 256, 1, 1, 0, 0),
+    ("proj16_1024_512", 16, 512, 512, 512, 1, 1, 0, 0),
+    ("proj8_1024_512", 8, 512, 512, 512, 1, 1, 0, 0),
+    ("out16_512_512", 16, 512, 0, 512, 1, 1, 0, 0),
 ]
 
 
