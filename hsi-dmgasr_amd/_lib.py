@@ -37,6 +37,7 @@ SIGNATURES = {
     "hsidm_conv_bk": [_i32],
     "hsidm_conv2d": [C.POINTER(ConvDesc), _vp],
     "hsidm_conv_stats_nsplit": [C.POINTER(ConvDesc)],
+    "hsidm_conv_kernel_id": [C.POINTER(ConvDesc)],
     "hsidm_gn_partial": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "hsidm_gn_finalize": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "hsidm_noise_film": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],

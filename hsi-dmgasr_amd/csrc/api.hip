@@ -72,6 +72,13 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     return HSIDM_OK;
 }
 
+extern "C" int hsidm_conv_kernel_id(const hsidm_conv_desc* d) {
+    int Hout, Wout, tile_kind, path;
+    const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
+    if (rc != HSIDM_OK) return rc;
+    return path | (tile_kind << 4) | (d->bn << 8);
+}
+
 extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
     int Hout, Wout, tile_kind, path;
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);

@@ -135,7 +135,13 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
         e1.record()
         k_total = pw.cin * pw.ksize * pw.ksize + pw.proj_cin
-        _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize,
+        kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
+        label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "conv1x1_ws")[kid & 15], kid >> 8,
+                                            "8x8x2" if (kid >> 4) & 1 else "8x16", pw.ksize, stride,
+                                            " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else ""),
+                                            " nchw" if pw.out_nchw else "")
+        _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize, kernel=label,
+                                bytes=(B * H * W * (C0 + C1) + B * Ho * Wo * pw.cout) * x0.element_size() + pw.w_hi.numel() * 2,
                                 stride=stride, ups=bool(ups), cin=pw.cin, cout=pw.cout, hw=(Ho, Wo),
                                 out_nchw=pw.out_nchw, tile=0 if Wo >= 16 else 1))
     return out

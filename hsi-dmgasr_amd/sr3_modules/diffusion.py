@@ -16,6 +16,7 @@ and public methods (``set_loss``, ``set_new_noise_schedule``, ``p_sample_loop``,
 driver; it is not part of the reference interface.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -128,7 +129,7 @@ class GaussianDiffusion(nn.Module):
         self.conditional = conditional
         self.noise = "torch"       # "torch" | "philox": where x_T and the per-step noise come from
         self.seed = 0              # Philox key
-        self.use_graph = True
+        self.use_graph = os.environ.get("HSIDM_NO_GRAPH", "") == ""   # eager launches for per-dispatch counters
         self._graph_cache = {}
 
     # ---------------------------------------------------------------------------------- configuration
