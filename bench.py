@@ -89,8 +89,9 @@ def conv_roofline(run, reps=3):
                                       tflops=all_fl / (all_ms * 1e-3) / 1e12))
 
 
-def cpu_baseline(batch=1, steps=24, warm=1):
-    """The oracle on the host CPU: full-size UNet p_sample steps (fp32), a bounded sample of the same workload."""
+def cpu_baseline(batch=1, steps=160, warm=2):
+    """The oracle on the host CPU: full-size UNet p_sample steps (fp32), a bounded sample (about 10-25 s) of the same
+    workload: 160 of the 1000 reverse steps at batch 1 (every step costs the same)."""
     from oracle import diffusion as odiff, sr3_unet
     from hsi_dmgasr_amd.init import init_weights_orthogonal
     from hsi_dmgasr_amd.sr3_modules import unet
