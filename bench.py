@@ -144,7 +144,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--patches", type=int, default=8, help="CAVE patches per GPU (x5 spectral groups = batch)")
+    ap.add_argument("--patches", type=int, default=24,
+                    help="CAVE patches per GPU (x5 spectral groups = batch); 24 fills the 512 workgroup slots of every UNet level "
+                         "(sweep in DESIGN.md)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -161,9 +163,11 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("HSIDM_FORCE_DIST")        # FORCE: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from hsi_dmgasr_amd import parallel
     log('building model')
@@ -180,19 +184,19 @@ def main():
             run.step()
         torch.cuda.synchronize()
         log('warmup done')
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run.step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         el = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dt = float(el.item())
         assert torch.isfinite(run.x).all(), "sampler state diverged"
@@ -225,7 +229,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

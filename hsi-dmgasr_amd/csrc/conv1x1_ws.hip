@@ -27,8 +27,17 @@ __global__ __launch_bounds__(1024) void conv1x1_ws_kernel(const C1Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int slice = blockIdx.x % p.n_slices;
-    const int brank = blockIdx.x / p.n_slices;              // rank of this workgroup within its slice
+    // Workgroups b and b + 8 sit on the same XCD (round-robin dispatch; speed only, never correctness).  The cout slices
+    // of one pixel range are given to such workgroups, so the second slice re-reads its activation rows from that
+    // XCD's L2 instead of HBM (the weights are in LDS and do not compete for it).
+    int slice, brank;
+    if (p.blocks_per_slice % 8 == 0) {
+        slice = (blockIdx.x >> 3) % p.n_slices;
+        brank = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * p.n_slices));
+    } else {
+        slice = blockIdx.x % p.n_slices;
+        brank = blockIdx.x / p.n_slices;
+    }
     const int n0 = slice * BN;
     const int U = p.ksteps * 4;                             // k-slices per tile
 

@@ -24,7 +24,7 @@ def shard_counts(n_items, world):
 def broadcast_module_(module, src=0, bucket_bytes=256 << 20):
     """One-time weight broadcast: parameters and buffers are flattened into large buckets (xGMI links are
     per-peer, so few large messages beat 374 small ones) and broadcast from `src`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return module
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.is_floating_point()]
     bucket, size = [], 0
