@@ -47,6 +47,9 @@ SIGNATURES = {
     "hsidm_p_sample_update": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _u64, _i64, _vp, _i32, _vp],
     "hsidm_step_advance": [_vp, _i32, _vp],
     "hsidm_philox_normal": [_vp, _i64, _u64, _u32, _vp],
+    "hsidm_q_sample": [_vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "hsidm_loss_workspace_bytes": [],
+    "hsidm_loss_sum": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "hsidm_ca_vector": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "hsidm_ca_apply": [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp],
     "hsidm_overlap_average": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

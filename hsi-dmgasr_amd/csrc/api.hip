@@ -47,6 +47,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     if (d->stride != 1 && d->stride != 2) return HSIDM_E_BADARG;
     if (d->bn != 32 && d->bn != 64 && d->bn != 128) return HSIDM_E_BADARG;
     if (d->B <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cout <= 0) return HSIDM_E_BADARG;
+    if (d->ups < 0 || d->ups > HSIDM_UPS_FOLDED) return HSIDM_E_BADARG;
     // geometry the reference uses: 3x3 pad 1 (stride 1|2, optional nearest x2), 1x1 pad 0 stride 1
     if (d->ksize == 1 && (d->stride != 1 || d->ups)) return HSIDM_E_UNSUPPORTED;
     if (d->ups && d->stride != 1) return HSIDM_E_UNSUPPORTED;
@@ -56,9 +57,15 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     Wout = d->ups ? 2 * d->Win : (d->stride == 2 ? (d->Win + 1) / 2 : d->Win);
     if (Hout != d->Hout || Wout != d->Wout) return HSIDM_E_BADARG;
     // spatial tile: 8x16 pixels of one image, or 8x8 pixels of two images when the map is narrow
-    tile_kind = (Wout >= 16) ? 0 : 1;
+    // (parity-folded upsample: tiles live on the INPUT grid)
+    const bool up4 = d->ups == HSIDM_UPS_FOLDED;
+    tile_kind = ((up4 ? d->Win : Wout) >= 16) ? 0 : 1;
     const int xf = d->ph[0].transform;
     path = PATH_V1;
+    if (up4) {
+        if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || xf != HSIDM_XF_NONE ||
+            d->bn != 128) return HSIDM_E_UNSUPPORTED;
+    }
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
         // weight-stationary 1x1: whole [K][64] slice in LDS (K padded to 128), 32-pixel tiles inside one image.
@@ -87,6 +94,8 @@ extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
     if (path == PATH_WS) return Hout * Wout / 32;
     const bool use_v2 = path == PATH_V2;
     const int TW = tile_kind == 0 ? 16 : 8;
+    if (d->ups == HSIDM_UPS_FOLDED)      // one entry per (input tile, parity, wave row)
+        return ((d->Win + TW - 1) / TW) * ((d->Hin + 7) / 8) * 4 * conv_v2_subs(tile_kind, d->bn);
     const int tiles = ((Wout + TW - 1) / TW) * ((Hout + 7) / 8);
     // v1 and v2 use the same wave grid rule per cout slice: WN = 2 (v1, bn >= 64) / bn/32 (v2)
     int subs;
@@ -126,7 +135,8 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         }
     }
     const int TH = 8, TW = tile_kind == 0 ? 16 : 8;
-    const int tiles_x = (Wout + TW - 1) / TW, tiles_y = (Hout + TH - 1) / TH;
+    const bool up4 = d->ups == HSIDM_UPS_FOLDED;
+    const int tiles_x = ((up4 ? d->Win : Wout) + TW - 1) / TW, tiles_y = ((up4 ? d->Hin : Hout) + TH - 1) / TH;
     const int cout_pad = (d->Cout + d->bn - 1) / d->bn * d->bn;
     hipStream_t s = (hipStream_t)stream;
     if (path == PATH_WS) {
@@ -154,8 +164,8 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.out = reinterpret_cast<bf16*>(d->out); v.stats = reinterpret_cast<float2*>(d->stats);
         v.B = d->B; v.Hin = d->Hin; v.Win = d->Win; v.Hout = Hout; v.Wout = Wout; v.Cout = d->Cout; v.Cout_pad = cout_pad;
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
-        v.steps_per_item = steps;
-        return conv_v2_run(tile_kind, d->bn, d->ph[0].transform, v, s);
+        v.steps_per_item = up4 ? p.ph[0].nchunks * 4 : steps;
+        return conv_v2_run(tile_kind, d->bn, up4 ? -1 : d->ph[0].transform, v, s);
     }
     p.w_hi = reinterpret_cast<const bf16*>(d->w_hi);
     p.w_lo = reinterpret_cast<const bf16*>(d->w_lo);

@@ -44,6 +44,7 @@ struct ConvV2Params {
     int ups, act;
     int tiles_x, tiles_y;
     int m_tiles, n_slices, total_items, steps_per_item;
+    int up_m;               // UP4 kernels: XCDs per cout slice when the L2-friendly (tile, parity) order applies, else 0
     unsigned long long* stamps;   // diagnostic build (HSIDM_V2_STAMPS): [block][wave][item<8][slot<16] s_memtime
     int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };
@@ -63,9 +64,16 @@ struct C1Params {
     int n_slices, m_tiles, blocks_per_slice;
 };
 
-template <int BN_, int TH_, int TW_, int NI_, int XF_>
+// UP4: nearest-x2 upsample folded into the weights.  Output pixel (2y+py, 2x+px) of conv3x3(nearest_x2(in)) only sees
+// the 2x2 input neighbourhood {y-1+py, y+py} x {x-1+px, x+px}; the host pre-sums the 3x3 taps that fall on the same input
+// pixel into four 2x2 kernels (one per output parity).  A work item is (input tile, parity, cout slice): K = 4*Cin per
+// output pixel instead of 9*Cin, and the halo tile is the plain input tile (each input pixel staged once per parity
+// instead of ~3.3 times per output tile).
+template <int BN_, int TH_, int TW_, int NI_, int XF_, int UP4_ = 0>
 struct V2Cfg {
     static constexpr int BN = BN_, TH = TH_, TW = TW_, NI = NI_, XF = XF_;
+    static constexpr bool UP4 = UP4_ != 0;
+    static constexpr int NT = UP4 ? 4 : 9;                      // taps per channel chunk
     static constexpr int BM = 128, BK = 64;
     static_assert(TH * TW * NI == BM, "tile");
     static constexpr int WN = BN / 32, WM = 4 / WN, MR = BM / WM / 32;
@@ -73,7 +81,9 @@ struct V2Cfg {
     static constexpr int PSTR = BK + 8, VPP = BK / 8;
     static constexpr int HVEC = NI * HPIX * VPP;
     static constexpr int MAXHV = (HVEC + 255) / 256;
+    static constexpr int NH = UP4 ? MAXHV : 4;                  // raw staging registers (vectors in flight)
     static_assert(MAXHV <= 7, "one staged vector per tap 2..8");
+    static_assert(!UP4 || XF_ == 0, "the upsample convs have no GroupNorm prologue");
     static constexpr int HALO_ELEMS = NI * HPIX * PSTR;
     static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2;
     // statistics sub-entries per spatial tile and image (see epilogue)
@@ -125,7 +135,8 @@ template <typename C>
 __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
     constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK;
-    constexpr int MAXHV = C::MAXHV;
+    constexpr int MAXHV = C::MAXHV, NT = C::NT, NH = C::NH;
+    constexpr bool UP4 = C::UP4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* halo = reinterpret_cast<bf16*>(smem_raw);          // [2][HALO_ELEMS]
@@ -149,7 +160,18 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     const bf16* wlane = p.w + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
     bf16x8 ring[3][4];
+    // item -> (pixel tile, output parity).  UP4 with up_m > 0: the four parities of one input tile are consecutive work
+    // of ONE XCD (blocks b, b+8, b+16, b+24), so its L2 fetches the tile once.
+    auto item_tile = [&](int it, int& par) __attribute__((always_inline)) -> int {
+        const int mt = it / p.n_slices;
+        if (!UP4) { par = 0; return mt; }
+        if (p.up_m > 0) { par = (mt / p.up_m) & 3; return (mt / (4 * p.up_m)) * p.up_m + mt % p.up_m; }
+        par = mt & 3;
+        return mt >> 2;
+    };
     int wnext = 0;                                              // step (within an item) of the next weight fetch
+    int w_item = item, w_base = 0;                              // UP4: item the ring fetches for, first step of its parity
+    if (UP4) { int par; item_tile(item, par); w_base = par * p.steps_per_item; }
     auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
         const bf16* src = wlane + (size_t)wnext * wstep_stride;
         if (!(HSIDM_ABL(8))) {
@@ -157,6 +179,21 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
         }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
+    };
+    // UP4: 16 fragments per chunk do not keep a 3-step ring in phase (4 taps), so the ring holds single fragments:
+    // 8 slots, fetched six sub-steps (24 MFMAs) ahead
+    bf16x8 fring[UP4 ? 8 : 1];
+    auto f_issue = [&](bf16x8& dst, int kk) __attribute__((always_inline)) {
+        if (!(HSIDM_ABL(8))) dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(w_base + wnext) * wstep_stride + kk * 64 * 8);
+        if (kk == 3) {
+            if (wnext + 1 == p.steps_per_item) {
+                wnext = 0;
+                w_item += G;
+                int par;
+                item_tile(w_item < p.total_items ? w_item : (int)blockIdx.x, par);
+                w_base = par * p.steps_per_item;
+            } else wnext += 1;
+        }
     };
 
     // ---- halo staging state ---------------------------------------------------------------------------------
@@ -173,8 +210,9 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         return (i < MAXHV - 1 || last_live) ? ((img << 16) | (hy << 8) | hx) : -1;
     };
     int st_b0 = 0;
-    auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {
-        const int mt = it / p.n_slices;
+    auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {   // tile origin on the staged grid
+        int par_;
+        const int mt = item_tile(it, par_);
         const int tg = mt / tiles_per_img;
         const int tr = mt - tg * tiles_per_img;
         b0 = tg * NI;
@@ -185,8 +223,9 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         int b0, oy0, ox0;
         tile_coords(it, b0, oy0, ox0);
         st_b0 = b0;
-        const int hlim = p.ups ? 2 * p.Hin : p.Hin, wlim = p.ups ? 2 * p.Win : p.Win;
-        const int sh = p.ups ? 1 : 0;
+        const bool up = !UP4 && p.ups;
+        const int hlim = up ? 2 * p.Hin : p.Hin, wlim = up ? 2 * p.Win : p.Win;
+        const int sh = up ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
             const int pos = hv_pos(i);
@@ -196,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             hv_pix[i] = ok ? (b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh) : -1;
         }
     };
-    u32x4 hreg[4];                 // staged raw vectors: vector i lives in slot i % 4 from tap i (issue) to tap min(i+3, 8) (commit)
+    u32x4 hreg[NH];                // staged raw vectors: vector i lives in slot i % NH from its issue tap to its commit tap
     unsigned abh[8];               // (scale, shift) of this thread's 8 channels, packed fp16x2: 11-bit significands, the
                                    // transformed value is rounded to bf16 (8 bits) anyway; halves the registers held across taps
     bool st_cok = true;
@@ -225,15 +264,15 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     auto halo_issue_one = [&](int i) __attribute__((always_inline)) {
         if (HSIDM_ABL(4)) return;
         const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
-        hreg[i & 3] = *reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
+        hreg[i % NH] = *reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
     };
     auto halo_commit_one = [&](int i, int buf) __attribute__((always_inline)) {
         if (i == MAXHV - 1 && !last_live) return;
         float v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[2 * k] = __uint_as_float(hreg[i & 3][k] << 16);
-            v[2 * k + 1] = __uint_as_float(hreg[i & 3][k] & 0xffff0000u);
+            v[2 * k] = __uint_as_float(hreg[i % NH][k] << 16);
+            v[2 * k + 1] = __uint_as_float(hreg[i % NH][k] & 0xffff0000u);
         }
         const bool live = st_cok && hv_pix[i] >= 0;             // zero padding stays zero (pad AFTER activation)
         if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
@@ -283,8 +322,13 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     };
 
     // prologue: first two weight steps, first halo tile (synchronously)
-    b_issue(ring[0]);
-    b_issue(ring[1]);
+    if (!UP4) {
+        b_issue(ring[0]);
+        b_issue(ring[1]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) f_issue(fring[f], f % 4);
+    }
     describe(item);
     halo_begin(0);
 #pragma unroll
@@ -305,7 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     float film_nx[NI];
     auto film_fetch = [&](int it_item) __attribute__((always_inline)) {
         const int itc = it_item < p.total_items ? it_item : blockIdx.x;       // past the end: any valid item
-        const int fb0 = ((itc / p.n_slices) / tiles_per_img) * NI;
+        int par_;
+        const int fb0 = (item_tile(itc, par_) / tiles_per_img) * NI;
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
@@ -324,41 +369,58 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             for (int j = 0; j < 16; ++j) acc[mr][j] = start;
         }
         film_fetch(item + G);
+        int par = 0;
+        const int it_tile = item_tile(item, par);
+        const int py = par >> 1, px = par & 1;
+        const int par_off = UP4 ? (py * HCOLS + px) * PSTR : 0;       // this parity's 2x2 window inside the 3x3 halo
         for (int chunk = 0; chunk < nch; ++chunk) {
-            const bf16* hb = halo + cur * C::HALO_ELEMS;
-            // A fragments: 3-deep register ring over the 36 (tap, k-slice) sub-steps of the chunk, fetched two
+            const bf16* hb = halo + cur * C::HALO_ELEMS + par_off;
+            // A fragments: 3-deep register ring over the 4*NT (tap, k-slice) sub-steps of the chunk, fetched two
             // sub-steps ahead (measured: with one sub-step of lookahead every k-slice waited ~300 cycles on LDS)
             bf16x8 a[3][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
-                const int off = ((tp / 3) * HCOLS + (tp % 3)) * PSTR + kq * 16;
+                const int off = (UP4 ? ((tp >> 1) * HCOLS + (tp & 1)) : ((tp / 3) * HCOLS + (tp % 3))) * PSTR + kq * 16;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + off);
             };
             a_fetch(0);
             a_fetch(1);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                b_issue(ring[(tap + 2) % 3]);                  // weights two K steps ahead
+            for (int tap = 0; tap < NT; ++tap) {
+                if (!UP4) b_issue(ring[(tap + 2) % 3]);        // weights two K steps ahead
                 if (st_valid) {                                // staging of the next chunk, one vector per tap
                     if (tap == 0) {
                         if (st_chunk == 0) describe(st_item);
                         halo_begin(st_chunk);
                     }
-                    if (tap < MAXHV) halo_issue_one(tap);
+                    if (!UP4) {
+                        if (tap < MAXHV) halo_issue_one(tap);
+                    } else if (tap < 2) {                      // 4 taps per chunk: vectors 0-3 at tap 0, the rest at tap 1
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (tap * 4 + i < MAXHV) halo_issue_one(tap * 4 + i);
+                    }
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = tap * 4 + kk;
-                    if (u + 2 < 36) a_fetch(u + 2);
+                    if (u + 2 < 4 * NT) a_fetch(u + 2);
+                    if (UP4) f_issue(fring[(u + 6) % 8], (u + 6) % 4);   // weights six fragments ahead
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], UP4 ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);         // keep the two-sub-step LDS lookahead the source expresses
                 }
                 if (st_valid && !(HSIDM_ABL(16))) {
-                    if (tap >= 3 && tap - 3 < MAXHV) halo_commit_one(tap - 3, cur ^ 1);
-                    if (tap == 8 && MAXHV == 7) halo_commit_one(6, cur ^ 1);
+                    if (!UP4) {
+                        if (tap >= 3 && tap - 3 < MAXHV) halo_commit_one(tap - 3, cur ^ 1);
+                        if (tap == 8 && MAXHV == 7) halo_commit_one(6, cur ^ 1);
+                    } else if (tap >= 2) {                     // committed two taps after their issue
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if ((tap - 2) * 4 + i < MAXHV) halo_commit_one((tap - 2) * 4 + i, cur ^ 1);
+                    }
                 }
             }
             HSIDM_STAMP(it, 10);                               // (last chunk's) MFMAs + commits issued
@@ -372,11 +434,14 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         HSIDM_STAMP(it, 12);
         int b0, oy0, ox0;
         tile_coords(item, b0, oy0, ox0);
-        const int trem = (item / p.n_slices) % tiles_per_img;
+        const int trem = UP4 ? (it_tile % tiles_per_img) * 4 + par : it_tile % tiles_per_img;   // statistics slot in the image
+        constexpr int US = UP4 ? 2 : 1;                                       // output pixel = US * tile pixel + parity
+        const int oyb = US * oy0 + py, oxb = US * ox0 + px;                  // (py = px = 0 unless UP4)
+        const int lim_h = UP4 ? p.Hin : p.Hout, lim_w = UP4 ? p.Win : p.Wout;
         float s1[NI], s2[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) s1[q] = s2[q] = 0.f;
-        const bool full = oy0 + TH <= p.Hout && ox0 + TW <= p.Wout && b0 + NI <= p.B && n0 + BN <= p.Cout;
+        const bool full = oy0 + TH <= lim_h && ox0 + TW <= lim_w && b0 + NI <= p.B && n0 + BN <= p.Cout;
         if (full) {
             // Whole tile inside the image.  2-byte stores straight from the accumulator layout cost ~200 cycles each
             // (in-kernel stamps: the epilogue took as long as 9 K steps), so the wave transposes its 64-pixel x 32-cout
@@ -391,13 +456,13 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));                                 // keep these lane constants out of the main loop's registers
             const int pl0 = lane_e >> 2, cq = lane_e & 3;
-            const unsigned lane_el = (unsigned)(((pl0 >> LTW) * p.Wout + (pl0 & (TW - 1))) * p.Cout + cq * 8);
+            const unsigned lane_el = (unsigned)((US * (pl0 >> LTW) * p.Wout + US * (pl0 & (TW - 1))) * p.Cout + cq * 8);
             auto vec_base = [&](int g, int v4) __attribute__((always_inline)) -> size_t {
                 const int pbase = wm * (C::BM / WM) + g * 32;
                 const int img = pbase / (TH * TW);
                 const int qimg = pbase - img * (TH * TW);
                 const int ty = (qimg >> LTW) + v4 * (16 >> LTW);
-                return (((size_t)(b0 + img) * p.Hout + oy0 + ty) * p.Wout + ox0) * p.Cout + n0 + wn * 32;
+                return (((size_t)(b0 + img) * p.Hout + oyb + US * ty) * p.Wout + oxb) * p.Cout + n0 + wn * 32;
             };
             auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
                 constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
@@ -467,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                         else if (WM == 1) sub = 0;
                         else sub = wm % (WM / 2 > 0 ? WM / 2 : 1);
                         if (lane < 4) {
-                            float2* dst = p.stats + ((size_t)b * (tiles_per_img * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n0 + wn * 32 + lane * 8;
+                            float2* dst = p.stats + ((size_t)b * (tiles_per_img * (US * US) * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n0 + wn * 32 + lane * 8;
 #pragma unroll
                             for (int k = 0; k < 8; ++k) dst[k] = make_float2(vs1[k], vs2[k]);
                         }
@@ -488,9 +553,9 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
                 const int q = pbase + row - img * (TH * TW);
                 const int ty = q / TW, tx = q - ty * TW;
-                const int oy = oy0 + ty, ox = ox0 + tx;
+                const int oy = oyb + US * ty, ox = oxb + US * tx;
                 float v = acc[mr][j];
-                if (!(nok && b < p.B && oy < p.Hout && ox < p.Wout)) continue;
+                if (!(nok && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
                 if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;
                 if (p.res) v = p.res_scale * v + (float)p.res[o];
@@ -514,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 else { img = (wm * (C::BM / WM)) / (TH * TW); sub = wm % (WM / 2 > 0 ? WM / 2 : 1); if (q != img) continue; }
                 const int b = b0 + img;
                 if (lh == 0 && nok && b < p.B)
-                    p.stats[((size_t)b * (tiles_per_img * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n] = make_float2(a, d);
+                    p.stats[((size_t)b * (tiles_per_img * (US * US) * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n] = make_float2(a, d);
             }
         }
         HSIDM_STAMP(it, 13);

@@ -29,8 +29,11 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     p.abl = abl;
     p.stamps = g_stamps;
     const int imgs = (p.B + C::NI - 1) / C::NI;
-    p.m_tiles = imgs * p.tiles_x * p.tiles_y;
     p.n_slices = p.Cout_pad / C::BN;
+    const int tiles = imgs * p.tiles_x * p.tiles_y;
+    p.m_tiles = C::UP4 ? 4 * tiles : tiles;
+    p.up_m = 0;
+    if (C::UP4 && 8 % p.n_slices == 0 && tiles % (8 / p.n_slices) == 0) p.up_m = 8 / p.n_slices;
     p.total_items = p.m_tiles * p.n_slices;
     int lcm = 8;
     while (lcm % p.n_slices) lcm += 8;
@@ -50,6 +53,10 @@ int conv_v2_subs(int tile_kind, int bn) {
 #define V2(BN, TH, TW, NI, XF) run_v2<V2Cfg<BN, TH, TW, NI, XF>>(p, s)
 
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s) {
+    if (xf == -1) {          // parity-folded nearest-x2 (weights: 4 parities x [chunk][2x2 taps])
+        if (bn != 128) return -2;
+        return tile_kind == 0 ? run_v2<V2Cfg<128, 8, 16, 1, XF_NONE, 1>>(p, s) : run_v2<V2Cfg<128, 8, 8, 2, XF_NONE, 1>>(p, s);
+    }
     if (xf != XF_NONE && xf != XF_AFFINE_SILU) return -2;
     const bool x = xf == XF_AFFINE_SILU;
     if (tile_kind == 0) {

@@ -94,6 +94,45 @@ __global__ void step_advance_kernel(int32_t* t_ptr, int32_t wrap_T) {
     *t_ptr = t;
 }
 
+
+// ---- forward process and training objective (diffusion.py:213-250) -----------------------------------
+// x_noisy = gamma_b * x0 + sqrt(1 - gamma_b^2) * noise, gamma per sample
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const float* __restrict__ gamma, float* __restrict__ out,
+                                                       int64_t per_sample, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float g = gamma[i / per_sample];
+        out[i] = g * x0[i] + sqrtf(1.0f - g * g) * noise[i];
+    }
+}
+
+constexpr int kLossBlocks = 256;
+// stage 1: block b sums its fixed strided subset (fp32 per thread, fp64 across the block) -> partial[b]
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                           int kind, double* __restrict__ partial) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float d = a[i] - b[i];
+        acc += kind == 0 ? fabsf(d) : d * d;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = (double)acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// stage 2: fixed-order sum of the partials -> out[0] (fp32, like the reference's scalar loss)
+__global__ __launch_bounds__(64) void loss_final_kernel(const double* __restrict__ partial, int nb, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += partial[i];
+        out[0] = (float)s;
+    }
+}
+
 // ---- NCHW fp32 planes -> NHWC (storage type), with channel concat / slicing / zero padding -----------
 template <typename ActT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ s0, const int64_t* __restrict__ off0, int C0,
@@ -209,6 +248,25 @@ extern "C" int hsidm_p_sample_update(float* x, const float* eps, const float* co
 extern "C" int hsidm_step_advance(int32_t* t_ptr, int32_t wrap_T, void* stream) {
     if (!t_ptr) return HSIDM_E_BADARG;
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_ptr, wrap_T);
+    return (int)hipGetLastError();
+}
+
+
+extern "C" int hsidm_q_sample(const float* x0, const float* noise, const float* gamma, float* out, int B,
+                              int64_t per_sample, void* stream) {
+    if (!x0 || !noise || !gamma || !out || B <= 0 || per_sample <= 0) return HSIDM_E_BADARG;
+    int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x0, noise, gamma, out, per_sample, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hsidm_loss_workspace_bytes(void) { return kLossBlocks * (int)sizeof(double); }
+
+extern "C" int hsidm_loss_sum(const float* a, const float* b, int64_t n, int kind, void* workspace, float* out, void* stream) {
+    if (!a || !b || !workspace || !out || n <= 0 || (kind != HSIDM_LOSS_L1 && kind != HSIDM_LOSS_L2)) return HSIDM_E_BADARG;
+    int nb = grid_for(n, 256, kLossBlocks);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, n, kind, (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nb, out);
     return (int)hipGetLastError();
 }
 

@@ -31,7 +31,7 @@ class PackedConv:
     the optional fused 1x1 projection (ResnetBlock.res_conv, reference unet.py:102-103).
     """
 
-    def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False):
+    def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False, fold_ups=False):
         prec = _lib.prec_id(precision)
         bk = 64 if prec == _lib.BF16 else 32
         dev = weight.device
@@ -66,9 +66,26 @@ class PackedConv:
             wv = self.w_hi
             if kh == 1 and wv.shape[0] % 2:          # weight-stationary 1x1 kernel: K padded to a multiple of 128
                 wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
-            st = wv.shape[0]
-            v = wv.reshape(st, cpad // 32, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5)
-            self.w_v2 = v.contiguous()
+            self.w_v2 = self._lanes(wv, cpad)
+        # nearest-x2 + conv3x3 as four 2x2 convs on the input grid (include/hsidm.h, HSIDM_UPS_FOLDED): taps that read
+        # the same input pixel are summed in fp32, then rounded to bf16 once
+        self.w_up4 = None
+        if fold_ups and self.w_v2 is not None and kh == 3 and self.bn == 128:
+            w = weight.detach().float()
+            rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # parity -> 3x3 taps behind each of the two 2x2 taps
+            pars = []
+            for py in (0, 1):
+                for px in (0, 1):
+                    f = torch.stack([torch.stack([sum(w[:, :, dy, dx] for dy in rows[py][ty] for dx in rows[px][tx])
+                                                  for tx in (0, 1)], dim=-1) for ty in (0, 1)], dim=-2)
+                    pars.append(self._steps(f, cpad, bk))
+            self.w_up4 = self._lanes(torch.cat(pars, dim=0).to(torch.bfloat16).contiguous(), cpad)
+
+    @staticmethod
+    def _lanes(w_steps, cpad):
+        """[step][Cout_pad][64] -> [step][Cout_pad/32][kk 4][lane = (k-half, cout r)][8]: one wave-load per MFMA B fragment."""
+        st = w_steps.shape[0]
+        return w_steps.reshape(st, cpad // 32, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
 
     @staticmethod
     def _steps(w, cpad, bk):
@@ -113,12 +130,15 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         d.nphase = 2
     d.w_hi, d.w_lo, d.bias = _lib.ptr(pw.w_hi), _lib.ptr(pw.w_lo), _lib.ptr(pw.bias)
     d.w_v2 = _lib.ptr(pw.w_v2) if _use_v2 else None
+    folded = bool(ups) and _use_v2 and _fold_ups and pw.w_up4 is not None
+    if folded:
+        d.w_v2 = _lib.ptr(pw.w_up4)
     if film is not None:          # a column slice of the [B, F] FiLM table
         assert film.stride(1) == 1 and film.shape == (B, pw.cout)
         d.film, d.film_stride = film.data_ptr(), film.stride(0)
     d.res, d.res_scale, d.out, d.stats = _lib.ptr(res), float(res_scale), _lib.ptr(out), None
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
-    d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, int(bool(ups)), act
+    d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, (UPS_FOLDED if folded else int(bool(ups))), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
     if stats and not pw.out_nchw:
         nsplit = _lib.lib().hsidm_conv_stats_nsplit(C.byref(d))
@@ -134,11 +154,12 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         e0.record()
         _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
         e1.record()
-        k_total = pw.cin * pw.ksize * pw.ksize + pw.proj_cin
+        k_total = pw.cin * (4 if folded else pw.ksize * pw.ksize) + pw.proj_cin      # multiplications actually executed
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
         label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "conv1x1_ws")[kid & 15], kid >> 8,
                                             "8x8x2" if (kid >> 4) & 1 else "8x16", pw.ksize, stride,
-                                            " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else ""),
+                                            " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else "") +
+                                            (" up4" if folded else (" ups" if ups else "")),
                                             " nchw" if pw.out_nchw else "")
         _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize, kernel=label,
                                 bytes=(B * H * W * (C0 + C1) + B * Ho * Wo * pw.cout) * x0.element_size() + pw.w_hi.numel() * 2,
@@ -149,6 +170,13 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
 
 _conv_probe = None
 _use_v2 = True          # set False to force the v1 kernel everywhere (A/B measurements)
+_fold_ups = True        # set False to run upsample convs with HSIDM_UPS_ADDRESS (A/B measurements)
+UPS_FOLDED = 2          # include/hsidm.h HSIDM_UPS_FOLDED
+
+
+def set_fold_ups(flag):
+    global _fold_ups
+    _fold_ups = bool(flag)
 
 
 def set_use_v2(flag):
@@ -307,6 +335,25 @@ def p_sample_update(x, eps, coef, t_ptr, T, *, noise=None, noise_stride=0, seed=
                                                 _lib.ptr(noise), int(noise_stride), int(seed), x.numel(),
                                                 _lib.ptr(snap), int(inter),
                                                 _lib.stream_ptr()), "p_sample_update")
+
+
+def q_sample(x0, noise, gamma):
+    """gamma[b]*x0 + sqrt(1-gamma[b]^2)*noise on fp32 [B,...] tensors (reference diffusion.py:213-220)."""
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    _lib.check(_lib.lib().hsidm_q_sample(_lib.ptr(x0), _lib.ptr(noise), _lib.ptr(gamma), _lib.ptr(out), B,
+                                         x0.numel() // B, _lib.stream_ptr()), "q_sample")
+    return out
+
+
+def loss_sum(a, b, kind):
+    """sum |a-b| (kind "l1") or sum (a-b)^2 ("l2") as a 0-dim fp32 device tensor (reference set_loss, diffusion.py:85-91)."""
+    L = _lib.lib()
+    ws = torch.empty(L.hsidm_loss_workspace_bytes() // 8, dtype=torch.float64, device=a.device)
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    _lib.check(L.hsidm_loss_sum(_lib.ptr(a), _lib.ptr(b), a.numel(), {"l1": 0, "l2": 1}[kind], _lib.ptr(ws),
+                                _lib.ptr(out), _lib.stream_ptr()), "loss_sum")
+    return out[0]
 
 
 def step_advance(t_ptr, wrap_T=0):

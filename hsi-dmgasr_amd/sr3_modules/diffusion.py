@@ -228,12 +228,32 @@ class GaussianDiffusion(nn.Module):
     # ---------------------------------------------------------------------------------- training objective
     def q_sample(self, x_start, continuous_sqrt_alpha_cumprod, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise
-        return continuous_sqrt_alpha_cumprod * x_start + (1 - continuous_sqrt_alpha_cumprod ** 2).sqrt() * noise
+        b = x_start.shape[0]
+        gamma = continuous_sqrt_alpha_cumprod.to(torch.float32).reshape(b).contiguous()
+        return ops.q_sample(x_start.contiguous(), noise.contiguous(), gamma)
 
+    @torch.no_grad()
     def p_losses(self, x_in, noise=None):
-        raise NotImplementedError(
-            "hsidm: the training objective (reference diffusion.py:222-250) needs backward kernels, which are the "
-            "next scope row (SURVEY 8f N2); this build implements the inference path")
+        """Value of the training objective (reference diffusion.py:222-250): sum-reduced L1/L2 between the drawn noise
+        and UNet(cat(SR, q_sample(HR)), gamma).  t and the per-sample gamma come from numpy's global generator exactly
+        as in the reference, so `np.random.seed` reproduces its draws.  Forward value only: the result carries no
+        autograd graph (backward kernels are SURVEY 8f N2)."""
+        x_start = x_in["HR"].contiguous()
+        b = x_start.shape[0]
+        t = np.random.randint(1, self.num_timesteps + 1)
+        gamma = torch.FloatTensor(np.random.uniform(self.sqrt_alphas_cumprod_prev[t - 1],
+                                                    self.sqrt_alphas_cumprod_prev[t], size=b)).to(x_start.device)
+        noise = torch.randn_like(x_start) if noise is None else noise.contiguous()
+        x_noisy = self.q_sample(x_start, gamma, noise)
+        fn = self.denoise_fn
+        cond = x_in["SR"].contiguous() if self.conditional else None
+        if isinstance(fn, UNet):
+            x_recon = fn.forward_pair(cond, x_noisy, gamma=gamma)
+        else:
+            x_recon = fn(torch.cat([cond, x_noisy], dim=1) if cond is not None else x_noisy, gamma.view(b, -1))
+        if self.loss_type not in ("l1", "l2"):
+            raise NotImplementedError()
+        return ops.loss_sum(noise, x_recon.contiguous(), self.loss_type)
 
     def forward(self, x, *args, **kwargs):
         return self.p_losses(x, *args, **kwargs)

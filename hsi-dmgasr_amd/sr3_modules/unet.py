@@ -113,7 +113,7 @@ class Upsample(_HipModule):
 
     def _packed(self, precision):
         return self._cache.get(precision, [self.conv.weight, self.conv.bias],
-                               lambda: ops.PackedConv(self.conv.weight, self.conv.bias, precision))
+                               lambda: ops.PackedConv(self.conv.weight, self.conv.bias, precision, fold_ups=True))
 
     def _run(self, x, precision):
         return ops.conv2d(x, self._packed(precision), ups=True, stats=True)

@@ -66,6 +66,14 @@ typedef struct hsidm_conv_phase {
  *   common.ResBlock / ResAttentionBlock convs common.py:163-182,250-271 (LeakyReLU, 0.1*res + x)
  * out = res_scale * act(conv + bias[c] + film[b,c]) + res.
  */
+/* ups: 0 none; HSIDM_UPS_ADDRESS: the conv reads in[y>>1][x>>1] (any kernel path);
+ * HSIDM_UPS_FOLDED (HSIDM_BF16, bn = 128, no input transform): w_v2 holds the four parity-folded 2x2 kernels
+ *   [parity 2*py+px][chunk][tap 2*ty+tx][Cout_pad/32][4][64][8],
+ *   W_par[ty][tx] = sum of the 3x3 taps (dy, dx) with (py+dy-1)>>1 == py+ty-1 and (px+dx-1)>>1 == px+tx-1,
+ * because output pixel (2y+py, 2x+px) of conv3x3(nearest_x2(in)) only sees in[y-1+py+ty][x-1+px+tx]: 4/9 of the
+ * multiplications of HSIDM_UPS_ADDRESS.  Statistics entries: one per (input tile, parity, wave row). */
+#define HSIDM_UPS_ADDRESS 1
+#define HSIDM_UPS_FOLDED  2
 typedef struct hsidm_conv_desc {
     hsidm_conv_phase ph[2];
     int32_t nphase;           /* 1, or 2 = phase 1 is a fused 1x1 projection of a second input      */
@@ -86,7 +94,7 @@ typedef struct hsidm_conv_desc {
     int32_t B, Hin, Win, Hout, Wout, Cout;
     int32_t ksize;            /* 3 or 1 (phase 0)                                                   */
     int32_t stride;           /* 1 or 2                                                             */
-    int32_t ups;              /* 1: nearest x2 upsample folded in (Hout = 2*Hin)                    */
+    int32_t ups;              /* HSIDM_UPS_*: nearest x2 upsample folded in (Hout = 2*Hin)          */
     int32_t act;              /* HSIDM_ACT_*                                                        */
     int32_t out_nchw;         /* 1: write NCHW fp32 (network outputs)                               */
     int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3                                           */
@@ -161,6 +169,18 @@ int hsidm_p_sample_update(float* x, const float* eps, const float* coef, const i
 int hsidm_step_advance(int32_t* t_ptr, int32_t wrap_T, void* stream);
 /* out[i] = N(0,1) from Philox4x32-10(seed, stream), i < n  (x_T: stream = T). */
 int hsidm_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* ---- forward process / training objective (diffusion.py:213-250) -----------------------------------
+ * q_sample (diffusion.py:213-220): out = gamma[b]*x0 + sqrt(1-gamma[b]^2)*noise, fp32 [B][per_sample]. */
+int hsidm_q_sample(const float* x0, const float* noise, const float* gamma, float* out, int B,
+                   int64_t per_sample, void* stream);
+/* loss_func of set_loss (diffusion.py:85-91): out[0] = sum |a-b| (HSIDM_LOSS_L1) or sum (a-b)^2
+ * (HSIDM_LOSS_L2) over n fp32 elements; deterministic two-stage reduction (fp64 between stages).
+ * workspace: hsidm_loss_workspace_bytes() bytes of device memory owned by the caller. */
+#define HSIDM_LOSS_L1 0
+#define HSIDM_LOSS_L2 1
+int hsidm_loss_workspace_bytes(void);
+int hsidm_loss_sum(const float* a, const float* b, int64_t n, int kind, void* workspace, float* out, void* stream);
 
 /* ---- group-autoencoder pieces (AE.py / common.py) -----------------------------------------------------
  * CALayer (common.py:231-247): ca[b][c] = sigmoid(W2 relu(W1 mean_b + b1) + b2), mean from `part`.

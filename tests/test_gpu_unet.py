@@ -187,6 +187,40 @@ def test_sampler_stored_noise_golden(dev, prec, name):
     check("sampler_%s_last" % name, prec, frames[-1], g[name + ".last"], tol=2e-3)
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("kind", ["l1", "l2"])
+def test_training_objective_golden(dev, prec, tol, kind):
+    """GaussianDiffusion.forward(dict) = p_losses value, with t / gamma drawn from numpy's seed as the reference does."""
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    g = load_npz("losses.npz")
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision=prec).to(dev).eval()
+    fill_synth(u, "unet_tiny.")
+    k = "loss_%s." % kind
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, loss_type=kind, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(jload(g[k + "opt_json"]), dev)
+    xq = gd.q_sample(G(g[k + "hr"], dev), G(g[k + "gamma"], dev).view(-1, 1, 1, 1), G(g[k + "noise"], dev))
+    check("q_sample_%s" % kind, "fp32", xq, g[k + "x_noisy"], tol=1e-6)
+    np.random.seed(int(g[k + "np_seed"]))
+    loss = gd({"HR": G(g[k + "hr"], dev), "SR": G(g[k + "sr"], dev)}, noise=G(g[k + "noise"], dev))
+    assert loss.ndim == 0 and loss.dtype == torch.float32
+    check("p_losses_%s" % kind, prec, loss.reshape(1), g[k + "loss"].reshape(1), tol=tol)
+
+
+def test_loss_sum_large_and_bad_args(dev):
+    from hsi_dmgasr_amd import ops
+    a = torch.randn(3_000_001, device=dev)
+    b = torch.randn(3_000_001, device=dev)
+    ref1 = (a.double() - b.double()).abs().sum().item()
+    ref2 = ((a.double() - b.double()) ** 2).sum().item()
+    assert abs(ops.loss_sum(a, b, "l1").item() - ref1) < 1e-6 * ref1
+    assert abs(ops.loss_sum(a, b, "l2").item() - ref2) < 1e-6 * ref2
+    assert ops.loss_sum(a, b, "l1").item() == ops.loss_sum(a, b, "l1").item()      # deterministic
+    with pytest.raises(KeyError):
+        ops.loss_sum(a, b, "huber")
+
+
 def test_sampler_api_shapes_and_philox_mode(dev):
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
     from oracle import diffusion as odiff, sr3_unet
@@ -256,6 +290,49 @@ def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
         outs.append(yf.cpu())
     ops.set_use_v2(True)
     check("conv_v2_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=2e-3)
+
+
+UP4_CASES = [  # B, H, W, Cin, Cout  (input grid)
+    (4, 16, 32, 128, 128),     # 8x16 tiles, one cout slice, L2-friendly (tile, parity) order (16 tiles % 8 == 0)
+    (3, 16, 32, 64, 128),      # 12 tiles: plain order
+    (8, 8, 8, 128, 256),       # two-image 8x8 tiles, two cout slices, 4 XCDs per slice
+    (5, 8, 8, 64, 256),        # odd batch: a half-empty two-image tile
+    (2, 12, 20, 64, 128),      # partial tiles on both axes
+    (1, 8, 16, 72, 100),       # channel counts that are not multiples of the chunk / slice
+]
+
+
+@pytest.mark.parametrize("case", UP4_CASES)
+def test_folded_upsample_conv_matches_addressed_upsample(dev, case):
+    """HSIDM_UPS_FOLDED (four parity 2x2 kernels, K = 4*Cin) against HSIDM_UPS_ADDRESS (3x3 on in[y>>1][x>>1]) and against
+    torch's fp32 conv3x3(nearest_x2(x)); statistics slab against sums of the stored output."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pk = ops.PackedConv(w.to(dev), bias.to(dev), "bf16", fold_ups=True)
+    assert pk.w_up4 is not None and pk.w_up4.shape[0] == 16 * ((Ci + 63) // 64)
+    x = torch.randn(B, H, W, Ci, generator=g).to(torch.bfloat16)
+    outs = []
+    for fold in (False, True):
+        ops.set_fold_ups(fold)
+        try:
+            y = ops.conv2d(x.to(dev), pk, ups=True, stats=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_fold_ups(True)
+        slab, nsplit = y._hsidm_stats
+        yf = y.float()
+        assert y.shape == (B, 2 * H, 2 * W, Co) and slab.shape == (B, nsplit, Co, 2)
+        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
+        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), fold
+        outs.append(yf.cpu())
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest"),
+                                     w, bias, padding=1).permute(0, 2, 3, 1)
+    check("up4_vs_addressed%s" % (case,), "bf16", outs[1], outs[0], tol=6e-3)
+    check("up4_vs_torch%s" % (case,), "bf16", outs[1], ref, tol=1e-2)
+    check("ups_vs_torch%s" % (case,), "bf16", outs[0], ref, tol=1e-2)
 
 
 C1_CASES = [  # B, H, W, C0, C1, Cout, with_res

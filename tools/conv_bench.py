@@ -27,6 +27,8 @@ SHAPES = [  # name, H, C0, C1, Cout, ksize, stride, ups, proj_cin
     ("l8_1024_512", 8, 512, 512, 512, 3, 1, 0, 0),
     ("up_128_to128", 64, 128, 0, 128, 3, 1, 1, 0),
     ("up_256_to64", 32, 256, 0, 256, 3, 1, 1, 0),
+    ("up_512_to32", 16, 512, 0, 512, 3, 1, 1, 0),
+    ("up_512_to16", 8, 512, 0, 512, 3, 1, 1, 0),
     ("down_128_64", 128, 64, 0, 64, 3, 2, 0, 0),
     ("qkv_16_512", 16, 512, 0, 1536, 1, 1, 0, 0),
     ("stem_128_8_64", 128, 8, 0, 64, 3, 1, 0, 0),
@@ -46,6 +48,7 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--v1", action="store_true", help="force the v1 kernel (A/B against conv_v2)")
+    ap.add_argument("--no-fold", action="store_true", help="upsample convs with HSIDM_UPS_ADDRESS instead of the parity-folded kernels")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops.set_use_v2(not args.v1)
@@ -59,7 +62,7 @@ def main():
         w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
         pwt = torch.randn(Co, pj, 1, 1, generator=g) / pj ** 0.5 if pj else None
         pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), prec, proj_weight=None if pwt is None else pwt.to(dev),
-                            proj_bias=None if pwt is None else torch.zeros(Co, device=dev))
+                            proj_bias=None if pwt is None else torch.zeros(Co, device=dev), fold_ups=bool(up) and not args.no_fold)
         x0 = torch.randn(B, H, H, C0, generator=g).to(dev, dt)
         x1 = torch.randn(B, H, H, C1, generator=g).to(dev, dt) if C1 else None
         px = torch.randn(B, H, H, pj, generator=g).to(dev, dt) if pj else None
@@ -75,7 +78,7 @@ def main():
             best = min(best, e0.elapsed_time(e1))
         Ho = y.shape[1]
         flops = 2.0 * B * Ho * Ho * Co * ((C0 + C1) * ks * ks + pj)
-        print("%-22s %9.1f us %8.1f TFLOP/s" % (name, best * 1e3, flops / (best * 1e-3) / 1e12), flush=True)
+        print("%-22s %9.1f us %8.1f TFLOP/s (reference FLOP count)" % (name, best * 1e3, flops / (best * 1e-3) / 1e12), flush=True)
         del x0, x1, px, y, pk
 
 
