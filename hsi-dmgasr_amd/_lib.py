@@ -9,7 +9,8 @@ import os
 import torch  # must be imported first: the library resolves libamdhip64.so.7 to the copy torch loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhsidm.so")
+# HSIDM_LIB: diagnostic override (A/B builds, in-kernel stamp builds); the product library is libhsidm.so next to this file
+LIB_PATH = os.environ.get("HSIDM_LIB") or os.path.join(_HERE, "libhsidm.so")
 
 BF16, F32X3 = 0, 1
 XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2

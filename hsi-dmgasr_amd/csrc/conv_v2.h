@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int HV_LDS_STEP = (256 / VPP) * PSTR;
     const bool last_live = tid + (MAXHV - 1) * 256 < C::HVEC;  // the last vector slot is partial
     int hv_pix[MAXHV];                                          // for the tile being STAGED
-    auto hv_pos = [&](int i) __attribute__((always_inline)) -> int {   // img<<16 | hy<<8 | hx, or -1 (dead slot); recomputed, not kept
-        const int hp = tid / VPP + i * (256 / VPP);
+    auto hv_pos = [&](int i, int t) __attribute__((always_inline)) -> int {   // img<<16 | hy<<8 | hx, or -1 (dead slot); recomputed, not kept
+        const int hp = t / VPP + i * (256 / VPP);
         const int img = hp / HPIX;
         const int r = hp - img * HPIX;
         const int hy = r / HCOLS, hx = r - hy * HCOLS;
@@ -226,9 +226,12 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const bool up = !UP4 && p.ups;
         const int hlim = up ? 2 * p.Hin : p.Hin, wlim = up ? 2 * p.Win : p.Win;
         const int sh = up ? 1 : 0;
+        int t_op = tid;
+        asm volatile("" : "+v"(t_op));      // recompute the halo positions here: hoisted out of the item loop they were spilled, and
+                                            // every scratch reload is an s_waitcnt vmcnt(0) that drains the prefetch queues
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int pos = hv_pos(i);
+            const int pos = hv_pos(i, t_op);
             const int b = b0 + (pos >> 16);
             const int iy = oy0 + ((pos >> 8) & 255) - 1, ix = ox0 + (pos & 255) - 1;
             const bool ok = pos >= 0 && b < p.B && iy >= 0 && ix >= 0 && iy < hlim && ix < wlim;
@@ -339,36 +342,38 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     lds_barrier();
     stage_advance();
 
-    // per-lane output channel and its bias are fixed for the whole block; the FiLM term depends on the item's
-    // image and is fetched ONE ITEM AHEAD.  bias + FiLM is the accumulators' start value, so the epilogue neither adds
-    // nor waits for them.
+    // Per-lane output channel n; bias[n] + FiLM[image][n] are added to the accumulators in the epilogue.  They are fetched at
+    // the start of the item with loads the compiler does not track (inline asm): as a tracked, loop-carried value the
+    // compiler waited for them with s_waitcnt vmcnt(0) at the loop latch, i.e. for the acknowledgement of every output
+    // store of the item, once per item.  vmcnt retires in order and a whole K loop of tracked weight loads follows, so
+    // the values have long landed when the epilogue's own `s_waitcnt vmcnt(4)` names them.
     const int n = n0 + wn * 32 + lr;
     const bool nok = n < p.Cout;
     const int nn = nok ? n : 0;
-    const float bias = p.bias ? p.bias[nn] : 0.f;
-    float film_nx[NI];
-    auto film_fetch = [&](int it_item) __attribute__((always_inline)) {
-        const int itc = it_item < p.total_items ? it_item : blockIdx.x;       // past the end: any valid item
-        int par_;
-        const int fb0 = (item_tile(itc, par_) / tiles_per_img) * NI;
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
-            film_nx[q] = p.film ? p.film[(size_t)fb * p.film_stride + nn] : 0.f;
-        }
+    auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
+        float v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
+        return v;
     };
-    film_fetch(item);
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         HSIDM_STAMP(it, 0);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            const int img = (wm * (C::BM / WM) + mr * 32) / (TH * TW);
-            const float start = nok ? bias + film_nx[NI == 1 ? 0 : img] : 0.f;
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mr][j] = start;
+            for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
+        float ep_add[NI], ep_bias = 0.f;                       // landed by the epilogue (see above)
+        {
+            int par_;
+            const int fb0 = (item_tile(item, par_) / tiles_per_img) * NI;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
+                ep_add[q] = 0.f;
+                if (p.film) ep_add[q] = untracked_load(p.film + (size_t)fb * p.film_stride + nn);
+            }
+            if (p.bias) ep_bias = untracked_load(p.bias + nn);
         }
-        film_fetch(item + G);
         int par = 0;
         const int it_tile = item_tile(item, par);
         const int py = par >> 1, px = par & 1;
@@ -441,6 +446,10 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         float s1[NI], s2[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) s1[q] = s2[q] = 0.f;
+        if (NI == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0]), "+v"(ep_bias));
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0]), "+v"(ep_add[NI - 1]), "+v"(ep_bias));
+#pragma unroll
+        for (int q = 0; q < NI; ++q) ep_add[q] = nok ? ep_add[q] + ep_bias : 0.f;
         const bool full = oy0 + TH <= lim_h && ox0 + TW <= lim_w && b0 + NI <= p.B && n0 + BN <= p.Cout;
         if (full) {
             // Whole tile inside the image.  2-byte stores straight from the accumulator layout cost ~200 cycles each
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));                                 // keep these lane constants out of the main loop's registers
             const int pl0 = lane_e >> 2, cq = lane_e & 3;
+            const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
             const unsigned lane_el = (unsigned)((US * (pl0 >> LTW) * p.Wout + US * (pl0 & (TW - 1))) * p.Cout + cq * 8);
             auto vec_base = [&](int g, int v4) __attribute__((always_inline)) -> size_t {
                 const int pbase = wm * (C::BM / WM) + g * 32;
@@ -467,15 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
                 constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
                 constexpr bool RES = decltype(res_tag)::value != 0;
-                bf16x8 rv[RES ? NV : 1];
-                if (RES) {
-#pragma unroll
-                    for (int g = 0; g < MR; g += 2)
-#pragma unroll
-                        for (int v4 = 0; v4 < 4; ++v4)
-                            if (v4 < 2 * (MR - g < 2 ? MR - g : 2))
-                                rv[g * 2 + v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(g, v4) + lane_el);
-                }
+                bf16x8 rv[RES ? 4 : 1];                                        // residual vectors of the current pass
                 float vs1[8], vs2[8];
 #pragma unroll
                 for (int g = 0; g < MR; g += 2) {
@@ -483,17 +485,23 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     const int pbase = wm * (C::BM / WM) + g * 32;
                     const int img = pbase / (TH * TW);                         // a pass never straddles two images
                     const int b = b0 + img;
+                    if (RES) {                                                 // requested first: the latency hides behind the transposition
+#pragma unroll
+                        for (int v4 = 0; v4 < 4; ++v4)
+                            if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(g, v4) + lane_el);
+                    }
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         if (m2 >= nm) break;
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
-                            const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
-                            float v = acc[g + m2][j];                          // bias + FiLM are the accumulator's start value
+                            const int row = (j & 3) + 8 * (j >> 2);
+                            float v = acc[g + m2][j] + ep_add[NI == 1 ? 0 : img];
                             if (LEAKY) v = v > 0.f ? v : 0.01f * v;
-                            scr[(m2 * 32 + row) * SCR_STR + lr] = (bf16)v;
+                            scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
                         }
                     }
+                    HSIDM_STAMP(it, 9);
                     if (NI == 2 || g == 0) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                         if (RES) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {
-                                o[k] = (bf16)fmaf(p.res_scale, f[k], (float)rv[g * 2 + v4][k]);
+                                o[k] = (bf16)fmaf(p.res_scale, f[k], (float)rv[v4][k]);
                                 f[k] = (float)o[k];
                             }
                         }
@@ -517,30 +525,38 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
                     }
+                    HSIDM_STAMP(it, 11);
                     if (p.stats && (NI == 2 || g + 2 >= MR)) {
-                        // lanes with equal (lane & 3) hold the same 8 couts: fold the 16 of them together
+                        // Lanes with equal (lane & 3) hold the same 8 couts: fold the 16 of them together with a halving
+                        // butterfly -- at every level a lane hands the half of its values its partner keeps and receives
+                        // the half it keeps itself: 8+4+2+1 = 15 cross-lane moves instead of 4*16, and every lane ends
+                        // up with ONE finished entry, idx = 8*bit2 + 4*bit3 + 2*bit4 + bit5 (idx < 8: sum of cout idx,
+                        // else sum of squares of cout idx - 8).
+                        const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
+                        float a8[8], a4[4], a2[2];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
+                        for (int i = 0; i < 8; ++i)
+                            a8[i] = (hi0 ? vs2[i] : vs1[i]) + __shfl_xor(hi0 ? vs1[i] : vs2[i], 4, 64);
 #pragma unroll
-                            for (int o2 = 4; o2 < 64; o2 <<= 1) {
-                                vs1[k] += __shfl_xor(vs1[k], o2, 64);
-                                vs2[k] += __shfl_xor(vs2[k], o2, 64);
-                            }
-                        }
+                        for (int i = 0; i < 4; ++i)
+                            a4[i] = (hi1 ? a8[i + 4] : a8[i]) + __shfl_xor(hi1 ? a8[i] : a8[i + 4], 8, 64);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            a2[i] = (hi2 ? a4[i + 2] : a4[i]) + __shfl_xor(hi2 ? a4[i] : a4[i + 2], 16, 64);
+                        const float a1 = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], 32, 64);
                         int sub;
                         if (NI == 1) sub = wm;
                         else if (WM == 1) sub = 0;
                         else sub = wm % (WM / 2 > 0 ? WM / 2 : 1);
-                        if (lane < 4) {
-                            float2* dst = p.stats + ((size_t)b * (tiles_per_img * (US * US) * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n0 + wn * 32 + lane * 8;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) dst[k] = make_float2(vs1[k], vs2[k]);
-                        }
+                        const int idx = ((lane_e >> 2) & 1) * 8 + ((lane_e >> 3) & 1) * 4 + ((lane_e >> 4) & 1) * 2 + (lane_e >> 5);
+                        float* dst = reinterpret_cast<float*>(p.stats + ((size_t)b * (tiles_per_img * (US * US) * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n0 + wn * 32);
+                        dst[(cq * 8 + (idx & 7)) * 2 + (idx >> 3)] = a1;
                     }
                 }
             };
             if (p.act == ACT_LEAKY) { if (p.res) run(SlotTag<1>{}, SlotTag<1>{}); else run(SlotTag<1>{}, SlotTag<0>{}); }
             else                    { if (p.res) run(SlotTag<0>{}, SlotTag<1>{}); else run(SlotTag<0>{}, SlotTag<0>{}); }
+            HSIDM_STAMP(it, 14);
             lds_barrier();                                                   // the patch is part of the next staging buffer
         } else {
 #pragma unroll
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 const int q = pbase + row - img * (TH * TW);
                 const int ty = q / TW, tx = q - ty * TW;
                 const int oy = oyb + US * ty, ox = oxb + US * tx;
-                float v = acc[mr][j];
+                float v = acc[mr][j] + ep_add[NI == 1 ? 0 : img];
                 if (!(nok && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
                 if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;

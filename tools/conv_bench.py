@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--v1", action="store_true", help="force the v1 kernel (A/B against conv_v2)")
+    ap.add_argument("--no-xf", action="store_true", help="3x3 convs without the GroupNorm+SiLU input transform (cost of the fused prologue)")
     ap.add_argument("--no-fold", action="store_true", help="upsample convs with HSIDM_UPS_ADDRESS instead of the parity-folded kernels")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -67,7 +68,7 @@ def main():
         x1 = torch.randn(B, H, H, C1, generator=g).to(dev, dt) if C1 else None
         px = torch.randn(B, H, H, pj, generator=g).to(dev, dt) if pj else None
         ab = torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev)
-        xf = ops.XF_AFFINE_SILU if (ks == 3 and st == 1 and not up) else ops.XF_NONE
+        xf = ops.XF_AFFINE_SILU if (ks == 3 and st == 1 and not up and not args.no_xf) else ops.XF_NONE
         best = 1e9
         for _ in range(args.reps + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

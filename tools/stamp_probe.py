@@ -24,7 +24,7 @@ def main():
     shp = [s for s in cb.SHAPES if s[0] == name][0]
     _, H, C0, C1, Co, ks, st, up, pj = shp
     dev = torch.device("cuda:0")
-    B = 40
+    B = int(os.environ.get("HSIDM_PROBE_BATCH", "40"))
     g = torch.Generator().manual_seed(0)
     w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
     pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), "bf16")
@@ -58,6 +58,9 @@ def main():
         ch = [a[:, :, 1 + c][ok] for c in range(8) if (a[:, :, 1 + c][ok] > 0).all()]
         line = "item %d: n=%4d  start@%8.0f  loop=%7.0f  (last pre-barrier->barrier %6.0f)  epilogue=%7.0f" % (
             it, ok.sum(), np.median(start - t0), np.median(ep0 - start), np.median(ep0 - pre), np.median(ep1 - ep0))
+        e = lambda k: a[:, :, k][ok]
+        line += "  ep: scr=%5.0f vec=%5.0f stats=%5.0f barrier=%5.0f" % (np.median(e(9) - ep0), np.median(e(11) - e(9)),
+                                                                          np.median(e(14) - e(11)), np.median(ep1 - e(14)))
         if len(ch) > 1:
             line += "  chunks=" + " ".join("%.0f" % np.median(ch[i] - (ch[i - 1] if i else start)) for i in range(len(ch)))
         print(line)
