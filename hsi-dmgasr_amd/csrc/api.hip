@@ -1,5 +1,6 @@
 // C-ABI entry points: argument validation, tile selection and dispatch for the convolution.
 #include "conv_v2.h"
+#include <cstdlib>
 #include "../../include/hsidm.h"
 
 namespace hsidm {
@@ -16,7 +17,9 @@ HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 void conv_v2_set_stamps(unsigned long long* p);
-int conv1x1_ws_run(C1Params& p, hipStream_t s);
+int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
+                  const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
+                  int nch, hipStream_t s);
 }  // namespace hsidm
 
 using namespace hsidm;
@@ -37,7 +40,17 @@ extern "C" const char* hsidm_error_string(int code) {
 
 extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
 
-enum { PATH_V1 = 0, PATH_V2 = 1, PATH_WS = 2 };
+enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3 };
+
+// HSIDM_1X1=v1 (diagnostic): keep 1x1 convolutions on the generic kernel for A/B measurements
+static bool force_v1_1x1() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("HSIDM_1X1");
+        mode = (e && e[0] == 'v') ? 1 : 0;
+    }
+    return mode == 1;
+}
 
 static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
     if (!d) return HSIDM_E_BADARG;
@@ -68,13 +81,9 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     }
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
-        // weight-stationary 1x1: whole [K][64] slice in LDS (K padded to 128), 32-pixel tiles inside one image.
-        // Measured (tools/conv_bench.py): faster than v1 for K <= 512; the K <= 1024 / 32-cout variant is not, so
-        // those shapes stay on v1.
-        const int kpad = (d->ph[0].C0 + d->ph[0].C1 + 127) / 128 * 128;
-        const int cpad64 = (d->Cout + d->bn - 1) / d->bn * d->bn;
-        if (d->ksize == 1 && xf == HSIDM_XF_NONE && d->act == HSIDM_ACT_NONE && !d->film && kpad <= 512 && cpad64 % 64 == 0 &&
-            (Hout * Wout) % 32 == 0) path = PATH_WS;
+        // LDS-staged GEMM (conv1x1_g.hip): whole cout slices, 64-pixel statistics groups
+        if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
+            (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
     }
     return HSIDM_OK;
 }
@@ -83,7 +92,7 @@ extern "C" int hsidm_conv_kernel_id(const hsidm_conv_desc* d) {
     int Hout, Wout, tile_kind, path;
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
-    return path | (tile_kind << 4) | (d->bn << 8);
+    return path | ((path == PATH_G1 ? 0 : tile_kind) << 4) | (d->bn << 8);
 }
 
 extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
@@ -91,7 +100,7 @@ extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
     if (d->out_nchw) return HSIDM_E_UNSUPPORTED;
-    if (path == PATH_WS) return Hout * Wout / 32;
+    if (path == PATH_G1) return Hout * Wout / 64;
     const bool use_v2 = path == PATH_V2;
     const int TW = tile_kind == 0 ? 16 : 8;
     if (d->ups == HSIDM_UPS_FOLDED)      // one entry per (input tile, parity, wave row)
@@ -139,18 +148,12 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     const int tiles_x = ((up4 ? d->Win : Wout) + TW - 1) / TW, tiles_y = ((up4 ? d->Hin : Hout) + TH - 1) / TH;
     const int cout_pad = (d->Cout + d->bn - 1) / d->bn * d->bn;
     hipStream_t s = (hipStream_t)stream;
-    if (path == PATH_WS) {
-        C1Params c;
-        c.src0 = reinterpret_cast<const bf16*>(p.ph[0].src0);
-        c.src1 = reinterpret_cast<const bf16*>(p.ph[0].src1);
-        c.C0 = p.ph[0].C0; c.C1 = p.ph[0].C1;
-        c.w = reinterpret_cast<const bf16*>(d->w_v2);
-        c.bias = d->bias; c.res = reinterpret_cast<const bf16*>(d->res); c.res_scale = d->res_scale;
-        c.out = reinterpret_cast<bf16*>(d->out); c.stats = reinterpret_cast<float2*>(d->stats);
-        c.M = d->B * Hout * Wout; c.HW = Hout * Wout; c.Cout = d->Cout; c.Cout_pad = cout_pad;
-        c.ksteps = (p.ph[0].C0 + p.ph[0].C1 + 127) / 128 * 2;
-        if (d->film) return HSIDM_E_UNSUPPORTED;
-        return conv1x1_ws_run(c, s);
+    if (path == PATH_G1) {
+        const hsidm_conv_phase& s0 = d->ph[0];
+        return conv1x1_g_run(d->bn, s0.transform, reinterpret_cast<const bf16*>(s0.src0), reinterpret_cast<const bf16*>(s0.C1 > 0 ? s0.src1 : nullptr),
+                             s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), d->bias, reinterpret_cast<const bf16*>(d->res),
+                             d->res_scale, reinterpret_cast<bf16*>(d->out), reinterpret_cast<float2*>(d->stats), d->B * Hout * Wout,
+                             Hout * Wout, d->Cout, (s0.C0 + s0.C1 + 127) / 128 * 2, s);
     }
     if (use_v2) {
         ConvV2Params v;

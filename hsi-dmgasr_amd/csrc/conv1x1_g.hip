@@ -1,0 +1,314 @@
+// conv1x1_g: LDS-staged 1x1 convolution (a GEMM out[pixel][cout] = T(x[pixel][:]) . W[cout][:]) for the bf16
+// throughput mode: ResnetBlock residual projections (reference unet.py:102-103), attention qkv / out projections
+// (unet.py:128,141).
+//
+// Measurements behind it (tools/conv_bench.py, batch 120): the generic v1 kernel ran these GEMMs at 180-310 TFLOP/s,
+// the weight-stationary kernel (conv1x1_ws.hip) loads activations as MFMA A-fragments (16 B per lane, 32 different
+// rows per wave-load) and is bound by the texture addresser, 1.6x off the HBM floor on the 128x128 level.  Here
+//   * the activation tile (128 consecutive pixels x 64 channels) is fetched with row-contiguous 16-byte loads (8 lanes
+//     = one 128-byte line), held in registers for one K chunk and a half, and committed to a double-buffered padded
+//     LDS tile (144-byte pixel rows, the conv_v2 layout: conflict-free ds_read_b128 A-fragments);
+//   * weights never touch LDS: each wave streams its B-fragments from L2 through an 8-slot register ring, six
+//     fragments (1.5 K chunks) ahead, in the order conv_v2 uses (one wave-load = 1 KiB contiguous);
+//   * the workgroup is persistent over (pixel tile, cout slice) items with conv_v2's XCD-aware slice mapping; the
+//     staging of the next item's first chunks overlaps the epilogue;
+//   * optional GroupNorm affine on the input (attention qkv: norm without SiLU) in the commit step;
+//   * epilogue as in conv_v2: bias, LDS transposition, 16-byte stores, residual, statistics per 64-pixel group.
+// K is padded to a multiple of 128 with zero weights (two chunks per loop trip keep every register index static).
+#include "conv_v2.h"
+#include "../../include/hsidm.h"
+
+namespace hsidm {
+
+struct C1gParams {
+    const bf16* src0;
+    const bf16* src1;
+    int C0, C1;
+    const f32x4* gn_ab;     // [B][Ctot/2] = (scale, shift) of two channels, or null
+    const bf16* w;          // [chunk][Cout_pad/32][kk 4][lane 64][8]
+    const float* bias;
+    const bf16* res;
+    float res_scale;
+    bf16* out;
+    float2* stats;          // [B][HW/64][Cout] or null
+    int M, HW, Cout, Cout_pad, nch;     // nch = K_pad / 64, even
+    int n_slices, m_tiles, total_items;
+};
+
+template <int BN, int XF>
+__global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
+    constexpr int WN = BN / 32, WM = 4 / WN, MR = 128 / WM / 32;
+    constexpr int PSTR = 72, TILE = 128 * PSTR;
+    constexpr int SCR_STR = 40;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* xt = reinterpret_cast<bf16*>(smem_raw);               // [2][TILE] (+ 2 KiB: the epilogue patch overruns buffer 1)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int G = gridDim.x;
+    const int ctot = p.C0 + p.C1;
+
+    int item = blockIdx.x;                                      // item = m_tile * n_slices + n_slice
+    const int ns = item % p.n_slices;                           // constant for this block (G % n_slices == 0)
+    const int n0 = ns * BN;
+    const int n_items_blk = (p.total_items - item + G - 1) / G;
+
+    // ---- weight stream -------------------------------------------------------------------------------------------
+    const int nsw = p.Cout_pad >> 5;
+    const bf16* wlane = p.w + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
+    bf16x8 fring[8];
+    int wnext = 0;
+    auto f_issue = [&](bf16x8& dst, int kk) __attribute__((always_inline)) {
+        dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)wnext * wstep_stride + kk * 64 * 8);
+        if (kk == 3) wnext = (wnext + 1 == p.nch) ? 0 : wnext + 1;
+    };
+
+    // ---- activation staging: vector i of this thread = pixel i*32 + tid/8 of the tile, channels 8*(tid%8).. of the chunk
+    const int cv = tid & 7;
+    const int px_l = tid >> 3;
+    const int hv0 = px_l * PSTR + cv * 8;
+    u32x4 hreg[2][4];
+    int set_m0[2] = {0, 0}, set_cc[2] = {0, 0};
+    bool set_ok[2] = {false, false};
+    int st_item = item, st_chunk = 0;
+    bool st_valid = true;
+    auto issue = [&](int S) __attribute__((always_inline)) {
+        set_ok[S] = st_valid;
+        if (!st_valid) return;
+        const int m0 = (st_item / p.n_slices) * 128;
+        const int c = st_chunk * 64 + cv * 8;
+        const int cc = c < ctot ? c : 0;                        // zero-weight padding: any finite data will do
+        const bf16* src;
+        int cs;
+        if (cc < p.C0) { src = p.src0 + cc; cs = p.C0; }
+        else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
+        set_m0[S] = m0;
+        set_cc[S] = cc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = m0 + i * 32 + px_l;
+            m = m < p.M ? m : p.M - 1;
+            hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
+        }
+        if (++st_chunk == p.nch) { st_chunk = 0; st_item += G; }
+        st_valid = st_item < p.total_items;
+    };
+    unsigned abh[2][8];                                         // GroupNorm (scale, shift), fp16x2, for pixel halves 0-63 / 64-127
+    auto params_fetch = [&](int S) __attribute__((always_inline)) {
+        if (XF == XF_NONE || !set_ok[S]) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = set_m0[S] + 64 * h;
+            m = m < p.M ? m : p.M - 1;
+            const int b = m / p.HW;
+            const f32x4* ab = p.gn_ab + (((size_t)b * ctot + set_cc[S]) >> 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = ab[q];
+                abh[h][2 * q] = pack_h2(t[0], t[1]);
+                abh[h][2 * q + 1] = pack_h2(t[2], t[3]);
+            }
+        }
+    };
+    auto commit = [&](int S, int i, int buf) __attribute__((always_inline)) {
+        if (!set_ok[S]) return;
+        u32x4 raw = hreg[S][i];
+        if (XF != XF_NONE) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] = __uint_as_float(raw[k] << 16);
+                v[2 * k + 1] = __uint_as_float(raw[k] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], h2_lo(abh[i >> 1][k]), h2_hi(abh[i >> 1][k]));
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
+            *reinterpret_cast<bf16x8*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = o;
+        } else {
+            *reinterpret_cast<u32x4*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = raw;
+        }
+    };
+
+    // ---- MFMA fragment bases ---------------------------------------------------------------------------------------
+    int abase[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (128 / WM) + mr * 32 + lr) * PSTR + 8 * lh;
+    f32x16 acc[MR];
+
+    // prologue: chunks 0 and 1 requested, six weight fragments in flight, chunk 0 committed
+#pragma unroll
+    for (int f = 0; f < 6; ++f) f_issue(fring[f], f % 4);
+    issue(0);
+    issue(1);
+    params_fetch(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) commit(0, i, 0);
+    lds_barrier();
+
+    const int n = n0 + wn * 32 + lr;
+    const float bias = p.bias ? p.bias[n] : 0.f;                // Cout % BN == 0 on this path
+
+    for (int it = 0; it < n_items_blk; ++it, item += G) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
+        for (int chunk = 0; chunk < p.nch; chunk += 2) {
+            // body(PAR): MFMAs on buffer PAR, commits the chunk held in register set PAR^1 into buffer PAR^1, requests the
+            // chunk after that into set PAR (whose previous content was committed one body ago)
+            auto body = [&](auto par_tag) __attribute__((always_inline)) {
+                constexpr int PAR = decltype(par_tag)::value;
+                const bf16* hb = xt + PAR * TILE;
+                issue(PAR);
+                params_fetch(PAR ^ 1);
+                bf16x8 a[3][MR];
+                auto a_fetch = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + u * 16);
+                };
+                a_fetch(0);
+                a_fetch(1);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int u = PAR * 4 + kk;                 // position in the two-chunk trip: the weight ring's period
+                    if (kk + 2 < 4) a_fetch(kk + 2);
+                    f_issue(fring[(u + 6) % 8], (u + 6) % 4);
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3][mr], fring[u % 8], acc[mr], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk == 1) { commit(PAR ^ 1, 0, PAR ^ 1); commit(PAR ^ 1, 1, PAR ^ 1); }
+                    if (kk == 2) { commit(PAR ^ 1, 2, PAR ^ 1); commit(PAR ^ 1, 3, PAR ^ 1); }
+                }
+                lds_barrier();
+            };
+            body(SlotTag<0>{});
+            body(SlotTag<1>{});
+        }
+
+        // ---- epilogue: buffer 1 is free (the last chunk of an item has odd parity), buffer 0 holds the next item's chunk 0
+        const int m0 = (item / p.n_slices) * 128;
+        bf16* scr = xt + TILE + wave * (64 * SCR_STR);
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int pl0 = lane_e >> 2, cq = lane_e & 3;
+        const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
+        auto run = [&](auto res_tag) __attribute__((always_inline)) {
+            constexpr bool RES = decltype(res_tag)::value != 0;
+#pragma unroll
+            for (int g = 0; g < MR; g += 2) {
+                const int nm = (MR - g) < 2 ? (MR - g) : 2;
+                const int mp = m0 + wm * (128 / WM) + g * 32;          // first pixel of this 64-pixel pass (M % 64 == 0)
+                if (mp >= p.M) break;
+                const size_t obase = (size_t)mp * p.Cout + n0 + wn * 32;
+                const unsigned lane_el = (unsigned)(pl0 * p.Cout + cq * 8);
+                bf16x8 rv[RES ? 4 : 1];
+                if (RES) {
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4)
+                        if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + obase + (size_t)16 * v4 * p.Cout + lane_el);
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    if (m2 >= nm) break;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int row = (j & 3) + 8 * (j >> 2);
+                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)(acc[g + m2][j] + bias);
+                    }
+                }
+                float vs1[8], vs2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    if (v4 >= 2 * nm) break;
+                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                    float f[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
+                    bf16x8 o = raw;
+                    if (RES) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            o[k] = (bf16)fmaf(p.res_scale, f[k], (float)rv[v4][k]);
+                            f[k] = (float)o[k];
+                        }
+                    }
+                    *reinterpret_cast<bf16x8*>(p.out + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                }
+                if (p.stats) {
+                    // halving butterfly over the 16 lanes that hold the same 8 couts (see conv_v2.h)
+                    const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
+                    float a8[8], a4[4], a2[2];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a8[i] = (hi0 ? vs2[i] : vs1[i]) + __shfl_xor(hi0 ? vs1[i] : vs2[i], 4, 64);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a4[i] = (hi1 ? a8[i + 4] : a8[i]) + __shfl_xor(hi1 ? a8[i] : a8[i + 4], 8, 64);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a2[i] = (hi2 ? a4[i + 2] : a4[i]) + __shfl_xor(hi2 ? a4[i] : a4[i + 2], 16, 64);
+                    const float a1 = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], 32, 64);
+                    const int idx = ((lane_e >> 2) & 1) * 8 + ((lane_e >> 3) & 1) * 4 + ((lane_e >> 4) & 1) * 2 + (lane_e >> 5);
+                    const int grp = mp >> 6;                           // 64-pixel group: image = grp / (HW/64)
+                    float* dst = reinterpret_cast<float*>(p.stats + (size_t)grp * p.Cout + n0 + wn * 32);
+                    dst[(cq * 8 + (idx & 7)) * 2 + (idx >> 3)] = a1;
+                }
+            }
+        };
+        if (p.res) run(SlotTag<1>{}); else run(SlotTag<0>{});
+        lds_barrier();                                                  // the patch is the next odd chunk's buffer
+    }
+}
+
+static int g1_slots = 0;
+
+template <int BN, int XF>
+static int run_g1(C1gParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 128 * 72 * 2 + 2048;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_g_kernel<BN, XF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    if (g1_slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g1_slots = 2 * cus;
+    }
+    p.n_slices = p.Cout_pad / BN;
+    p.m_tiles = (p.M + 127) / 128;
+    p.total_items = p.m_tiles * p.n_slices;
+    int lcm = 8;
+    while (lcm % p.n_slices) lcm += 8;
+    int G = (p.total_items < g1_slots ? p.total_items : g1_slots) / lcm * lcm;
+    if (G == 0) G = p.total_items;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF>), dim3(G), dim3(256), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+// bn: 64 or 128 (Cout % bn == 0); xf: XF_NONE or XF_AFFINE; HW % 64 == 0; nch even
+int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
+                  const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
+                  int nch, hipStream_t s) {
+    C1gParams p;
+    p.src0 = src0; p.src1 = src1; p.C0 = C0; p.C1 = C1;
+    p.gn_ab = reinterpret_cast<const f32x4*>(gn_ab);
+    p.w = w; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
+    p.M = M; p.HW = HW; p.Cout = Cout; p.Cout_pad = Cout; p.nch = nch;
+    if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE>(p, s) : run_g1<128, XF_AFFINE>(p, s);
+    if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE>(p, s) : run_g1<64, XF_AFFINE>(p, s);
+    return HSIDM_E_UNSUPPORTED;
+}
+
+}  // namespace hsidm

@@ -49,21 +49,6 @@ struct ConvV2Params {
     int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };
 
-// parameters of the weight-stationary 1x1 kernel (conv1x1_ws.hip)
-struct C1Params {
-    const bf16* src0;
-    const bf16* src1;
-    int C0, C1;
-    const bf16* w;          // [kstep][Cout_pad/32][kk 4][lane 64][8]  (conv_v2's order with one tap)
-    const float* bias;
-    const bf16* res;
-    float res_scale;
-    bf16* out;
-    float2* stats;          // [B][HW/32][Cout] or null
-    int M, HW, Cout, Cout_pad, ksteps;   // ksteps = K_pad / 64, even
-    int n_slices, m_tiles, blocks_per_slice;
-};
-
 // UP4: nearest-x2 upsample folded into the weights.  Output pixel (2y+py, 2x+px) of conv3x3(nearest_x2(in)) only sees
 // the 2x2 input neighbourhood {y-1+py, y+py} x {x-1+px, x+px}; the host pre-sums the 3x3 taps that fall on the same input
 // pixel into four 2x2 kernels (one per output parity).  A work item is (input tile, parity, cout slice): K = 4*Cin per

@@ -64,7 +64,7 @@ class PackedConv:
         self.w_v2 = None
         if prec == _lib.BF16 and not out_nchw and proj_weight is None:
             wv = self.w_hi
-            if kh == 1 and wv.shape[0] % 2:          # weight-stationary 1x1 kernel: K padded to a multiple of 128
+            if kh == 1 and wv.shape[0] % 2:          # 1x1 GEMM kernel (conv1x1_g.hip): K padded to a multiple of 128
                 wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
             self.w_v2 = self._lanes(wv, cpad)
         # nearest-x2 + conv3x3 as four 2x2 convs on the input grid (include/hsidm.h, HSIDM_UPS_FOLDED): taps that read
@@ -156,7 +156,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         e1.record()
         k_total = pw.cin * (4 if folded else pw.ksize * pw.ksize) + pw.proj_cin      # multiplications actually executed
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
-        label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "conv1x1_ws")[kid & 15], kid >> 8,
+        label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "-", "conv1x1_g")[kid & 15], kid >> 8,
                                             "8x8x2" if (kid >> 4) & 1 else "8x16", pw.ksize, stride,
                                             " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else "") +
                                             (" up4" if folded else (" ups" if ups else "")),

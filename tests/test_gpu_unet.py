@@ -335,18 +335,23 @@ def test_folded_upsample_conv_matches_addressed_upsample(dev, case):
     check("ups_vs_torch%s" % (case,), "bf16", outs[0], ref, tol=1e-2)
 
 
-C1_CASES = [  # B, H, W, C0, C1, Cout, with_res
-    (2, 16, 16, 64, 0, 128, False),       # K=64 padded to 128, BN=64
-    (3, 8, 8, 128, 64, 64, True),         # concat input, K=192 -> 256, residual + statistics (attention out)
-    (2, 16, 8, 256, 256, 512, False),     # K=512: the largest weight-stationary slice
-    (5, 8, 16, 512, 512, 96, True),       # K=1024 stays on the v1 kernel (dispatch check)
+C1_CASES = [  # B, H, W, C0, C1, Cout, with_res, gn_affine
+    (2, 16, 16, 64, 0, 128, False, False),       # K=64 padded to 128, one 128-cout slice
+    (3, 8, 8, 128, 64, 64, True, False),         # concat input, K=192 -> 256, residual + statistics; 192 pixels: half-empty last tile
+    (2, 16, 8, 256, 256, 512, False, False),     # K=512, four cout slices
+    (5, 8, 16, 512, 512, 96, True, False),       # Cout not a multiple of the slice: stays on the v1 kernel (dispatch check)
+    (3, 16, 16, 512, 0, 1536, False, True),      # attention qkv: GroupNorm affine prologue, 12 cout slices
+    (5, 8, 8, 64, 0, 192, False, True),          # two images per 128-pixel tile: per-half GroupNorm parameters; Cout 192 -> v1
+    (7, 8, 8, 128, 0, 256, True, True),          # same with whole slices (448 pixels: half-empty last tile)
+    (2, 32, 32, 72, 40, 128, True, False),       # channel counts that are not multiples of the 64-channel chunk
 ]
 
 
 @pytest.mark.parametrize("case", C1_CASES)
-def test_conv1x1_weight_stationary_matches_v1(dev, case):
+def test_conv1x1_gemm_kernels_match_v1(dev, case):
+    """1x1 convolutions on the LDS-staged GEMM kernel (conv1x1_g) against the generic v1 kernel, statistics included."""
     from hsi_dmgasr_amd import ops
-    B, H, W, C0, C1, Co, with_res = case
+    B, H, W, C0, C1, Co, with_res, affine = case
     g = torch.Generator().manual_seed(sum(case[:6]))
     w = torch.randn(Co, C0 + C1, 1, 1, generator=g) / (C0 + C1) ** 0.5
     pk = ops.PackedConv(w.to(dev), torch.randn(Co, generator=g).to(dev), "bf16")
@@ -354,10 +359,12 @@ def test_conv1x1_weight_stationary_matches_v1(dev, case):
     x0 = torch.randn(B, H, W, C0, generator=g).to(dev, torch.bfloat16)
     x1 = torch.randn(B, H, W, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
     res = torch.randn(B, H, W, Co, generator=g).to(dev, torch.bfloat16) if with_res else None
+    ab = torch.stack([1 + 0.2 * torch.randn(B, C0 + C1, generator=g), 0.3 * torch.randn(B, C0 + C1, generator=g)], 2).contiguous().to(dev)
     outs = []
     for use_v2 in (False, True):
         ops.set_use_v2(use_v2)
-        y = ops.conv2d(x0, pk, x1=x1, res=res, stats=True)
+        y = ops.conv2d(x0, pk, x1=x1, res=res, stats=True, gn_ab=ab if affine else None,
+                       transform=ops.XF_AFFINE if affine else ops.XF_NONE)
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
         yf = y.float()
@@ -366,4 +373,4 @@ def test_conv1x1_weight_stationary_matches_v1(dev, case):
         outs.append(yf.cpu())
     ops.set_use_v2(True)
     # with a residual the vector epilogue rounds the conv result to bf16 before the add (v1 adds in fp32): <= 1 bf16 ulp
-    check("conv1x1_ws_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
+    check("conv1x1_g_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
