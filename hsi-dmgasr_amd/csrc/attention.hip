@@ -13,6 +13,7 @@
 //            a wave-private LDS patch so the key axis becomes the contiguous MFMA k axis.
 // qkv is NHWC [B][N][3C]; q, k, v are the channel thirds (reference unet.py:129, n_head = 1).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/hsidm.h"
 
 namespace hsidm {
@@ -205,11 +206,181 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
     return (int)hipGetLastError();
 }
 
+
+// ---- attention_v2 (bf16 mode, N = 32*NKT keys, C % 64 == 0): the whole row of scores lives in registers ----------------
+// Measured on the kernel above (batch 120, N = 256, C = 512): 155 us per launch = 104 TFLOP/s; K rows loaded as MFMA
+// fragments straight from global (32 rows per wave-load, texture-addresser bound), V transposed with 2-byte LDS writes
+// behind two barriers per 32 keys, and every 32-query workgroup re-reading all of K and V (8x per image).  Here
+//   * a wave owns 32 queries and ALL keys: S^T = K Q^T (keys on the accumulator rows, the query on the lane), so the row
+//     softmax is a per-lane reduction plus one exchange between the two lane halves, exact and in fp32 as before;
+//   * the probabilities never leave the registers: an accumulator tile converted to bf16 is directly the B operand of
+//     O^T = V^T P^T (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"); its k order is permuted
+//     (element j of lane half h = key 16s + 8(j>>2) + 4h + (j&3)), and V^T fragments in exactly that order come from a
+//     row-major V image in LDS through ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group, delivered
+//     channel-major): two reads per fragment, 192-byte key rows -> conflict-free;
+//   * K and V stream through a double-buffered LDS image in 64-channel chunks with row-contiguous 16-byte loads, shared
+//     by the 4 waves (128 queries) of the workgroup: K and V are read twice per image instead of eight times;
+//   * O^T tiles have the query on the lane and 4 consecutive channels per register quad: 8-byte stores, no epilogue pass.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int NKT, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_v2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int C, float scale) {
+    constexpr int N = 32 * NKT, T = 64 * NW, NV = N * 8 / T;
+    constexpr int KRS = 72, VRS = 96;                      // bf16 per key row: 144 B (ds_read_b128 fragments) / 192 B (transposed reads)
+    constexpr int BUFE = N * VRS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* buf = reinterpret_cast<bf16*>(smem_raw);         // [2][BUFE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y, q0 = blockIdx.x * 32 * NW + 32 * wave;
+    const size_t row3 = (size_t)3 * C;
+    const bf16* base = qkv + (size_t)b * N * row3;
+    const int nch = C >> 6;
+
+    u32x4 hreg[NV];
+    auto issue = [&](int chunk, int third) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * T;
+            hreg[i] = *reinterpret_cast<const u32x4*>(base + (size_t)(v >> 3) * row3 + third * C + chunk * 64 + (v & 7) * 8);
+        }
+    };
+    auto commit = [&](int bi, int rs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * T;
+            *reinterpret_cast<u32x4*>(buf + bi * BUFE + (v >> 3) * rs + (v & 7) * 8) = hreg[i];
+        }
+    };
+
+    // ---- phase 1: S^T[key][query] = K Q^T, all NKT key tiles of this wave's 32 queries ----------------------------------
+    const bf16* qrow = base + (size_t)(q0 + lr) * row3 + 8 * lh;
+    bf16x8 qf[4], qn[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+    issue(0, 1);
+    commit(0, KRS);
+    __syncthreads();
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[kt][j] = 0.f;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool more = chunk + 1 < nch;
+        if (more) {
+            issue(chunk + 1, 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) qn[kk] = *reinterpret_cast<const bf16x8*>(qrow + (chunk + 1) * 64 + kk * 16);
+        }
+        const bf16* kb = buf + (chunk & 1) * BUFE + lr * KRS + 8 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * KRS + kk * 16);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], sc[kt], 0, 0, 0);
+            }
+        if (more) {
+            commit((chunk + 1) & 1, KRS);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+        }
+        __syncthreads();
+    }
+
+    // ---- exact softmax over the keys of this lane's query (fp32); V chunk 0 is on its way meanwhile ---------------------
+    issue(0, 2);
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sc[kt][j] *= scale; m = fmaxf(m, sc[kt][j]); }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sc[kt][j] = __expf(sc[kt][j] - m); sum += sc[kt][j]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    bf16x8 pf[NKT][2];                                     // P^T fragments: k-step st of key tile kt = registers 8st .. 8st+7
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kt][st][j] = (bf16)(sc[kt][8 * st + j] * inv);
+    commit(0, VRS);
+    __syncthreads();
+
+    // ---- phase 2: O^T[channel][query] = V^T P^T, 64 channels per chunk ------------------------------------------------------
+    const int gi = lane & 15;
+    const int tr_lane = (4 * lh + (gi >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (gi & 3);   // this lane's address duty in its 16-lane group
+    bf16* orow = out + ((size_t)b * N + q0 + lr) * C + 4 * lh;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool more = chunk + 1 < nch;
+        if (more) issue(chunk + 1, 2);
+        const bf16* vb = buf + (chunk & 1) * BUFE + tr_lane;
+        f32x16 o[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[c2][j] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+                    const bf16* a0 = vb + (kt * 32 + st * 16) * VRS + c2 * 32;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 8 * VRS));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[c2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[kt][st], o[c2], 0, 0, 0);
+                }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int jg = 0; jg < 4; ++jg) {
+                bf16x4 w4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w4[e] = (bf16)o[c2][4 * jg + e];
+                *reinterpret_cast<bf16x4*>(orow + chunk * 64 + c2 * 32 + 8 * jg) = w4;
+            }
+        if (more) commit((chunk + 1) & 1, VRS);
+        __syncthreads();
+    }
+}
+
+template <int NKT, int NW>
+static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 32 * NKT * 96 * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_v2_kernel<NKT, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(NKT / NW, B);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW>), grid, dim3(64 * NW), lds, s, (const bf16*)qkv, (bf16*)out, C,
+                       1.0f / sqrtf((float)C));
+    return (int)hipGetLastError();
+}
+
 }  // namespace hsidm
 
 extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int N, int C, void* stream) {
     if (!qkv || !out || B <= 0 || N <= 0 || C <= 0 || (C & 31)) return HSIDM_E_BADARG;
     if (N > 1024) return HSIDM_E_UNSUPPORTED;
+    if (prec == HSIDM_BF16 && (C & 63) == 0 && !getenv("HSIDM_ATTENTION_V1")) {     // (env: diagnostic A/B switch)
+        if (N == 256) return hsidm::launch_attention_v2<8, 4>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 64) return hsidm::launch_attention_v2<2, 2>(qkv, out, B, C, (hipStream_t)stream);
+    }
     if (prec == HSIDM_BF16) return hsidm::launch_attention<hsidm::bf16, false>(qkv, out, B, N, C, (hipStream_t)stream);
     if (prec == HSIDM_F32X3) return hsidm::launch_attention<float, true>(qkv, out, B, N, C, (hipStream_t)stream);
     return HSIDM_E_BADARG;

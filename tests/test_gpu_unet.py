@@ -249,6 +249,26 @@ def test_sampler_api_shapes_and_philox_mode(dev):
     check("sampler_philox_T12", "fp32", got, xo, tol=2e-3)
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96)])
+def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
+    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (N = 64 / 256, C % 64 == 0), the panel
+    kernel it replaces (other shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same bf16 inputs."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    qkv = (torch.randn(B, H, W, 3 * C, generator=g) * 1.5).to(torch.bfloat16)
+    q, k, v = qkv.float().reshape(B, H * W, 3, C).unbind(2)
+    ref = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
+    got = ops.attention(qkv.to(dev), "bf16")
+    torch.cuda.synchronize()
+    monkeypatch.setenv("HSIDM_ATTENTION_V1", "1")
+    old = ops.attention(qkv.to(dev), "bf16")
+    torch.cuda.synchronize()
+    monkeypatch.delenv("HSIDM_ATTENTION_V1")
+    check("attention%s" % (shape,), "bf16", got.reshape(B, H * W, C), ref, tol=1e-2)
+    check("attention_panel%s" % (shape,), "bf16", old.reshape(B, H * W, C), ref, tol=1e-2)
+
+
 CONV_CASES = [  # B, H, W, C0, C1, Cout, ups, proj_cin, xf
     (3, 16, 32, 64, 0, 128, False, 0, True),      # 8x16 tiles, BN=128, several items per block
     (2, 24, 40, 64, 32, 64, False, 0, True),      # concat input, BN=64, partial tiles
