@@ -6,7 +6,9 @@ OUT="$HERE/../libhsidm.so"
 OBJ="$HERE/obj"
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable ${HSIDM_EXTRA_FLAGS:-}"
+# -fno-slp-vectorize: the SLP pass packs adjacent fp32 mul/add into v_pk_*_f32, which co-issues badly beside MFMAs
+# (measured: the 3x3 convs with Cin >= 256 run 6-8 % faster without it; MI355X_MICROARCH.md, filler price table)
+FLAGS="--offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable ${HSIDM_EXTRA_FLAGS:-}"
 OUT="${HSIDM_OUT:-$OUT}"
 OBJ="${HSIDM_OBJ:-$OBJ}"
 mkdir -p "$OBJ"

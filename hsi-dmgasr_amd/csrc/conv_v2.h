@@ -278,12 +278,13 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = silu_fast(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = live ? v[k] : 0.f;
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
-        *reinterpret_cast<bf16x8*>(halo + buf * C::HALO_ELEMS + hv_lds0 + i * HV_LDS_STEP) = o;
+        u32x4 ou = __builtin_bit_cast(u32x4, o);                // zero padding / dead channels: select on the packed words
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
+        *reinterpret_cast<u32x4*>(halo + buf * C::HALO_ELEMS + hv_lds0 + i * HV_LDS_STEP) = ou;
     };
 
     // ---- MFMA fragment bases --------------------------------------------------------------------------------------
