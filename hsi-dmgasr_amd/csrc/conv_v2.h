@@ -69,7 +69,13 @@ struct V2Cfg {
     static constexpr int NH = UP4 ? MAXHV : 4;                  // raw staging registers (vectors in flight)
     static_assert(MAXHV <= 7, "one staged vector per tap 2..8");
     static_assert(!UP4 || XF_ == 0, "the upsample convs have no GroupNorm prologue");
-    static constexpr int HALO_ELEMS = NI * HPIX * PSTR;
+    // LDS pitch of one halo row (bf16 elements).  A wave's ds_read_b128 A-fragment covers 32 pixels = two tile rows of 16
+    // (or four of 8); with the natural pitch (18 pixels x 144 B = 2592 B) the second row lands 32 B off the 256-byte bank
+    // period and two lanes of every 16-lane service group hit the same banks (measured: SQ_LDS_BANK_CONFLICT = 48 % of
+    // SQ_LDS_IDX_ACTIVE).  A pitch of 0 (TW 16) / 128 (TW 8) bytes modulo 256 makes every group cover all 64 banks once.
+    static constexpr int RP = (TW == 16) ? 1408 : 832;
+    static_assert(RP >= HCOLS * PSTR, "row pitch");
+    static constexpr int HALO_ELEMS = NI * HROWS * RP;
     static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2;
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
@@ -119,7 +125,7 @@ __device__ __forceinline__ float silu_fast(float y) {
 template <typename C>
 __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
-    constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK;
+    constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK, RP = C::RP, HROWS = C::HROWS;
     constexpr int MAXHV = C::MAXHV, NT = C::NT, NH = C::NH;
     constexpr bool UP4 = C::UP4;
 
@@ -183,8 +189,11 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 
     // ---- halo staging state ---------------------------------------------------------------------------------
     const int cv = tid % VPP;
-    const int hv_lds0 = (tid / VPP) * PSTR + cv * 8;           // vector i lives at hv_lds0 + i * (256/VPP) * PSTR
-    constexpr int HV_LDS_STEP = (256 / VPP) * PSTR;
+    auto hv_lds = [&](int i) __attribute__((always_inline)) -> int {   // LDS offset of staged vector i (halo pixel tid/VPP + i*256/VPP)
+        const int hp = tid / VPP + i * (256 / VPP);
+        const int row = hp / HCOLS;                            // (image, halo row) pairs are consecutive rows of the LDS image
+        return row * RP + (hp - row * HCOLS) * PSTR + cv * 8;
+    };
     const bool last_live = tid + (MAXHV - 1) * 256 < C::HVEC;  // the last vector slot is partial
     int hv_pix[MAXHV];                                          // for the tile being STAGED
     auto hv_pos = [&](int i, int t) __attribute__((always_inline)) -> int {   // img<<16 | hy<<8 | hx, or -1 (dead slot); recomputed, not kept
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const bool live = st_cok && hv_pix[i] >= 0;             // zero padding stays zero (pad AFTER activation)
         if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
             if (NI > 1) {
-                const int img = ((hv_lds0 + i * HV_LDS_STEP) / PSTR) / HPIX;
+                const int img = (tid / VPP + i * (256 / VPP)) / HPIX;
                 const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
                 const f32x4* ab = p.gn_ab + (((size_t)bb * ctot + st_c) >> 1);
 #pragma unroll
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         u32x4 ou = __builtin_bit_cast(u32x4, o);                // zero padding / dead channels: select on the packed words
 #pragma unroll
         for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
-        *reinterpret_cast<u32x4*>(halo + buf * C::HALO_ELEMS + hv_lds0 + i * HV_LDS_STEP) = ou;
+        *reinterpret_cast<u32x4*>(halo + buf * C::HALO_ELEMS + hv_lds(i)) = ou;
     };
 
     // ---- MFMA fragment bases --------------------------------------------------------------------------------------
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const int img = pm / (TH * TW);
         const int q = pm - img * (TH * TW);
         const int ty = q / TW, tx = q - ty * TW;
-        abase[mr] = (img * HPIX + ty * HCOLS + tx) * PSTR + 8 * lh;
+        abase[mr] = (img * HROWS + ty) * RP + tx * PSTR + 8 * lh;
     }
     f32x16 acc[MR];
 
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         int par = 0;
         const int it_tile = item_tile(item, par);
         const int py = par >> 1, px = par & 1;
-        const int par_off = UP4 ? (py * HCOLS + px) * PSTR : 0;       // this parity's 2x2 window inside the 3x3 halo
+        const int par_off = UP4 ? py * RP + px * PSTR : 0;            // this parity's 2x2 window inside the 3x3 halo
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bf16* hb = halo + cur * C::HALO_ELEMS + par_off;
             // A fragments: 3-deep register ring over the 4*NT (tap, k-slice) sub-steps of the chunk, fetched two
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             bf16x8 a[3][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
-                const int off = (UP4 ? ((tp >> 1) * HCOLS + (tp & 1)) : ((tp / 3) * HCOLS + (tp % 3))) * PSTR + kq * 16;
+                const int off = (UP4 ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + kq * 16;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + off);
             };
