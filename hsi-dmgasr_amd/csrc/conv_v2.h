@@ -263,37 +263,49 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
         hreg[i % NH] = *reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
     };
-    auto halo_commit_one = [&](int i, int buf) __attribute__((always_inline)) {
-        if (i == MAXHV - 1 && !last_live) return;
-        float v[8];
+    // dead slot of the last (partial) vector round: the store goes to the row padding instead of being branched around,
+    // so that the commit stays in the MFMAs' basic block and the scheduler can interleave the two
+    const int dead_off = (tid % (NI * HROWS)) * RP + HCOLS * PSTR + ((tid >> 4) % ((RP - HCOLS * PSTR) / 8)) * 8;
+    // The commit of one staged vector is cut into four slices (two elements each) that ride in the four k-slices of a tap,
+    // so that every scheduling region holds 4 MFMAs and ~1/4 of the transform instead of 16 MFMAs followed by a block of
+    // 70 VALU instructions (a single wave then overlaps the two; measured with one workgroup per CU).
+    float cm_v[8];
+    auto halo_commit_part = [&](int i, int buf, int part) __attribute__((always_inline)) {
+        if (part == 0 && C::XF != XF_NONE && NI > 1 && !(HSIDM_ABL(2))) {
+            const int img = (tid / VPP + i * (256 / VPP)) / HPIX;
+            const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
+            const f32x4* ab = p.gn_ab + (((size_t)bb * ctot + st_c) >> 1);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[2 * k] = __uint_as_float(hreg[i % NH][k] << 16);
-            v[2 * k + 1] = __uint_as_float(hreg[i % NH][k] & 0xffff0000u);
-        }
-        const bool live = st_cok && hv_pix[i] >= 0;             // zero padding stays zero (pad AFTER activation)
-        if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
-            if (NI > 1) {
-                const int img = (tid / VPP + i * (256 / VPP)) / HPIX;
-                const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
-                const f32x4* ab = p.gn_ab + (((size_t)bb * ctot + st_c) >> 1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t = ab[q];
-                    abh[2 * q] = pack_h2(t[0], t[1]);
-                    abh[2 * q + 1] = pack_h2(t[2], t[3]);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = ab[q];
+                abh[2 * q] = pack_h2(t[0], t[1]);
+                abh[2 * q + 1] = pack_h2(t[2], t[3]);
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = silu_fast(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
         }
-        bf16x8 o;
+        {
+            const unsigned w = hreg[i % NH][part];
+            cm_v[2 * part] = __uint_as_float(w << 16);
+            cm_v[2 * part + 1] = __uint_as_float(w & 0xffff0000u);
+            if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
-        u32x4 ou = __builtin_bit_cast(u32x4, o);                // zero padding / dead channels: select on the packed words
+                for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_fast(fmaf(cm_v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+            }
+        }
+        if (part == 3) {
+            const bool live = st_cok && hv_pix[i] >= 0;         // zero padding stays zero (pad AFTER activation)
+            bf16x8 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
-        *reinterpret_cast<u32x4*>(halo + buf * C::HALO_ELEMS + hv_lds(i)) = ou;
+            for (int k = 0; k < 8; ++k) o[k] = (bf16)cm_v[k];
+            u32x4 ou = __builtin_bit_cast(u32x4, o);            // zero padding / dead channels: select on the packed words
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
+            const int off = (i == MAXHV - 1 && !last_live) ? dead_off : hv_lds(i);
+            *reinterpret_cast<u32x4*>(halo + buf * C::HALO_ELEMS + off) = ou;
+        }
+    };
+    auto halo_commit_one = [&](int i, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) halo_commit_part(i, buf, part);
     };
 
     // ---- MFMA fragment bases --------------------------------------------------------------------------------------
@@ -389,39 +401,44 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) {
                 if (!UP4) b_issue(ring[(tap + 2) % 3]);        // weights two K steps ahead
-                if (st_valid) {                                // staging of the next chunk, one vector per tap
-                    if (tap == 0) {
-                        if (st_chunk == 0) describe(st_item);
-                        halo_begin(st_chunk);
-                    }
-                    if (!UP4) {
-                        if (tap < MAXHV) halo_issue_one(tap);
-                    } else if (tap < 2) {                      // 4 taps per chunk: vectors 0-3 at tap 0, the rest at tap 1
+                if (st_valid && tap == 0) {                    // staging of the next chunk, one vector per tap
+                    if (st_chunk == 0) describe(st_item);
+                    halo_begin(st_chunk);
+                }
+                // Issue and commit are unconditional (past the last item they move stale but valid data into the unused
+                // buffer): no branch separates them from the MFMAs, and the group barriers below ask the scheduler for
+                // "1 MFMA, a few VALU, 1 LDS read" slices instead of 4 MFMAs back to back followed by a block of VALU.
+                if (!UP4) {
+                    if (tap < MAXHV) halo_issue_one(tap);
+                } else if (tap < 2) {                          // 4 taps per chunk: vectors 0-3 at tap 0, the rest at tap 1
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (tap * 4 + i < MAXHV) halo_issue_one(tap * 4 + i);
-                    }
+                    for (int i = 0; i < 4; ++i)
+                        if (tap * 4 + i < MAXHV) halo_issue_one(tap * 4 + i);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = tap * 4 + kk;
                     if (u + 2 < 4 * NT) a_fetch(u + 2);
                     if (UP4) f_issue(fring[(u + 6) % 8], (u + 6) % 4);   // weights six fragments ahead
+                    if (!(HSIDM_ABL(16))) {
+                        if (!UP4) {                            // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, k-slices 2-3)
+                            if (tap >= 3 && tap - 3 < MAXHV) halo_commit_part(tap - 3, cur ^ 1, kk);
+                        } else if (tap >= 2 && (tap - 2) * 4 + kk < MAXHV) {   // one whole vector per k-slice, two taps after its issue
+                            halo_commit_one((tap - 2) * 4 + kk, cur ^ 1);
+                        }
+                    }
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
                         acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], UP4 ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // 1 LDS read (A fragment, two sub-steps ahead)
+                        __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 6 : 2, 0);   // a slice of the staging VALU
+                    }
                     __builtin_amdgcn_sched_barrier(0);         // keep the two-sub-step LDS lookahead the source expresses
                 }
-                if (st_valid && !(HSIDM_ABL(16))) {
-                    if (!UP4) {
-                        if (tap >= 3 && tap - 3 < MAXHV) halo_commit_one(tap - 3, cur ^ 1);
-                        if (tap == 8 && MAXHV == 7) halo_commit_one(6, cur ^ 1);
-                    } else if (tap >= 2) {                     // committed two taps after their issue
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if ((tap - 2) * 4 + i < MAXHV) halo_commit_one((tap - 2) * 4 + i, cur ^ 1);
-                    }
-                }
+                if (!UP4 && tap == 8 && MAXHV == 7 && !(HSIDM_ABL(16))) halo_commit_one(6, cur ^ 1);
             }
             HSIDM_STAMP(it, 10);                               // (last chunk's) MFMAs + commits issued
             lds_barrier();                                     // next halo tile complete; this one free for re-use

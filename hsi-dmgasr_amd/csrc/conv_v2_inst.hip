@@ -22,7 +22,8 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        g_slots = 2 * cus;
+        const char* e = getenv("HSIDM_V2_WGS_PER_CU");       // diagnostic: 1 = one workgroup per CU (overlap experiments)
+        g_slots = ((e && e[0] == '1') ? 1 : 2) * cus;
     }
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("HSIDM_V2_ABL"); abl = e ? atoi(e) : 0; }
