@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerates the measurement artefacts of profiles/ on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh TAG      -> gpurun_out/TAG/{bench.json,kernel_stats.csv,fetch.csv,write.csv,hbm_traffic.json}
+tag=${1:-final}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/$tag
+mkdir -p $out
+python bench.py > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/stats.log 2>&1
+cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  HSIDM_NO_GRAPH=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $out/pmc_$c.log 2>&1
+done
+cp $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $out/fetch.csv
+cp $(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $out/write.csv
+python tools/hbm_traffic.py $out/fetch.csv $out/write.csv > $out/hbm_traffic.json 2> $out/hbm.err
+rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+cat $out/bench.json | cut -c1-600
+head -30 $out/kernel_stats.csv | cut -c1-150
