@@ -79,6 +79,11 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || xf != HSIDM_XF_NONE ||
             d->bn != 128) return HSIDM_E_UNSUPPORTED;
     }
+    // stride 2 with w_v2: the four input-parity planes on the conv_v2 schedule (w_v2 = [plane][chunk][2x2 taps] layout)
+    if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 2) {
+        if (d->ksize != 3 || xf != HSIDM_XF_NONE || (d->bn != 64 && d->bn != 128) || (d->Hin & 1) || (d->Win & 1)) return HSIDM_E_UNSUPPORTED;
+        path = PATH_V2;
+    }
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
         // LDS-staged GEMM (conv1x1_g.hip): whole cout slices, 64-pixel statistics groups
@@ -167,8 +172,10 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.out = reinterpret_cast<bf16*>(d->out); v.stats = reinterpret_cast<float2*>(d->stats);
         v.B = d->B; v.Hin = d->Hin; v.Win = d->Win; v.Hout = Hout; v.Wout = Wout; v.Cout = d->Cout; v.Cout_pad = cout_pad;
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
-        v.steps_per_item = up4 ? p.ph[0].nchunks * 4 : steps;
-        return conv_v2_run(tile_kind, d->bn, up4 ? -1 : d->ph[0].transform, v, s);
+        const bool dn4 = d->stride == 2;
+        if (dn4) v.nchunks = 4 * p.ph[0].nchunks;
+        v.steps_per_item = dn4 ? v.nchunks * 4 : (up4 ? p.ph[0].nchunks * 4 : steps);
+        return conv_v2_run(tile_kind, d->bn, dn4 ? -2 : (up4 ? -1 : d->ph[0].transform), v, s);
     }
     p.w_hi = reinterpret_cast<const bf16*>(d->w_hi);
     p.w_lo = reinterpret_cast<const bf16*>(d->w_lo);

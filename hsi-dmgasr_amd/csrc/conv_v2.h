@@ -54,11 +54,18 @@ struct ConvV2Params {
 // pixel into four 2x2 kernels (one per output parity).  A work item is (input tile, parity, cout slice): K = 4*Cin per
 // output pixel instead of 9*Cin, and the halo tile is the plain input tile (each input pixel staged once per parity
 // instead of ~3.3 times per output tile).
-template <int BN_, int TH_, int TW_, int NI_, int XF_, int UP4_ = 0>
+//
+// DN4 (SP_ = 2): the stride-2 conv on the same 2x2-window schedule.  Output (y, x) reads input rows 2y-1, 2y, 2y+1: the odd
+// rows 2(y-1)+1 and 2y+1 are rows y-1 and y of the odd-row plane, the even row is row y of the even-row plane (same for
+// columns).  The K loop walks the four (row parity, column parity) planes of the input; a staged halo pixel (iy, ix) of
+// plane (ry, rx) is in[2*iy + ry][2*ix + rx] and every plane contributes the window {iy-1, iy} x {ix-1, ix} with zero
+// weights where the plane has no tap (16/9 of the minimal MFMAs, on convs that are 1 % of the step's FLOPs).
+template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0>
 struct V2Cfg {
     static constexpr int BN = BN_, TH = TH_, TW = TW_, NI = NI_, XF = XF_;
-    static constexpr bool UP4 = UP4_ != 0;
-    static constexpr int NT = UP4 ? 4 : 9;                      // taps per channel chunk
+    static constexpr bool UP4 = SP_ == 1, DN4 = SP_ == 2;
+    static constexpr bool FR = SP_ != 0;                        // 4-tap chunks, fragment-granular weight ring
+    static constexpr int NT = FR ? 4 : 9;                       // taps per channel chunk
     static constexpr int BM = 128, BK = 64;
     static_assert(TH * TW * NI == BM, "tile");
     static constexpr int WN = BN / 32, WM = 4 / WN, MR = BM / WM / 32;
@@ -66,9 +73,9 @@ struct V2Cfg {
     static constexpr int PSTR = BK + 8, VPP = BK / 8;
     static constexpr int HVEC = NI * HPIX * VPP;
     static constexpr int MAXHV = (HVEC + 255) / 256;
-    static constexpr int NH = UP4 ? MAXHV : 4;                  // raw staging registers (vectors in flight)
+    static constexpr int NH = FR ? MAXHV : 4;                   // raw staging registers (vectors in flight)
     static_assert(MAXHV <= 7, "one staged vector per tap 2..8");
-    static_assert(!UP4 || XF_ == 0, "the upsample convs have no GroupNorm prologue");
+    static_assert(!FR || XF_ == 0, "the up/downsample convs have no GroupNorm prologue");
     // LDS pitch of one halo row (bf16 elements).  A wave's ds_read_b128 A-fragment covers 32 pixels = two tile rows of 16
     // (or four of 8); with the natural pitch (18 pixels x 144 B = 2592 B) the second row lands 32 B off the 256-byte bank
     // period and two lanes of every 16-lane service group hit the same banks (measured: SQ_LDS_BANK_CONFLICT = 48 % of
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
     constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK, RP = C::RP, HROWS = C::HROWS;
     constexpr int MAXHV = C::MAXHV, NT = C::NT, NH = C::NH;
-    constexpr bool UP4 = C::UP4;
+    constexpr bool UP4 = C::UP4, DN4 = C::DN4, FR = C::FR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* halo = reinterpret_cast<bf16*>(smem_raw);          // [2][HALO_ELEMS]
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     };
     // UP4: 16 fragments per chunk do not keep a 3-step ring in phase (4 taps), so the ring holds single fragments:
     // 8 slots, fetched six sub-steps (24 MFMAs) ahead
-    bf16x8 fring[UP4 ? 8 : 1];
+    bf16x8 fring[FR ? 8 : 1];
     auto f_issue = [&](bf16x8& dst, int kk) __attribute__((always_inline)) {
         if (!(HSIDM_ABL(8))) dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(w_base + wnext) * wstep_stride + kk * 64 * 8);
         if (kk == 3) {
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         int b0, oy0, ox0;
         tile_coords(it, b0, oy0, ox0);
         st_b0 = b0;
-        const bool up = !UP4 && p.ups;
-        const int hlim = up ? 2 * p.Hin : p.Hin, wlim = up ? 2 * p.Win : p.Win;
+        const bool up = !FR && p.ups;
+        const int hlim = DN4 ? p.Hout : (up ? 2 * p.Hin : p.Hin), wlim = DN4 ? p.Wout : (up ? 2 * p.Win : p.Win);
         const int sh = up ? 1 : 0;
         int t_op = tid;
         asm volatile("" : "+v"(t_op));      // recompute the halo positions here: hoisted out of the item loop they were spilled, and
@@ -229,20 +236,26 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             const int b = b0 + (pos >> 16);
             const int iy = oy0 + ((pos >> 8) & 255) - 1, ix = ox0 + (pos & 255) - 1;
             const bool ok = pos >= 0 && b < p.B && iy >= 0 && ix >= 0 && iy < hlim && ix < wlim;
-            hv_pix[i] = ok ? (b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh) : -1;
+            hv_pix[i] = !ok ? -1 : (DN4 ? (b * p.Hin + 2 * iy) * p.Win + 2 * ix : (b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh));
         }
     };
     u32x4 hreg[NH];                // staged raw vectors: vector i lives in slot i % NH from its issue tap to its commit tap
     unsigned abh[8];               // (scale, shift) of this thread's 8 channels, packed fp16x2: 11-bit significands, the
                                    // transformed value is rounded to bf16 (8 bits) anyway; halves the registers held across taps
     bool st_cok = true;
-    int st_c = 0, st_cs = 0, st_cl = 0;
+    int st_c = 0, st_cs = 0, st_cl = 0, st_plane = 0;
     const bf16* st_src = p.src0;
     auto halo_begin = [&](int chunk) __attribute__((always_inline)) {
         // channel slice of the chunk being staged (+ its GroupNorm parameters).  Loads are UNCONDITIONAL (clamped
         // addresses): a predicated load would be merged with its zero alternative right away and that use would
         // wait for the load, draining the weight ring; out-of-range data is zeroed at commit time instead.
-        const int c = chunk * BK + cv * 8;
+        int c = chunk * BK + cv * 8;
+        if (DN4) {                                              // chunk = (input plane, channel chunk)
+            const int nch_c = p.nchunks >> 2;
+            const int plane = chunk / nch_c;
+            c = (chunk - plane * nch_c) * BK + cv * 8;
+            st_plane = (plane >> 1) * p.Win + (plane & 1);
+        }
         st_cok = c < ctot;
         const int cc = st_cok ? c : 0;
         if (cc < p.C0) { st_src = p.src0; st_cs = p.C0; st_cl = cc; }
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     };
     auto halo_issue_one = [&](int i) __attribute__((always_inline)) {
         if (HSIDM_ABL(4)) return;
-        const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
+        const int pix = hv_pix[i] >= 0 ? hv_pix[i] + (DN4 ? st_plane : 0) : 0;
         hreg[i % NH] = *reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
     };
     // dead slot of the last (partial) vector round: the store goes to the row padding instead of being branched around,
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     };
 
     // prologue: first two weight steps, first halo tile (synchronously)
-    if (!UP4) {
+    if (!FR) {
         b_issue(ring[0]);
         b_issue(ring[1]);
     } else {
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             bf16x8 a[3][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
-                const int off = (UP4 ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + kq * 16;
+                const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + kq * 16;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + off);
             };
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             a_fetch(1);
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) {
-                if (!UP4) b_issue(ring[(tap + 2) % 3]);        // weights two K steps ahead
+                if (!FR) b_issue(ring[(tap + 2) % 3]);         // weights two K steps ahead
                 if (st_valid && tap == 0) {                    // staging of the next chunk, one vector per tap
                     if (st_chunk == 0) describe(st_item);
                     halo_begin(st_chunk);
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 // Issue and commit are unconditional (past the last item they move stale but valid data into the unused
                 // buffer): no branch separates them from the MFMAs, and the group barriers below ask the scheduler for
                 // "1 MFMA, a few VALU, 1 LDS read" slices instead of 4 MFMAs back to back followed by a block of VALU.
-                if (!UP4) {
+                if (!FR) {
                     if (tap < MAXHV) halo_issue_one(tap);
                 } else if (tap < 2) {                          // 4 taps per chunk: vectors 0-3 at tap 0, the rest at tap 1
 #pragma unroll
@@ -419,9 +432,9 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = tap * 4 + kk;
                     if (u + 2 < 4 * NT) a_fetch(u + 2);
-                    if (UP4) f_issue(fring[(u + 6) % 8], (u + 6) % 4);   // weights six fragments ahead
+                    if (FR) f_issue(fring[(u + 6) % 8], (u + 6) % 4);    // weights six fragments ahead
                     if (!(HSIDM_ABL(16))) {
-                        if (!UP4) {                            // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, k-slices 2-3)
+                        if (!FR) {                             // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, k-slices 2-3)
                             if (tap >= 3 && tap - 3 < MAXHV) halo_commit_part(tap - 3, cur ^ 1, kk);
                         } else if (tap >= 2 && (tap - 2) * 4 + kk < MAXHV) {   // one whole vector per k-slice, two taps after its issue
                             halo_commit_one((tap - 2) * 4 + kk, cur ^ 1);
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     }
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], UP4 ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], FR ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);         // keep the two-sub-step LDS lookahead the source expresses
                 }
-                if (!UP4 && tap == 8 && MAXHV == 7 && !(HSIDM_ABL(16))) halo_commit_one(6, cur ^ 1);
+                if (!FR && tap == 8 && MAXHV == 7 && !(HSIDM_ABL(16))) halo_commit_one(6, cur ^ 1);
             }
             HSIDM_STAMP(it, 10);                               // (last chunk's) MFMAs + commits issued
             lds_barrier();                                     // next halo tile complete; this one free for re-use

@@ -54,6 +54,11 @@ int conv_v2_subs(int tile_kind, int bn) {
 #define V2(BN, TH, TW, NI, XF) run_v2<V2Cfg<BN, TH, TW, NI, XF>>(p, s)
 
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s) {
+    if (xf == -2) {          // stride 2 over the four input-parity planes (weights: [plane][chunk][2x2 taps])
+        if (bn == 128) return tile_kind == 0 ? run_v2<V2Cfg<128, 8, 16, 1, XF_NONE, 2>>(p, s) : run_v2<V2Cfg<128, 8, 8, 2, XF_NONE, 2>>(p, s);
+        if (bn == 64) return tile_kind == 0 ? run_v2<V2Cfg<64, 8, 16, 1, XF_NONE, 2>>(p, s) : run_v2<V2Cfg<64, 8, 8, 2, XF_NONE, 2>>(p, s);
+        return -2;
+    }
     if (xf == -1) {          // parity-folded nearest-x2 (weights: 4 parities x [chunk][2x2 taps])
         if (bn != 128) return -2;
         return tile_kind == 0 ? run_v2<V2Cfg<128, 8, 16, 1, XF_NONE, 1>>(p, s) : run_v2<V2Cfg<128, 8, 8, 2, XF_NONE, 1>>(p, s);

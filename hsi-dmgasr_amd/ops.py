@@ -31,7 +31,7 @@ class PackedConv:
     the optional fused 1x1 projection (ResnetBlock.res_conv, reference unet.py:102-103).
     """
 
-    def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False, fold_ups=False):
+    def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False, fold_ups=False, fold_dn=False):
         prec = _lib.prec_id(precision)
         bk = 64 if prec == _lib.BF16 else 32
         dev = weight.device
@@ -80,6 +80,23 @@ class PackedConv:
                                                   for tx in (0, 1)], dim=-1) for ty in (0, 1)], dim=-2)
                     pars.append(self._steps(f, cpad, bk))
             self.w_up4 = self._lanes(torch.cat(pars, dim=0).to(torch.bfloat16).contiguous(), cpad)
+
+        # stride-2 conv over the four input-parity planes (include/hsidm.h, hsidm_conv_desc.stride)
+        self.w_dn4 = None
+        if fold_dn and self.w_v2 is not None and kh == 3 and self.bn in (64, 128):
+            w = weight.detach().float()
+            tapmap = {0: (None, 1), 1: (0, 2)}                      # plane parity -> 3x3 tap behind each of the two window taps
+            planes = []
+            for ry in (0, 1):
+                for rx in (0, 1):
+                    f = torch.zeros(cout, cin, 2, 2, dtype=torch.float32, device=w.device)
+                    for ty in (0, 1):
+                        for tx in (0, 1):
+                            dy, dx = tapmap[ry][ty], tapmap[rx][tx]
+                            if dy is not None and dx is not None:
+                                f[:, :, ty, tx] = w[:, :, dy, dx]
+                    planes.append(self._steps(f, cpad, bk))
+            self.w_dn4 = self._lanes(torch.cat(planes, dim=0).to(torch.bfloat16).contiguous(), cpad)
 
     @staticmethod
     def _lanes(w_steps, cpad):
@@ -133,6 +150,9 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     folded = bool(ups) and _use_v2 and _fold_ups and pw.w_up4 is not None
     if folded:
         d.w_v2 = _lib.ptr(pw.w_up4)
+    planes = stride == 2 and _use_v2 and _fold_ups and pw.w_dn4 is not None and H % 2 == 0 and W % 2 == 0
+    if stride == 2:
+        d.w_v2 = _lib.ptr(pw.w_dn4) if planes else None
     if film is not None:          # a column slice of the [B, F] FiLM table
         assert film.stride(1) == 1 and film.shape == (B, pw.cout)
         d.film, d.film_stride = film.data_ptr(), film.stride(0)
@@ -154,12 +174,12 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         e0.record()
         _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
         e1.record()
-        k_total = pw.cin * (4 if folded else pw.ksize * pw.ksize) + pw.proj_cin      # multiplications actually executed
+        k_total = pw.cin * (4 if folded else (16 if planes else pw.ksize * pw.ksize)) + pw.proj_cin      # multiplications actually executed
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
         label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "-", "conv1x1_g")[kid & 15], kid >> 8,
                                             "8x8x2" if (kid >> 4) & 1 else "8x16", pw.ksize, stride,
                                             " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else "") +
-                                            (" up4" if folded else (" ups" if ups else "")),
+                                            (" up4" if folded else (" ups" if ups else (" dn4" if planes else ""))),
                                             " nchw" if pw.out_nchw else "")
         _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize, kernel=label,
                                 bytes=(B * H * W * (C0 + C1) + B * Ho * Wo * pw.cout) * x0.element_size() + pw.w_hi.numel() * 2,

@@ -132,7 +132,7 @@ class Downsample(_HipModule):
 
     def _packed(self, precision):
         return self._cache.get(precision, [self.conv.weight, self.conv.bias],
-                               lambda: ops.PackedConv(self.conv.weight, self.conv.bias, precision))
+                               lambda: ops.PackedConv(self.conv.weight, self.conv.bias, precision, fold_dn=True))
 
     def _run(self, x, precision):
         return ops.conv2d(x, self._packed(precision), stride=2, stats=True)

@@ -71,7 +71,12 @@ typedef struct hsidm_conv_phase {
  *   [parity 2*py+px][chunk][tap 2*ty+tx][Cout_pad/32][4][64][8],
  *   W_par[ty][tx] = sum of the 3x3 taps (dy, dx) with (py+dy-1)>>1 == py+ty-1 and (px+dx-1)>>1 == px+tx-1,
  * because output pixel (2y+py, 2x+px) of conv3x3(nearest_x2(in)) only sees in[y-1+py+ty][x-1+px+tx]: 4/9 of the
- * multiplications of HSIDM_UPS_ADDRESS.  Statistics entries: one per (input tile, parity, wave row). */
+ * multiplications of HSIDM_UPS_ADDRESS.  Statistics entries: one per (input tile, parity, wave row).
+ *
+ * stride = 2 with w_v2 != NULL (HSIDM_BF16, bn 64|128, even Hin/Win, no input transform): w_v2 holds
+ *   [plane 2*ry+rx][chunk][tap 2*ty+tx][Cout_pad/32][4][64][8], plane (ry, rx) = in[2i+ry][2j+rx],
+ *   W_plane[ty][tx] = W[dy][dx] with dy = 2*ty if ry else (ty == 1 ? 1 : none), dx likewise (absent taps are zero);
+ * without w_v2 the stride is folded into the addressing of the generic kernel. */
 #define HSIDM_UPS_ADDRESS 1
 #define HSIDM_UPS_FOLDED  2
 typedef struct hsidm_conv_desc {

@@ -355,6 +355,45 @@ def test_folded_upsample_conv_matches_addressed_upsample(dev, case):
     check("ups_vs_torch%s" % (case,), "bf16", outs[0], ref, tol=1e-2)
 
 
+DN4_CASES = [  # B, H, W, Cin, Cout  (input grid, even)
+    (4, 32, 32, 64, 64),       # 64-cout slices, 8x16 output tiles
+    (3, 16, 16, 128, 128),     # 8x8 output map: two-image tiles
+    (2, 24, 40, 72, 100),      # partial tiles, channel counts off the chunk / slice grid
+    (5, 16, 32, 256, 256),     # two cout slices, four channel chunks per plane
+]
+
+
+@pytest.mark.parametrize("case", DN4_CASES)
+def test_stride2_conv_over_parity_planes_matches_v1_and_torch(dev, case):
+    """Downsample conv (3x3, stride 2, pad 1) on the conv_v2 schedule over the four input-parity planes against the generic
+    kernel and torch fp32; statistics slab against sums of the stored output."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pk = ops.PackedConv(w.to(dev), bias.to(dev), "bf16", fold_dn=True)
+    assert pk.w_dn4 is not None and pk.w_dn4.shape[0] == 16 * ((Ci + 63) // 64)
+    x = torch.randn(B, H, W, Ci, generator=g).to(torch.bfloat16)
+    outs = []
+    for use_v2 in (False, True):
+        ops.set_use_v2(use_v2)
+        try:
+            y = ops.conv2d(x.to(dev), pk, stride=2, stats=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_use_v2(True)
+        slab, nsplit = y._hsidm_stats
+        yf = y.float()
+        assert y.shape == (B, H // 2, W // 2, Co)
+        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
+        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), use_v2
+        outs.append(yf.cpu())
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, bias, stride=2, padding=1).permute(0, 2, 3, 1)
+    check("dn4_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
+    check("dn4_vs_torch%s" % (case,), "bf16", outs[1], ref, tol=1e-2)
+
+
 C1_CASES = [  # B, H, W, C0, C1, Cout, with_res, gn_affine
     (2, 16, 16, 64, 0, 128, False, False),       # K=64 padded to 128, one 128-cout slice
     (3, 8, 8, 128, 64, 64, True, False),         # concat input, K=192 -> 256, residual + statistics; 192 pixels: half-empty last tile

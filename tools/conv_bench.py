@@ -30,6 +30,9 @@ SHAPES = [  # name, H, C0, C1, Cout, ksize, stride, ups, proj_cin
     ("up_512_to32", 16, 512, 0, 512, 3, 1, 1, 0),
     ("up_512_to16", 8, 512, 0, 512, 3, 1, 1, 0),
     ("down_128_64", 128, 64, 0, 64, 3, 2, 0, 0),
+    ("down_64_128", 64, 128, 0, 128, 3, 2, 0, 0),
+    ("down_32_256", 32, 256, 0, 256, 3, 2, 0, 0),
+    ("down_16_512", 16, 512, 0, 512, 3, 2, 0, 0),
     ("qkv_16_512", 16, 512, 0, 1536, 1, 1, 0, 0),
     ("stem_128_8_64", 128, 8, 0, 64, 3, 1, 0, 0),
     ("proj128_192_64", 128, 128, 64, 64, 1, 1, 0, 0),
@@ -63,7 +66,7 @@ def main():
         w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
         pwt = torch.randn(Co, pj, 1, 1, generator=g) / pj ** 0.5 if pj else None
         pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), prec, proj_weight=None if pwt is None else pwt.to(dev),
-                            proj_bias=None if pwt is None else torch.zeros(Co, device=dev), fold_ups=bool(up) and not args.no_fold)
+                            proj_bias=None if pwt is None else torch.zeros(Co, device=dev), fold_ups=bool(up) and not args.no_fold, fold_dn=(st == 2) and not args.no_fold)
         x0 = torch.randn(B, H, H, C0, generator=g).to(dev, dt)
         x1 = torch.randn(B, H, H, C1, generator=g).to(dev, dt) if C1 else None
         px = torch.randn(B, H, H, pj, generator=g).to(dev, dt) if pj else None
