@@ -19,7 +19,7 @@ int conv_v2_subs(int tile_kind, int bn);
 void conv_v2_set_stamps(unsigned long long* p);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
-                  int nch, hipStream_t s);
+                  int nch, int im_H, int im_W, hipStream_t s);
 }  // namespace hsidm
 
 using namespace hsidm;
@@ -86,6 +86,15 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     }
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
+        // 8 input channels (one 16-byte vector per pixel): w_v2 is the tap-major GEMM layout (include/hsidm.h), which only
+        // the GEMM kernel reads
+        if (d->ksize == 3 && d->ph[0].C0 + d->ph[0].C1 == 8) {
+            const bool g1 = !d->ups && xf == HSIDM_XF_NONE && d->act == HSIDM_ACT_NONE && !d->film && d->ph[0].C1 == 0 &&
+                            (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 &&
+                            (Wout & (Wout - 1)) == 0 && Hout * Wout >= 128;
+            if (!g1) return HSIDM_E_UNSUPPORTED;
+            path = PATH_G1;
+        }
         // LDS-staged GEMM (conv1x1_g.hip): whole cout slices, 64-pixel statistics groups
         if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
@@ -158,7 +167,8 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         return conv1x1_g_run(d->bn, s0.transform, reinterpret_cast<const bf16*>(s0.src0), reinterpret_cast<const bf16*>(s0.C1 > 0 ? s0.src1 : nullptr),
                              s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), d->bias, reinterpret_cast<const bf16*>(d->res),
                              d->res_scale, reinterpret_cast<bf16*>(d->out), reinterpret_cast<float2*>(d->stats), d->B * Hout * Wout,
-                             Hout * Wout, d->Cout, (s0.C0 + s0.C1 + 127) / 128 * 2, s);
+                             Hout * Wout, d->Cout, d->ksize == 3 ? 2 : (s0.C0 + s0.C1 + 127) / 128 * 2, d->ksize == 3 ? Hout : 0,
+                             d->ksize == 3 ? Wout : 0, s);
     }
     if (use_v2) {
         ConvV2Params v;

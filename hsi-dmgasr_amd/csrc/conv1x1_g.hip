@@ -15,6 +15,12 @@
 //   * optional GroupNorm affine on the input (attention qkv: norm without SiLU) in the commit step;
 //   * epilogue as in conv_v2: bias, LDS transposition, 16-byte stores, residual, statistics per 64-pixel group.
 // K is padded to a multiple of 128 with zero weights (two chunks per loop trip keep every register index static).
+//
+// IM (im2col-8): the same GEMM for a 3x3 stride-1 convolution whose input has exactly 8 channels (the UNet stem conv,
+// reference unet.py:177-178: 6 -> 64, padded to 8).  On conv_v2 those 8 channels occupy a 64-channel chunk (36 k-slices of
+// which 31.5 multiply zeros: 234 us at batch 120 for a layer whose HBM floor is 45 us).  Here the K axis is tap-major,
+// k = 8*tap + c: staged vector (pixel, tap) is the 16-byte pixel in[y+dy][x+dx][0..7] (zero outside the image), so the
+// layer is a K = 72 -> 128 GEMM: 2 chunks, 8 k-slices.
 #include "conv_v2.h"
 #include "../../include/hsidm.h"
 
@@ -32,10 +38,11 @@ struct C1gParams {
     bf16* out;
     float2* stats;          // [B][HW/64][Cout] or null
     int M, HW, Cout, Cout_pad, nch;     // nch = K_pad / 64, even
+    int im_H, im_W;                     // IM kernels: image size (HW = im_H * im_W)
     int n_slices, m_tiles, total_items;
 };
 
-template <int BN, int XF>
+template <int BN, int XF, int IM = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MR = 128 / WM / 32;
     constexpr int PSTR = 72, TILE = 128 * PSTR;
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     const int hv0 = px_l * PSTR + cv * 8;
     u32x4 hreg[2][4];
     int set_m0[2] = {0, 0}, set_cc[2] = {0, 0};
+    unsigned set_zero[2] = {0u, 0u};                           // IM: bit i = staged vector i lies outside the image
     bool set_ok[2] = {false, false};
     int st_item = item, st_chunk = 0;
     bool st_valid = true;
@@ -88,11 +96,37 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
         set_m0[S] = m0;
         set_cc[S] = cc;
+        if (IM) {
+            const int tap = st_chunk * 8 + cv;                  // k = 8*tap + channel: this thread's vector is one tap of one pixel
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            unsigned zero = 0u;
+            // position of the tile's first pixel: once per item on the scalar unit; im_W is a power of two and HW >= 128,
+            // so a vector's (y, x) follows with shifts and at most one image wrap
+            const int r0 = m0 % p.HW;
+            const int wsh = 31 - __builtin_clz(p.im_W);
+            const int y0 = r0 >> wsh, x0 = r0 & (p.im_W - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m = m0 + i * 32 + px_l;
-            m = m < p.M ? m : p.M - 1;
-            hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
+            for (int i = 0; i < 4; ++i) {
+                int m = m0 + i * 32 + px_l;
+                m = m < p.M ? m : p.M - 1;
+                const int xl = x0 + (m - m0);
+                int y = y0 + (xl >> wsh);
+                const int x = xl & (p.im_W - 1);
+                y = y >= p.im_H ? y - p.im_H : y;
+                const int yy = y + dy, xx = x + dx;
+                const bool ok = tap < 9 && yy >= 0 && yy < p.im_H && xx >= 0 && xx < p.im_W;
+                zero |= ok ? 0u : (1u << i);
+                const int ms = ok ? m + dy * p.im_W + dx : m;
+                hreg[S][i] = *reinterpret_cast<const u32x4*>(p.src0 + (size_t)ms * 8);
+            }
+            set_zero[S] = zero;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int m = m0 + i * 32 + px_l;
+                m = m < p.M ? m : p.M - 1;
+                hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
+            }
         }
         if (++st_chunk == p.nch) { st_chunk = 0; st_item += G; }
         st_valid = st_item < p.total_items;
@@ -117,6 +151,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     auto commit = [&](int S, int i, int buf) __attribute__((always_inline)) {
         if (!set_ok[S]) return;
         u32x4 raw = hreg[S][i];
+        if (IM) {
+            const bool z = (set_zero[S] >> i) & 1u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raw[k] = z ? 0u : raw[k];
+        }
         if (XF != XF_NONE) {
             float v[8];
 #pragma unroll
@@ -270,12 +309,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 
 static int g1_slots = 0;
 
-template <int BN, int XF>
+template <int BN, int XF, int IM = 0>
 static int run_g1(C1gParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 128 * 72 * 2 + 2048;
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_g_kernel<BN, XF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_g_kernel<BN, XF, IM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         done = true;
@@ -291,21 +330,32 @@ static int run_g1(C1gParams& p, hipStream_t s) {
     p.total_items = p.m_tiles * p.n_slices;
     int lcm = 8;
     while (lcm % p.n_slices) lcm += 8;
-    int G = (p.total_items < g1_slots ? p.total_items : g1_slots) / lcm * lcm;
+    const int slots = g1_slots;
+    int G = (p.total_items < slots ? p.total_items : slots) / lcm * lcm;
     if (G == 0) G = p.total_items;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF>), dim3(G), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM>), dim3(G), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }
 
-// bn: 64 or 128 (Cout % bn == 0); xf: XF_NONE or XF_AFFINE; HW % 64 == 0; nch even
+// bn: 64 or 128 (Cout % bn == 0); xf: XF_NONE or XF_AFFINE; HW % 64 == 0; nch even.
+// im_W > 0: 3x3 conv of an 8-channel input as a tap-major GEMM (C0 = 8, C1 = 0, xf = XF_NONE, nch = 2).
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
-                  int nch, hipStream_t s) {
+                  int nch, int im_H, int im_W, hipStream_t s) {
     C1gParams p;
+    p.im_H = im_H; p.im_W = im_W;
+    if (im_W > 0) {
+        if (xf != XF_NONE || C0 != 8 || C1 != 0 || nch != 2 || (im_W & (im_W - 1)) || HW < 128) return HSIDM_E_UNSUPPORTED;
+    }
     p.src0 = src0; p.src1 = src1; p.C0 = C0; p.C1 = C1;
     p.gn_ab = reinterpret_cast<const f32x4*>(gn_ab);
     p.w = w; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
     p.M = M; p.HW = HW; p.Cout = Cout; p.Cout_pad = Cout; p.nch = nch;
+    if (im_W > 0) {
+        if (bn == 128) return run_g1<128, XF_NONE, 1>(p, s);
+        if (bn == 64) return run_g1<64, XF_NONE, 1>(p, s);
+        return HSIDM_E_UNSUPPORTED;
+    }
     if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE>(p, s) : run_g1<128, XF_AFFINE>(p, s);
     if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE>(p, s) : run_g1<64, XF_AFFINE>(p, s);
     return HSIDM_E_UNSUPPORTED;

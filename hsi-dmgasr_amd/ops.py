@@ -62,8 +62,13 @@ class PackedConv:
         # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
         # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
         self.w_v2 = None
+        self.tap_major = False
         if prec == _lib.BF16 and not out_nchw and proj_weight is None:
             wv = self.w_hi
+            self.tap_major = kh == 3 and cin == 8
+            if self.tap_major:                       # stem-like convs: tap-major GEMM (conv1x1_g IM mode), k = 8*tap + c -> 128
+                w2 = weight.detach().float().reshape(cout, 8, 9).permute(0, 2, 1).reshape(cout, 72, 1, 1)
+                wv = self._steps(w2, cpad, bk).to(torch.bfloat16).contiguous()
             if kh == 1 and wv.shape[0] % 2:          # 1x1 GEMM kernel (conv1x1_g.hip): K padded to a multiple of 128
                 wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
             self.w_v2 = self._lanes(wv, cpad)
@@ -147,6 +152,9 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         d.nphase = 2
     d.w_hi, d.w_lo, d.bias = _lib.ptr(pw.w_hi), _lib.ptr(pw.w_lo), _lib.ptr(pw.bias)
     d.w_v2 = _lib.ptr(pw.w_v2) if _use_v2 else None
+    if pw.tap_major and (ups or stride != 1 or transform != XF_NONE or act != ACT_NONE or film is not None or x1 is not None or
+                         pw.cout % pw.bn or pw.bn < 64 or (Ho * Wo) % 64 or Ho * Wo < 128 or (Wo & (Wo - 1))):
+        d.w_v2 = None                 # the tap-major layout is only read by the GEMM kernel (include/hsidm.h)
     folded = bool(ups) and _use_v2 and _fold_ups and pw.w_up4 is not None
     if folded:
         d.w_v2 = _lib.ptr(pw.w_up4)

@@ -84,9 +84,13 @@ typedef struct hsidm_conv_desc {
     int32_t nphase;           /* 1, or 2 = phase 1 is a fused 1x1 projection of a second input      */
     const void*  w_hi;        /* packed bf16 [step][Cout_pad][BK], step = (phase, chunk, tap)       */
     const void*  w_lo;        /* low halves (HSIDM_F32X3 only)                                      */
-    const void*  w_v2;        /* optional (HSIDM_BF16, 3x3 stride 1): the same weights in the register-
-                                 streaming order [step][Cout_pad/32][4][64 lanes][8]; enables the
-                                 persistent kernel (csrc/conv_v2.h)                                   */
+    const void*  w_v2;        /* optional (HSIDM_BF16): the same weights in the register-streaming order
+                                 [step][Cout_pad/32][4][64 lanes][8]; enables the persistent kernels
+                                 (csrc/conv_v2.h, conv1x1_g.hip).  1x1: K padded to a multiple of 128.
+                                 3x3 with C0 + C1 == 8: tap-major GEMM layout, k = 8*tap + c padded to
+                                 128 (2 steps); such a descriptor must satisfy: stride 1, no ups, no
+                                 transform / act / film, Cout % bn == 0, Hout*Wout % 64 == 0, >= 128,
+                                 Wout a power of two                                                   */
     const float* bias;        /* [Cout] or NULL                                                     */
     const float* film;        /* [B][film_stride], pre-offset to this layer's columns, or NULL      */
     int32_t film_stride;

@@ -394,6 +394,38 @@ def test_stride2_conv_over_parity_planes_matches_v1_and_torch(dev, case):
     check("dn4_vs_torch%s" % (case,), "bf16", outs[1], ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("case", [(3, 24, 16, 6, 64), (3, 16, 24, 6, 64), (2, 16, 8, 8, 128), (1, 16, 16, 6, 32), (2, 32, 32, 5, 64), (3, 8, 8, 8, 64)])
+def test_eight_channel_conv_as_tap_major_gemm(dev, case):
+    """3x3 convs with <= 8 input channels (the UNet stem) run as a K = 72 GEMM (conv1x1_g, im2col on the fly); shapes the
+    GEMM kernel refuses (32 couts) stay on the generic kernel.  Against v1 and torch fp32, with statistics."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pk = ops.PackedConv(w.to(dev), bias.to(dev), "bf16")
+    assert pk.tap_major and pk.cin == 8
+    x = torch.zeros(B, H, W, 8)
+    x[..., :Ci] = torch.randn(B, H, W, Ci, generator=g)
+    x = x.to(torch.bfloat16)
+    outs = []
+    for use_v2 in (False, True):
+        ops.set_use_v2(use_v2)
+        try:
+            y = ops.conv2d(x.to(dev), pk, stats=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_use_v2(True)
+        slab, nsplit = y._hsidm_stats
+        yf = y.float()
+        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
+        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), use_v2
+        outs.append(yf.cpu())
+    ref = torch.nn.functional.conv2d(x.float()[..., :Ci].permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1)
+    check("stem_gemm_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
+    check("stem_gemm_vs_torch%s" % (case,), "bf16", outs[1], ref, tol=1e-2)
+
+
 C1_CASES = [  # B, H, W, C0, C1, Cout, with_res, gn_affine
     (2, 16, 16, 64, 0, 128, False, False),       # K=64 padded to 128, one 128-cout slice
     (3, 8, 8, 128, 64, 64, True, False),         # concat input, K=192 -> 256, residual + statistics; 192 pixels: half-empty last tile
