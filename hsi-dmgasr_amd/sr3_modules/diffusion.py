@@ -61,7 +61,7 @@ class ReverseRun:
 
     def __init__(self, gd, cond, shape, continous, x_T, noise, precision, wrap):
         dev = gd.betas.device
-        T = gd.num_timesteps
+        T = gd._run_T                      # steps of the active sampler (num_timesteps for the reference's ancestral one)
         self.gd, self.T, self.precision, self.wrap = gd, T, precision, wrap
         self.inter = 1 | (T // 10)
         if x_T is not None:
@@ -94,7 +94,7 @@ class ReverseRun:
         eps = gd._denoise(self.cond, self.x, self.t_ptr, self.precision)
         if self.zbuf is not None:
             self.zbuf.normal_()
-        ops.p_sample_update(self.x, eps.contiguous(), gd._coef, self.t_ptr, self.T,
+        ops.p_sample_update(self.x, eps.contiguous(), gd._run_coef, self.t_ptr, self.T,
                             noise=self.stored if self.stored is not None else self.zbuf, noise_stride=self.stride,
                             seed=gd.seed, snap=self.snap, inter=self.inter)
         ops.step_advance(self.t_ptr, self.T if self.wrap else 0)
@@ -174,15 +174,52 @@ class GaussianDiffusion(nn.Module):
         self.register_buffer("_level", torch.tensor(self.sqrt_alphas_cumprod_prev, dtype=torch.float32, device=device),
                              persistent=False)
         self._graph_cache = {}
+        self._schedule_opt = dict(schedule_opt)
+        self.set_sampler("ddpm")
+
+    def set_sampler(self, kind="ddpm", steps=None, eta=0.0):
+        """Which reverse process p_sample_loop / super_resolution run.
+
+        "ddpm": the reference's ancestral sampler over all num_timesteps (diffusion.py:152-201).
+        "ddim": K = `steps` strided steps (Song et al. 2021, eq. 12) on the same schedule, kernels and noise-level
+        conditioning (not in the reference).  The update has the posterior's form, so it runs on
+        hsidm_p_sample_update with a different coefficient table: x_prev = c_x0*clamp(x0) + c_xt*x_t + sigma*z, eps being
+        re-derived from the clamped x0; eta = 1 with steps = num_timesteps reproduces "ddpm" exactly."""
+        dev = self.betas.device
+        if kind == "ddpm":
+            self._run_T, self._run_coef, self._run_level = self.num_timesteps, self._coef, self._level
+            self._run_level_host = self.sqrt_alphas_cumprod_prev
+        elif kind == "ddim":
+            T = self.num_timesteps
+            K = T if steps is None else int(steps)
+            if not 1 <= K <= T:
+                raise ValueError("ddim steps must be in [1, %d]" % T)
+            ac = np.cumprod(1.0 - np.asarray(
+                make_beta_schedule(self._schedule_opt["schedule"], self._schedule_opt["n_timestep"],
+                                   self._schedule_opt["linear_start"], self._schedule_opt["linear_end"]), dtype=np.float64))
+            tau = np.round(np.linspace(0, T - 1, K)).astype(np.int64) if K > 1 else np.array([T - 1], dtype=np.int64)
+            a_t = ac[tau]
+            a_prev = np.append(1.0, a_t[:-1])
+            sigma2 = (float(eta) ** 2) * (1.0 - a_prev) / (1.0 - a_t) * (1.0 - a_t / a_prev)
+            c_xt = np.sqrt(np.maximum(1.0 - a_prev - sigma2, 0.0)) / np.sqrt(1.0 - a_t)
+            table = np.stack([np.sqrt(1.0 / a_t), np.sqrt(1.0 / a_t - 1), np.sqrt(a_prev) - c_xt * np.sqrt(a_t), c_xt,
+                              np.log(np.maximum(sigma2, 1e-20))], axis=1)
+            self._run_T = K
+            self._run_coef = torch.tensor(table, dtype=torch.float32, device=dev).contiguous()
+            self._run_level_host = np.sqrt(np.append(1.0, a_t))
+            self._run_level = torch.tensor(self._run_level_host, dtype=torch.float32, device=dev)
+        else:
+            raise NotImplementedError(kind)
+        self.sampler = kind
 
     # ---------------------------------------------------------------------------------- reverse process
     def _denoise(self, cond, x, t_ptr, precision=None):
         fn = self.denoise_fn
         if isinstance(fn, UNet):
-            return fn.forward_pair(cond, x, level_table=self._level, t_ptr=t_ptr, precision=precision)
+            return fn.forward_pair(cond, x, level_table=self._run_level, t_ptr=t_ptr, precision=precision)
         # a foreign denoiser module: reference call convention (diffusion.py:154-161), host-side level
         t = int(t_ptr.item())
-        lvl = torch.full((x.shape[0], 1), float(np.float32(self.sqrt_alphas_cumprod_prev[t + 1])), device=x.device)
+        lvl = torch.full((x.shape[0], 1), float(np.float32(self._run_level_host[t + 1])), device=x.device)
         inp = torch.cat([cond, x], dim=1) if cond is not None else x
         return fn(inp, lvl)
 

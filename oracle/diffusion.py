@@ -148,3 +148,63 @@ def p_losses(denoise, x_hr, x_sr, gamma, noise, loss_type="l1"):
     if loss_type == "l2":
         return ((noise - rec) ** 2).sum()
     raise NotImplementedError(loss_type)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Strided DDIM sampler.  NOT in the reference (it only has the ancestral sampler above):
+# restated from Song, Meng & Ermon, "Denoising Diffusion Implicit Models" (ICLR 2021), eq. 12 / 16, on the
+# reference's schedule buffers.  Pin: with eta = 1 and all T steps its tables equal the reference's
+# posterior tables (tests/test_oracle_golden.py::test_ddim_tables_reduce_to_the_reference_posterior).
+# ---------------------------------------------------------------------------------------------------
+def ddim_schedule(schedule_opt, steps, eta=0.0):
+    """Tables of a K-step sampler on the sub-sequence tau = round(linspace(0, T-1, K)) of the reference schedule.
+
+    Row i (loop index, i = K-1 .. 0) holds what p_sample_step takes from the reference buffers at index t:
+    x0 = sqrt_recip*x - sqrt_recipm1*eps (clamped, diffusion.py:171), x_prev = coef_x0*x0 + coef_xt*x + sigma*z, where
+    eps is re-derived from the clamped x0:  coef_xt = c/sqrt(1-a_t), coef_x0 = sqrt(a_prev) - coef_xt*sqrt(a_t),
+    c = sqrt(1 - a_prev - sigma^2), sigma = eta*sqrt((1-a_prev)/(1-a_t))*sqrt(1 - a_t/a_prev).  ``level[i+1]`` is the
+    noise level handed to the UNet (sqrt(a_tau_i), the reference's sqrt_alphas_cumprod_prev[t+1]).
+    """
+    betas = np.asarray(make_beta_schedule(schedule_opt["schedule"], schedule_opt["n_timestep"],
+                                          schedule_opt["linear_start"], schedule_opt["linear_end"]), dtype=np.float64)
+    T = betas.shape[0]
+    K = int(steps)
+    assert 1 <= K <= T
+    ac = np.cumprod(1.0 - betas)
+    tau = np.round(np.linspace(0, T - 1, K)).astype(np.int64) if K > 1 else np.array([T - 1], dtype=np.int64)
+    a_t = ac[tau]
+    a_prev = np.append(1.0, a_t[:-1])
+    sigma2 = (eta ** 2) * (1.0 - a_prev) / (1.0 - a_t) * (1.0 - a_t / a_prev)
+    c = np.sqrt(np.maximum(1.0 - a_prev - sigma2, 0.0))
+    coef_xt = c / np.sqrt(1.0 - a_t)
+    return {
+        "tau": tau, "num_timesteps": K,
+        "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / a_t).astype(np.float32),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / a_t - 1).astype(np.float32),
+        "coef_x0": (np.sqrt(a_prev) - coef_xt * np.sqrt(a_t)).astype(np.float32),
+        "coef_xt": coef_xt.astype(np.float32),
+        "log_sigma2": np.log(np.maximum(sigma2, 1e-20)).astype(np.float32),
+        "level": np.sqrt(np.append(1.0, a_t)),
+    }
+
+
+def ddim_step(denoise, tab, x, cond, i, z):
+    """One step of the strided sampler; same shape as p_sample_step (z ignored at i == 0)."""
+    b = x.shape[0]
+    gamma = torch.full((b, 1), float(np.float32(tab["level"][i + 1])), dtype=torch.float32)
+    inp = torch.cat([cond, x], dim=1) if cond is not None else x
+    eps = denoise(inp, gamma)
+    f = lambda name: torch.tensor(tab[name][i], dtype=torch.float32)
+    x0 = (f("sqrt_recip_alphas_cumprod") * x - f("sqrt_recipm1_alphas_cumprod") * eps).clamp(-1.0, 1.0)
+    mean = f("coef_x0") * x0 + f("coef_xt") * x
+    if i > 0:
+        return mean + z * (0.5 * f("log_sigma2")).exp()
+    return mean
+
+
+def ddim_sample_loop(denoise, tab, cond, x_T, noise_fn):
+    """K-step reverse process; returns the final x (all samples of the batch)."""
+    img = x_T
+    for i in reversed(range(tab["num_timesteps"])):
+        img = ddim_step(denoise, tab, img, cond, i, noise_fn(i) if i > 0 else None)
+    return img

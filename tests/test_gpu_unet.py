@@ -249,6 +249,35 @@ def test_sampler_api_shapes_and_philox_mode(dev):
     check("sampler_philox_T12", "fp32", got, xo, tol=2e-3)
 
 
+@pytest.mark.parametrize("steps,eta", [(6, 0.0), (9, 0.7), (12, 1.0)])
+def test_strided_ddim_sampler_matches_oracle(dev, steps, eta):
+    """K-step DDIM on the device (same kernels, alternative coefficient table) against the oracle's restatement with the
+    same Philox noise; eta = 1 with all steps is the reference's ancestral sampler."""
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import diffusion as odiff, sr3_unet
+    cfg = jload(load_npz("unets.npz")["tiny.cfg_json"])
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision="fp32").to(dev).eval()
+    sd = fill_synth(u, "unet_tiny.")
+    opt = dict(schedule="cosine", n_timestep=12, linear_start=1e-6, linear_end=1e-2)
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(opt, dev)
+    gd.set_sampler("ddim", steps=steps, eta=eta)
+    gd.noise, gd.seed = "philox", 77
+    cond = G(synth_tensor("ddim.cond", (2, 3, 16, 16)), dev)
+    got = gd.p_sample_loop_batched(cond)
+    tab = odiff.ddim_schedule(opt, steps, eta)
+    den = lambda x, gam: sr3_unet.unet_forward(sd, cfg, x, gam)
+    nf = odiff.philox_noise_fn(77, (2, 3, 16, 16))
+    want = odiff.ddim_sample_loop(den, tab, cond.cpu(), nf(steps), nf)
+    check("ddim_K%d_eta%g" % (steps, eta), "fp32", got, want, tol=2e-3)
+    if steps == 12 and eta == 1.0:
+        gd.set_sampler("ddpm")
+        check("ddim_full_eta1_is_ddpm", "fp32", got, gd.p_sample_loop_batched(cond), tol=1e-4)
+    assert gd.super_resolution(cond, continous=False).shape == (3, 16, 16)
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96)])
 def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
     """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (N = 64 / 256, C % 64 == 0), the panel

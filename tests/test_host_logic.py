@@ -131,6 +131,31 @@ def test_product_schedule_buffers_match_reference(name):
         diffusion.make_beta_schedule("bogus", 10)
 
 
+def test_product_sampler_tables_match_the_oracle():
+    from hsi_dmgasr_amd.sr3_modules import diffusion
+    from oracle import diffusion as odiff
+    opt = dict(schedule="cosine", n_timestep=50, linear_start=1e-6, linear_end=1e-2)
+    gd = diffusion.GaussianDiffusion(torch.nn.Identity(), image_size=16, channels=3, conditional=True)
+    gd.set_new_noise_schedule(opt, "cpu")
+    assert gd.sampler == "ddpm" and gd._run_T == 50 and gd._run_coef is gd._coef
+    for steps, eta in ((50, 1.0), (9, 0.0), (13, 0.5), (1, 0.0)):
+        gd.set_sampler("ddim", steps=steps, eta=eta)
+        tab = odiff.ddim_schedule(opt, steps, eta)
+        assert gd._run_T == steps
+        want = np.stack([tab["sqrt_recip_alphas_cumprod"], tab["sqrt_recipm1_alphas_cumprod"], tab["coef_x0"], tab["coef_xt"],
+                         tab["log_sigma2"]], axis=1)
+        np.testing.assert_allclose(gd._run_coef.numpy(), want, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(gd._run_level_host, tab["level"], rtol=1e-14)
+    gd.set_sampler("ddim", steps=50, eta=1.0)                  # == the reference's ancestral sampler
+    np.testing.assert_allclose(gd._run_coef.numpy(), gd._coef.numpy(), rtol=2e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        gd.set_sampler("ddim", steps=51)
+    with pytest.raises(NotImplementedError):
+        gd.set_sampler("plms")
+    gd.set_new_noise_schedule(opt, "cpu")                      # a new schedule resets the sampler
+    assert gd.sampler == "ddpm"
+
+
 def test_shard_ranges_partition_the_patches():
     from hsi_dmgasr_amd import parallel
     for n in (0, 1, 7, 8, 9, 64, 65):
