@@ -54,6 +54,8 @@ SIGNATURES = {
     "hsidm_ca_vector": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "hsidm_ca_apply": [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp],
     "hsidm_overlap_average": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "hsidm_hsi_metrics_workspace_bytes": [_i32, _i32, _i32],
+    "hsidm_hsi_metrics": [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -207,6 +207,14 @@ int hsidm_ca_apply(int prec, const void* r, const float* ca, const void* skip, c
 int hsidm_overlap_average(const float* dec, const int32_t* start, int G, int n_subs, int B, int C,
                           int HW, float* y, void* stream);
 
+/* ---- quality indices of decoded cubes (eval_hsi.py:27-121; caller sr_gae.py:468-474) -----------------------
+ * truth, pred: NCHW fp32 [P][C][HW].  out[p] = {MPSNR (dB, data_range), SAM (degrees), ERGAS (ratio = upsampling
+ * factor), CC, RMSE}.  workspace: hsidm_hsi_metrics_workspace_bytes(P, C, HW) bytes of device memory.
+ * Deterministic; the SAM cosine is clamped to [-1, 1] (the reference returns NaN when fp32 rounding exceeds 1). */
+int hsidm_hsi_metrics_workspace_bytes(int P, int C, int HW);
+int hsidm_hsi_metrics(const float* truth, const float* pred, int P, int C, int HW, float ratio, float data_range,
+                      void* workspace, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

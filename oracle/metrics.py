@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-MPSNR follows eval_hsi.py:110-121 (mean over bands of skimage's
+ERGAS, CC and RMSE (eval_hsi.py:27-44, 68-80, 99-107) are restated for the on-device indices and pinned
+to values of the reference itself (tests/golden/metrics2.npz).  MPSNR follows eval_hsi.py:110-121 (mean over bands of skimage's
 peak_signal_noise_ratio = 10*log10(range^2 / MSE), restated because skimage is
 not part of this image); SAM follows eval_hsi.py:47-65 (mean spectral angle in
 degrees over pixels whose two spectra are non-zero).  Inputs are (H, W, C).
@@ -29,3 +30,32 @@ def sam_degrees(x_true, x_pred):
     cos = np.sum(t[ok] * p[ok], axis=1) / (nt[ok] * npd[ok])
     ang = np.arccos(cos)
     return float(np.sum(ang) / np.count_nonzero(ok) * 180.0 / np.pi)
+
+
+def _bands(x_true, x_pred):
+    """img_2d_mat, eval_hsi.py:83-96: (H, W, C) -> (C, H*W) float32."""
+    c = x_true.shape[2]
+    return (x_true.astype(np.float32).reshape(-1, c).T.copy(), x_pred.astype(np.float32).reshape(-1, c).T.copy())
+
+
+def ergas(x_true, x_pred, ratio):
+    """eval_hsi.py:27-44: (100/ratio) * sqrt(mean_band(MSE_band / mean(true_band)^2))."""
+    t, p = _bands(x_true, x_pred)
+    acc = 0.0
+    for i in range(t.shape[0]):
+        acc += np.mean((t[i] - p[i]) ** 2) / (np.mean(t[i]) ** 2)
+    return float((100.0 / ratio) * np.sqrt(acc / t.shape[0]))
+
+
+def cross_correlation(x_true, x_pred):
+    """eval_hsi.py:68-80: mean over bands of the Pearson correlation of the two band images."""
+    t, p = _bands(x_true, x_pred)
+    t = t - t.mean(axis=1, keepdims=True)
+    p = p - p.mean(axis=1, keepdims=True)
+    return float(np.mean(np.sum(t * p, axis=1) / np.sqrt(np.sum(t * t, axis=1) * np.sum(p * p, axis=1))))
+
+
+def rmse(x_true, x_pred):
+    """eval_hsi.py:99-107: Frobenius norm of the difference / sqrt(number of elements)."""
+    d = x_true.astype(np.float32) - x_pred.astype(np.float32)
+    return float(np.linalg.norm(d) / np.sqrt(d.size))

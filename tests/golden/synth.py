@@ -32,3 +32,17 @@ def synth_state_dict(shapes, seed=0):
 def synth_tensor(tag, shape, seed=0, scale=1.0):
     rng = np.random.Generator(np.random.PCG64((zlib.crc32(tag.encode()) ^ (seed * 0x85EBCA6B)) & 0xFFFFFFFF))
     return (scale * rng.standard_normal(tuple(shape))).astype(np.float32)
+
+
+METRIC_CASES = {"a": ((16, 16, 31), 0.05), "b": ((24, 40, 8), 0.2), "c": ((64, 64, 31), 0.01)}
+
+
+def metric_pair(tag):
+    """(H, W, C) ground truth in [0, 1) and a perturbed prediction for the quality-index goldens (metrics2.npz); a few
+    all-zero spectra exercise SAM's skip rule (reference eval_hsi.py:60)."""
+    shape, noise = METRIC_CASES[tag]
+    t = np.abs(synth_tensor("metrics_%s.t" % tag, shape)) % 1.0
+    p = np.clip(t + noise * synth_tensor("metrics_%s.n" % tag, shape), 0.0, 1.0)
+    t[0, :3, :] = 0.0
+    p[1, :2, :] = 0.0
+    return t.astype(np.float32), p.astype(np.float32)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import torch
 
-from synth import synth_param, synth_tensor  # tests/golden/synth.py (path added by conftest)
+from synth import METRIC_CASES, metric_pair, synth_param, synth_tensor  # noqa: F401  tests/golden/synth.py (path added by conftest)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -82,3 +82,28 @@ def test_pipeline_golden(dev, prec):
     y, lat = pipeline.super_resolve(m, gd, G(g["sr"], dev), x_T=x_T, noise=noise)
     check("pipeline_latents", prec, lat[0], g["x0"][:, 0], tol=2e-3)
     check("pipeline_cube", prec, y, g["y"], tol=2e-3)
+
+
+def test_quality_indices_on_device(dev):
+    """MPSNR / SAM / ERGAS / CC / RMSE kernels against the oracle restatements (pinned to the reference, metrics2.npz) and
+    against the reference's own values, for cubes of different sizes batched one by one and together."""
+    from helpers import METRIC_CASES, metric_pair
+    from hsi_dmgasr_amd import metrics
+    from oracle import metrics as om
+    g = load_npz("metrics2.npz")
+    for tag in METRIC_CASES:
+        t, p = metric_pair(tag)
+        tt = torch.from_numpy(t.transpose(2, 0, 1)[None].copy()).to(dev)
+        pp = torch.from_numpy(p.transpose(2, 0, 1)[None].copy()).to(dev)
+        row = metrics.as_dicts(metrics.quality_indices(torch.cat([tt, tt]), torch.cat([pp, pp]), ratio=4, data_range=1.0))
+        assert row[0] == row[1]                                   # deterministic, batch entries independent
+        r = row[0]
+        assert abs(r["mpsnr"] - om.mpsnr(t, p)) < 1e-3
+        assert abs(r["sam"] - float(g[tag + ".sam"])) < 2e-3 and abs(r["sam"] - om.sam_degrees(t, p)) < 2e-3
+        assert abs(r["ergas"] - float(g[tag + ".ergas"])) < 1e-4 * float(g[tag + ".ergas"])
+        assert abs(r["cc"] - float(g[tag + ".cc"])) < 1e-5
+        assert abs(r["rmse"] - float(g[tag + ".rmse"])) < 1e-6
+    same = metrics.as_dicts(metrics.quality_indices(tt, tt))[0]    # identical cubes: cosine clamped -> a tiny angle, never NaN
+    assert 0.0 <= same["sam"] < 0.05 and same["rmse"] == 0.0 and same["mpsnr"] == float("inf")
+    with pytest.raises(ValueError):
+        metrics.quality_indices(tt, pp[:, :3])
