@@ -56,6 +56,9 @@ SIGNATURES = {
     "hsidm_overlap_average": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "hsidm_hsi_metrics_workspace_bytes": [_i32, _i32, _i32],
     "hsidm_hsi_metrics": [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
+    "hsidm_resample_axis": [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp],
+    "hsidm_minmax_workspace_bytes": [_i32],
+    "hsidm_minmax_normalize": [_vp, _vp, _i32, _i64, _vp, _vp],
 }
 
 _lib = None

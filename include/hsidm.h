@@ -215,6 +215,16 @@ int hsidm_hsi_metrics_workspace_bytes(int P, int C, int HW);
 int hsidm_hsi_metrics(const float* truth, const float* pred, int P, int C, int HW, float ratio, float data_range,
                       void* workspace, float* out, void* stream);
 
+/* ---- patch preparation (HStest.py:37-45, HStrain.py:49-63, imsize.py) ------------------------------------
+ * One axis of the MATLAB-compatible resize: dst[o][j][i] = sum_p weights[j][p] * src[o][indices[j][p]][i] for
+ * src [outer][in_len][inner], dst [outer][out_len][inner] (fp32).  weights/indices [out_len][taps] are the tap
+ * tables of imsize.py:35-60 (host-built, device-resident).  clamp01: clamp the result to [0, 1] (HStest.py:59-60). */
+int hsidm_resample_axis(const float* src, float* dst, int64_t outer, int in_len, int out_len, int inner,
+                        const float* weights, const int32_t* indices, int taps, int clamp01, void* stream);
+/* out = (x - min) / (max - min) per cube, x [P][n] fp32; workspace: hsidm_minmax_workspace_bytes(P) bytes. */
+int hsidm_minmax_workspace_bytes(int P);
+int hsidm_minmax_normalize(const float* x, float* out, int P, int64_t n, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

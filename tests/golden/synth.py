@@ -46,3 +46,12 @@ def metric_pair(tag):
     t[0, :3, :] = 0.0
     p[1, :2, :] = 0.0
     return t.astype(np.float32), p.astype(np.float32)
+
+
+IMRESIZE_CASES = {"sq": ((64, 64, 5), 4), "odd": ((55, 74, 3), 4), "x2": ((32, 48, 4), 2)}
+
+
+def imresize_input(tag):
+    """(H, W, C) float32 cube in [0, 1) for the resize goldens (imresize.npz)."""
+    shape, _ = IMRESIZE_CASES[tag]
+    return (np.abs(synth_tensor("imresize_%s" % tag, shape)) % 1.0).astype(np.float32)

@@ -107,3 +107,28 @@ def test_quality_indices_on_device(dev):
     assert 0.0 <= same["sam"] < 0.05 and same["rmse"] == 0.0 and same["mpsnr"] == float("inf")
     with pytest.raises(ValueError):
         metrics.quality_indices(tt, pp[:, :3])
+
+
+def test_patch_preparation_on_device(dev):
+    """min-max normalisation and the bicubic x1/n, xn pair (HStest.py:37-60) against outputs of the reference's imsize.py."""
+    from helpers import IMRESIZE_CASES, imresize_input
+    from hsi_dmgasr_amd import degrade
+    g = load_npz("imresize.npz")
+    for tag, (shape, n) in IMRESIZE_CASES.items():
+        gt = imresize_input(tag)
+        x = torch.from_numpy(gt.transpose(2, 0, 1)[None].copy()).to(dev)
+        x2 = torch.cat([x, x.flip(1)])                              # a second cube: batch entries are independent
+        ms, lms = degrade.lr_pair(x2, n)
+        torch.cuda.synchronize()
+        want_ms = np.clip(g[tag + ".ms"], 0, 1).transpose(2, 0, 1)
+        want_lms = np.clip(g[tag + ".lms"], 0, 1).transpose(2, 0, 1)
+        assert ms.shape == (2, shape[2], shape[0] // n, shape[1] // n) and lms.shape == (2, shape[2], shape[0], shape[1])
+        assert np.abs(ms[0].cpu().numpy() - want_ms).max() < 2e-6 and np.abs(lms[0].cpu().numpy() - want_lms).max() < 2e-6
+        assert np.abs(ms[1].flip(0).cpu().numpy() - want_ms).max() < 2e-6
+        assert float(lms.min()) >= 0.0 and float(lms.max()) <= 1.0
+    raw = torch.randn(3, 5, 16, 24, device=dev) * 37.0 + 11.0
+    got = degrade.minmax_normalize(raw)
+    lo = raw.reshape(3, -1).min(dim=1).values.view(3, 1, 1, 1)
+    hi = raw.reshape(3, -1).max(dim=1).values.view(3, 1, 1, 1)
+    assert torch.allclose(got, (raw - lo) / (hi - lo), rtol=0, atol=1e-6)
+    assert float(got.min()) == 0.0 and float(got.max()) == 1.0

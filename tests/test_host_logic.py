@@ -156,6 +156,17 @@ def test_product_sampler_tables_match_the_oracle():
     assert gd.sampler == "ddpm"
 
 
+def test_product_resize_tap_tables_match_the_oracle():
+    from hsi_dmgasr_amd import degrade
+    from oracle import imresize as oi
+    for a, b in ((64, 16), (16, 64), (55, 13), (13, 55), (74, 18), (18, 74), (128, 32), (32, 128), (7, 7), (5, 9)):
+        w, idx = degrade.tap_tables(a, b)
+        wo, io = oi.taps(a, b)
+        assert w.shape == wo.shape and np.array_equal(idx, io), (a, b)
+        np.testing.assert_allclose(w, wo, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(w.sum(axis=1), 1.0, atol=1e-12)
+
+
 def test_shard_ranges_partition_the_patches():
     from hsi_dmgasr_amd import parallel
     for n in (0, 1, 7, 8, 9, 64, 65):
