@@ -6,7 +6,7 @@ sampled by G sequential batch-1 p_sample_loop calls with a device->host->device 
 """
 import torch
 
-from . import parallel
+from . import degrade, metrics, parallel
 
 
 @torch.no_grad()
@@ -29,3 +29,15 @@ def super_resolve_sharded(gae, gd, sr_cubes_all, precision=None):
     (weights are expected to have been broadcast once with parallel.broadcast_module_)."""
     fn = lambda cubes: super_resolve(gae, gd, cubes, precision=precision)[0]
     return parallel.run_sharded(sr_cubes_all, fn)
+
+
+@torch.no_grad()
+def evaluate(gae, gd, raw_cubes, n_scale=4, normalize=True, precision=None):
+    """The whole validation iteration of sr_gae.py:436-494 on the device, for a batch of ground-truth cubes
+    raw_cubes [P, C, H, W]: min-max normalise (HStest.py:37) -> bicubic x1/n, xn (HStest.py:43-45) -> encode, denoise every
+    group latent with the sampler set on `gd` (set_sampler), decode -> quality indices against the ground truth
+    (eval_hsi.py).  Returns (SR cubes, indices [P, 5] with columns metrics.NAMES, bicubic baseline indices [P, 5])."""
+    gt = degrade.minmax_normalize(raw_cubes) if normalize else raw_cubes.to(torch.float32).contiguous()
+    _, lms = degrade.lr_pair(gt, n_scale)
+    sr, _ = super_resolve(gae, gd, lms, precision=precision)
+    return sr, metrics.quality_indices(gt, sr, ratio=n_scale), metrics.quality_indices(gt, lms, ratio=n_scale)

@@ -132,3 +132,42 @@ def test_patch_preparation_on_device(dev):
     hi = raw.reshape(3, -1).max(dim=1).values.view(3, 1, 1, 1)
     assert torch.allclose(got, (raw - lo) / (hi - lo), rtol=0, atol=1e-6)
     assert float(got.min()) == 0.0 and float(got.max()) == 1.0
+
+
+def test_validation_iteration_end_to_end(dev):
+    """pipeline.evaluate = normalise -> degrade -> encode -> K-step sampler -> decode -> indices, all on the device, against the
+    same chain assembled from the oracle pieces (Philox noise, DDIM 5 steps, eta 0)."""
+    from hsi_dmgasr_amd import gae, pipeline
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import diffusion as odiff, gae as ogae, imresize as oi, metrics as om, sr3_unet
+    cfg = jload(load_npz("unets.npz")["tiny.cfg_json"])
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision="fp32").to(dev).eval()
+    usd = fill_synth(u, "unet_tiny.")
+    opt = dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2)
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(opt, dev)
+    gd.set_sampler("ddim", steps=5, eta=0.0)
+    gd.noise, gd.seed = "philox", 5
+    m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision="fp32").to(dev).eval()
+    gsd = fill_synth(m, "gae_cave_synth.")
+    raw = (torch.rand(1, 31, 16, 16, generator=torch.Generator().manual_seed(3)) * 900.0 + 50.0)
+    sr, idx, base = pipeline.evaluate(m, gd, raw.to(dev), n_scale=4)
+    # oracle chain
+    r = raw[0].numpy().transpose(1, 2, 0).astype(np.float32)
+    gt = (r - r.min()) / (r.max() - r.min())
+    _, lms = oi.lr_pair(gt, 4)
+    x = torch.from_numpy(lms.transpose(2, 0, 1)[None].copy())
+    z = torch.cat(ogae.gae_encode(gsd, x, 8, 2), dim=0)                       # [G, 3, H, W]
+    tab = odiff.ddim_schedule(opt, 5, 0.0)
+    den = lambda xx, gam: sr3_unet.unet_forward(usd, cfg, xx, gam)
+    nf = odiff.philox_noise_fn(5, tuple(z.shape))
+    x0 = odiff.ddim_sample_loop(den, tab, z, nf(5), nf)
+    y = ogae.gae_decode(gsd, 31, [x0[i:i + 1] for i in range(x0.shape[0])], 8, 2).clamp(0, 1)
+    check("evaluate_cube", "fp32", sr, y, tol=2e-3)
+    yy = y[0].numpy().transpose(1, 2, 0)
+    got = dict(zip(("mpsnr", "sam", "ergas", "cc", "rmse"), idx[0].tolist()))
+    assert abs(got["mpsnr"] - om.mpsnr(gt, yy)) < 0.01 and abs(got["sam"] - om.sam_degrees(gt, yy)) < 0.01
+    assert abs(got["rmse"] - om.rmse(gt, yy)) < 1e-4 and abs(got["cc"] - om.cross_correlation(gt, yy)) < 1e-3
+    assert abs(base[0, 0].item() - om.mpsnr(gt, lms)) < 1e-3                    # bicubic baseline row
