@@ -83,7 +83,8 @@ struct V2Cfg {
     static constexpr int RP = (TW == 16) ? 1408 : 832;
     static_assert(RP >= HCOLS * PSTR, "row pitch");
     static constexpr int HALO_ELEMS = NI * HROWS * RP;
-    static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2;
+    // two halo buffers + the per-thread table of halo positions (MAXHV packed ints per thread, see describe)
+    static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2 + (size_t)MAXHV * 256 * 4;
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
@@ -210,6 +211,11 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const int hy = r / HCOLS, hx = r - hy * HCOLS;
         return (i < MAXHV - 1 || last_live) ? ((img << 16) | (hy << 8) | hx) : -1;
     };
+    // The positions are constant per thread; recomputing them per item cost ~25 VALU per vector (two divisions by
+    // constants), keeping them in registers made the allocator spill.  They live in LDS instead: one ds_read per vector.
+    int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2);
+#pragma unroll
+    for (int i = 0; i < MAXHV; ++i) pos_tab[i * 256 + tid] = hv_pos(i, tid);
     int st_b0 = 0;
     auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {   // tile origin on the staged grid
         int par_;
@@ -227,15 +233,12 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const bool up = !FR && p.ups;
         const int hlim = DN4 ? p.Hout : (up ? 2 * p.Hin : p.Hin), wlim = DN4 ? p.Wout : (up ? 2 * p.Win : p.Win);
         const int sh = up ? 1 : 0;
-        int t_op = tid;
-        asm volatile("" : "+v"(t_op));      // recompute the halo positions here: hoisted out of the item loop they were spilled, and
-                                            // every scratch reload is an s_waitcnt vmcnt(0) that drains the prefetch queues
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int pos = hv_pos(i, t_op);
+            const int pos = pos_tab[i * 256 + tid];
             const int b = b0 + (pos >> 16);
             const int iy = oy0 + ((pos >> 8) & 255) - 1, ix = ox0 + (pos & 255) - 1;
-            const bool ok = pos >= 0 && b < p.B && iy >= 0 && ix >= 0 && iy < hlim && ix < wlim;
+            const bool ok = pos >= 0 && b < p.B && (unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim;
             hv_pix[i] = !ok ? -1 : (DN4 ? (b * p.Hin + 2 * iy) * p.Win + 2 * ix : (b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh));
         }
     };
