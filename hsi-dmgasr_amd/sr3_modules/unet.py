@@ -379,7 +379,12 @@ class UNet(_HipModule):
         p = self._prec(precision)
         B = x.shape[0]
         wf, bf, _ = self._film_pack()
-        film = ops.noise_film(B, self._emb_dim, self._mlp(), wf, bf, gamma=gamma, level_table=level_table, t_ptr=t_ptr)
+        if gamma is None:
+            # sampler mode: every sample of the batch is at the same noise level (reference diffusion.py:154-155), so the
+            # embedding MLP and the 27 FiLM projections are evaluated once and read with batch stride 0
+            film = ops.noise_film(1, self._emb_dim, self._mlp(), wf, bf, level_table=level_table, t_ptr=t_ptr).expand(B, -1)
+        else:
+            film = ops.noise_film(B, self._emb_dim, self._mlp(), wf, bf, gamma=gamma)
         stem_in = ops.to_nhwc(cond, p, x1=x) if cond is not None else ops.to_nhwc(x, p)
         return self.run_nhwc(stem_in, film, p)
 
