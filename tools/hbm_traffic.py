@@ -20,9 +20,10 @@ def label(name):
     if m:
         bn, tw, ni, xf, up4 = map(int, m.groups())
         return "conv_v2 bn%d %s k3 s1%s" % (bn, "8x8x2" if ni == 2 else "8x16", " gn+silu" if xf == 2 else (" up4" if up4 == 1 else (" dn4" if up4 == 2 else "")))
-    m = re.search(r"conv1x1_g_kernel<(\d+), (\d)>", name) or re.search(r"conv1x1_g_kernelILi(\d+)ELi(\d)", name)
+    m = re.search(r"conv1x1_g_kernel<(\d+), (\d), (\d)>", name) or re.search(r"conv1x1_g_kernelILi(\d+)ELi(\d)ELi(\d)", name)
     if m:
-        return "conv1x1_g bn%d 8x16 k1 s1%s" % (int(m.group(1)), " gn" if int(m.group(2)) == 1 else "")
+        bn, xf, im = map(int, m.groups())
+        return "conv1x1_g bn%d 8x16 k%d s1%s" % (bn, 3 if im else 1, " gn" if xf == 1 else "")
     return None
 
 
