@@ -16,6 +16,7 @@ HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 #undef HSIDM_DECL
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
+int conv_v3_run(ConvV2Params& p, hipStream_t s);
 void conv_v2_set_stamps(unsigned long long* p);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
@@ -40,7 +41,7 @@ extern "C" const char* hsidm_error_string(int code) {
 
 extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
 
-enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3 };
+enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4 };
 
 // HSIDM_1X1=v1 (diagnostic): keep 1x1 convolutions on the generic kernel for A/B measurements
 static bool force_v1_1x1() {
@@ -86,6 +87,9 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     }
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
+        // 64-cout GN+SiLU layers on whole 16x16 tiles: the 256-pixel kernel (conv_v3.hip); HSIDM_NO_V3=1: diagnostic A/B switch
+        if (path == PATH_V2 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 64 && d->Cout == 64 && Hout % 16 == 0 &&
+            Wout % 16 == 0 && !getenv("HSIDM_NO_V3")) path = PATH_V3;
         // 8 input channels (one 16-byte vector per pixel): w_v2 is the tap-major GEMM layout (include/hsidm.h), which only
         // the GEMM kernel reads
         if (d->ksize == 3 && d->ph[0].C0 + d->ph[0].C1 == 8) {
@@ -114,6 +118,7 @@ extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
     if (d->out_nchw) return HSIDM_E_UNSUPPORTED;
+    if (path == PATH_V3) return (Hout / 16) * (Wout / 16) * 2;
     if (path == PATH_G1) return Hout * Wout / 64;
     const bool use_v2 = path == PATH_V2;
     const int TW = tile_kind == 0 ? 16 : 8;
@@ -134,7 +139,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     int Hout, Wout, tile_kind, path;
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
-    const bool use_v2 = path == PATH_V2;
+    const bool use_v2 = path == PATH_V2 || path == PATH_V3;
     if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
     if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
     const int bk = hsidm_conv_bk(d->prec);
@@ -182,6 +187,10 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.out = reinterpret_cast<bf16*>(d->out); v.stats = reinterpret_cast<float2*>(d->stats);
         v.B = d->B; v.Hin = d->Hin; v.Win = d->Win; v.Hout = Hout; v.Wout = Wout; v.Cout = d->Cout; v.Cout_pad = cout_pad;
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
+        if (path == PATH_V3) {
+            v.steps_per_item = steps;
+            return conv_v3_run(v, s);
+        }
         const bool dn4 = d->stride == 2;
         if (dn4) v.nchunks = 4 * p.ph[0].nchunks;
         v.steps_per_item = dn4 ? v.nchunks * 4 : (up4 ? p.ph[0].nchunks * 4 : steps);

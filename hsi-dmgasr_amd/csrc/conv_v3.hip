@@ -1,0 +1,321 @@
+// conv_v3: 3x3 stride-1 convolution with GroupNorm + SiLU prologue for the 64-cout layers of the 128x128 level
+// (ResnetBlock convs at inner_channel, reference unet.py:83-111), bf16.
+//
+// Why another kernel: on conv_v2 these layers are instruction-issue bound, not MFMA bound (SQ counters, batch 120,
+// 64->64 at 128x128: 13 VALU + 5.6 SALU + 1.6 LDS instructions per MFMA, MFMA pipe 24 % busy, 254 us against an HBM
+// floor of 80 us): a 128-pixel x 64-cout item has only 72 MFMAs per wave to carry its halo description, GroupNorm
+// transform, epilogue and bookkeeping.  conv_v3 doubles the pixels per item at the same cout slice:
+//   * tile = 16x16 pixels x 64 couts, 4 waves as 2 (pixel halves of 8 rows) x 2 (cout halves): 4 MFMA tiles per wave and
+//     k-slice instead of 2, so every A-fragment read, weight fragment, wait and loop instruction is amortised over twice
+//     the MFMAs, the 18x18 halo is 1.27x the tile instead of 1.41x, and per-item costs are paid once per 256 pixels;
+//   * the halo tile is SINGLE-buffered (50 KB; double-buffered it would not leave room for two workgroups per CU):
+//     commit (transform) -> barrier -> 36 k-slices of MFMAs -> barrier.  The raw vectors of the next chunk are requested
+//     before the MFMA phase and held in registers through it; the overlap of one workgroup's transform/epilogue with
+//     MFMAs comes from the OTHER workgroup on the CU;
+//   * weights stream through conv_v2's 3-step register ring, epilogue / statistics / FiLM handling are conv_v2's.
+// Requirements (api.hip falls back to conv_v2 otherwise): Cout == 64, H % 16 == 0, W % 16 == 0, no upsampling.
+#include "conv_v2.h"
+#include "../../include/hsidm.h"
+
+namespace hsidm {
+
+namespace v3 {
+constexpr int TH = 16, TW = 16, BM = 256, BN = 64, BK = 64;
+constexpr int WN = 2, WM = 2, MR = 4;
+constexpr int HROWS = TH + 2, HCOLS = TW + 2, HPIX = HROWS * HCOLS;      // 18 x 18
+constexpr int PSTR = BK + 8, VPP = BK / 8;
+constexpr int RP = 1408;                                                   // halo row pitch: 2816 B = 0 mod 256 (conv_v2.h)
+constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;               // 2592 vectors, 11 per thread
+constexpr int HALO_ELEMS = HROWS * RP;
+constexpr size_t LDS_BYTES = (size_t)HALO_ELEMS * 2 + (size_t)MAXHV * 256 * 4;
+}  // namespace v3
+
+__global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
+    using namespace v3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* halo = reinterpret_cast<bf16*>(smem_raw);
+    int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)HALO_ELEMS * 2);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int G = gridDim.x;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ctot = p.C0 + p.C1;
+    const int nch = p.nchunks;
+
+    int item = blockIdx.x;                                      // one cout slice: item = pixel tile
+    const int n_items_blk = (p.total_items - item + G - 1) / G;
+
+    // ---- weight stream (conv_v2's order: [step = chunk*9 + tap][cout/32][kk][lane][8]) ----------------------------------
+    const int nsw = p.Cout_pad >> 5;
+    const bf16* wlane = p.w + ((size_t)wn * 4 * 64 + lane) * 8;
+    const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
+    bf16x8 ring[3][4];
+    int wnext = 0;
+    auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
+        const bf16* src = wlane + (size_t)wnext * wstep_stride;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
+        wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
+    };
+
+    // ---- halo staging: vector i of this thread = halo pixel (tid/8 + 32 i), channels 8*(tid%8).. of the chunk ------------
+    const int cv = tid & 7;
+#pragma unroll
+    for (int i = 0; i < MAXHV; ++i) {
+        const int hp = (tid >> 3) + i * 32;
+        const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
+        pos_tab[i * 256 + tid] = hp < HPIX ? (((hy * RP + hx * PSTR + cv * 8) << 10) | (hy << 5) | hx) : -1;   // LDS offset | hy | hx
+    }
+    int hv_pix[MAXHV];
+    u32x4 hreg[MAXHV];
+    unsigned abh[8];
+    int st_item = item, st_chunk = 0, st_b = 0;
+    bool st_valid = true, st_cok = true;
+    auto describe = [&](int it) __attribute__((always_inline)) {
+        const int b = it / tiles_per_img;
+        const int tr = it - b * tiles_per_img;
+        const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+        st_b = b;
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) {
+            const int pos = pos_tab[i * 256 + tid];
+            const int iy = oy0 + ((pos >> 5) & 31) - 1, ix = ox0 + (pos & 31) - 1;
+            const bool ok = pos >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            hv_pix[i] = ok ? (b * p.Hin + iy) * p.Win + ix : -1;
+        }
+    };
+    auto issue_all = [&](int chunk) __attribute__((always_inline)) {
+        const int c = chunk * BK + cv * 8;
+        st_cok = c < ctot;
+        const int cc = st_cok ? c : 0;
+        const bf16* src;
+        int cs;
+        if (cc < p.C0) { src = p.src0 + cc; cs = p.C0; }
+        else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
+        const f32x4* ab = p.gn_ab + (((size_t)st_b * ctot + cc) >> 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = ab[q];
+            abh[2 * q] = pack_h2(t[0], t[1]);
+            abh[2 * q + 1] = pack_h2(t[2], t[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) {
+            const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
+            hreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)pix * cs);
+        }
+    };
+    auto commit_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) {
+            const int pos = pos_tab[i * 256 + tid];
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] = __uint_as_float(hreg[i][k] << 16);
+                v[2 * k + 1] = __uint_as_float(hreg[i][k] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = silu_fast(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
+            u32x4 ou = __builtin_bit_cast(u32x4, o);
+            const bool live = st_cok && hv_pix[i] >= 0;         // zero padding stays zero (pad AFTER activation)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
+            if (pos >= 0) *reinterpret_cast<u32x4*>(halo + (pos >> 10)) = ou;
+        }
+    };
+
+    // ---- MFMA fragment bases: MFMA tile mr = tile rows 8 wm + 2 mr, +1; lane = (row lr/16, column lr%16) ------------------
+    int abase[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * 8 + mr * 2 + (lr >> 4)) * RP + (lr & 15) * PSTR + 8 * lh;
+    f32x16 acc[MR];
+
+    const int n = wn * 32 + lr;                                 // Cout == 64: every lane's cout exists
+    auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
+        float v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
+        return v;
+    };
+
+    // prologue: two weight steps in flight, raw vectors of (first item, chunk 0) requested
+    b_issue(ring[0]);
+    b_issue(ring[1]);
+    describe(item);
+    issue_all(0);
+    auto stage_advance = [&]() __attribute__((always_inline)) {
+        if (st_chunk + 1 < nch) st_chunk += 1;
+        else { st_chunk = 0; st_item += G; }
+        st_valid = st_item < p.total_items;
+    };
+
+    for (int it = 0; it < n_items_blk; ++it, item += G) {
+        HSIDM_STAMP(it, 0);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
+        const int b = item / tiles_per_img;
+        float ep_add = 0.f, ep_bias = 0.f;                      // landed by the epilogue (conv_v2.h: untracked loads)
+        if (p.film) ep_add = untracked_load(p.film + (size_t)b * p.film_stride + n);
+        if (p.bias) ep_bias = untracked_load(p.bias + n);
+
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            commit_all();                                       // hreg holds (item, chunk): transform -> LDS
+            if (chunk == 0) HSIDM_STAMP(it, 1);
+            stage_advance();
+            if (st_valid) {                                     // request the next chunk's raw vectors; they fly during the MFMAs
+                if (st_chunk == 0) describe(st_item);
+                issue_all(st_chunk);
+            }
+            if (chunk == 0) HSIDM_STAMP(it, 2);
+            lds_barrier();
+            if (chunk == 0) HSIDM_STAMP(it, 3);
+            bf16x8 a[3][MR];
+            auto a_fetch = [&](int u) __attribute__((always_inline)) {
+                const int tp = u >> 2, kq = u & 3;
+                const int off = (tp / 3) * RP + (tp % 3) * PSTR + kq * 16;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(halo + abase[mr] + off);
+            };
+            a_fetch(0);
+            a_fetch(1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                b_issue(ring[(tap + 2) % 3]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int u = tap * 4 + kk;
+                    if (u + 2 < 36) a_fetch(u + 2);
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (chunk == 0) HSIDM_STAMP(it, 4);
+            lds_barrier();                                      // every wave is done reading: the tile may be overwritten
+            if (chunk == 0) HSIDM_STAMP(it, 5);
+        }
+        HSIDM_STAMP(it, 12);
+
+        // ---- epilogue (conv_v2's vector epilogue; the halo buffer is free between the two barriers) ------------------------
+        const int tr = item - b * tiles_per_img;
+        const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add), "+v"(ep_bias));       // older than the 8 weight + 11 halo requests in flight
+        ep_add += ep_bias;
+        constexpr int SCR_STR = 40;
+        bf16* scr = halo + wave * (64 * SCR_STR);
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int pl0 = lane_e >> 2, cq = lane_e & 3;
+        const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
+        const unsigned lane_el = (unsigned)(pl0 * p.Cout + cq * 8);                // pass pixel (row v4, column pl0): row part is uniform
+        auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
+            constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
+            constexpr bool RES = decltype(res_tag)::value != 0;
+            bf16x8 rv[RES ? 4 : 1];
+            float vs1[8], vs2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
+#pragma unroll
+            for (int g = 0; g < MR; g += 2) {                                      // a pass = 4 tile rows x 16 columns
+                const int row0 = oy0 + wm * 8 + g * 2;
+                auto vec_base = [&](int v4) __attribute__((always_inline)) -> size_t {
+                    return (((size_t)b * p.Hout + row0 + v4) * p.Wout + ox0) * p.Cout + wn * 32;
+                };
+                if (RES) {
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(v4) + lane_el);
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int row = (j & 3) + 8 * (j >> 2);
+                        float v = acc[g + m2][j] + ep_add;
+                        if (LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
+                    }
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                    float f[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
+                    bf16x8 o = raw;
+                    if (RES) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            o[k] = (bf16)fmaf(p.res_scale, f[k], (float)rv[v4][k]);
+                            f[k] = (float)o[k];
+                        }
+                    }
+                    *reinterpret_cast<bf16x8*>(p.out + vec_base(v4) + lane_el) = o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                }
+            }
+            if (p.stats) {                                                          // one entry per (image, tile, pixel half)
+                const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
+                float a8[8], a4[4], a2[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a8[i] = (hi0 ? vs2[i] : vs1[i]) + __shfl_xor(hi0 ? vs1[i] : vs2[i], 4, 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a4[i] = (hi1 ? a8[i + 4] : a8[i]) + __shfl_xor(hi1 ? a8[i] : a8[i + 4], 8, 64);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a2[i] = (hi2 ? a4[i + 2] : a4[i]) + __shfl_xor(hi2 ? a4[i] : a4[i + 2], 16, 64);
+                const float a1 = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], 32, 64);
+                const int idx = ((lane_e >> 2) & 1) * 8 + ((lane_e >> 3) & 1) * 4 + ((lane_e >> 4) & 1) * 2 + (lane_e >> 5);
+                float* dst = reinterpret_cast<float*>(p.stats + ((size_t)b * (tiles_per_img * WM) + tr * WM + wm) * p.Cout + wn * 32);
+                dst[(cq * 8 + (idx & 7)) * 2 + (idx >> 3)] = a1;
+            }
+        };
+        if (p.act == ACT_LEAKY) { if (p.res) run(SlotTag<1>{}, SlotTag<1>{}); else run(SlotTag<1>{}, SlotTag<0>{}); }
+        else                    { if (p.res) run(SlotTag<0>{}, SlotTag<1>{}); else run(SlotTag<0>{}, SlotTag<0>{}); }
+        HSIDM_STAMP(it, 14);
+        lds_barrier();                                                              // the patch is the halo tile of the next commit
+        HSIDM_STAMP(it, 13);
+    }
+}
+
+static int g3_slots = 0;
+extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds)
+
+// Cout == 64, Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller)
+int conv_v3_run(ConvV2Params& p, hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)v3::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    if (g3_slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g3_slots = 2 * cus;
+    }
+    p.tiles_x = p.Wout / v3::TW;
+    p.tiles_y = p.Hout / v3::TH;
+    p.n_slices = 1;
+    p.m_tiles = p.B * p.tiles_x * p.tiles_y;
+    p.total_items = p.m_tiles;
+    p.up_m = 0;
+    p.abl = 0;
+    p.stamps = g_stamps;
+    int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;
+    if (G == 0) G = p.total_items;
+    hipLaunchKernelGGL(conv_v3_kernel, dim3(G), dim3(256), v3::LDS_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace hsidm

@@ -303,7 +303,10 @@ CONV_CASES = [  # B, H, W, C0, C1, Cout, ups, proj_cin, xf
     (2, 24, 40, 64, 32, 64, False, 0, True),      # concat input, BN=64, partial tiles
     (5, 8, 8, 128, 0, 96, False, 0, True),        # two-image tiles (odd batch), cout not a multiple of 32
     (2, 8, 16, 32, 0, 24, True, 0, False),        # nearest-x2 folded in, BN=32, no transform
-    (40, 16, 16, 64, 0, 64, False, 0, True),      # many items: persistent loop over tiles
+    (40, 16, 16, 64, 0, 64, False, 0, True),      # many items: persistent loop over tiles (16x16 tiles: conv_v3)
+    (3, 32, 48, 64, 0, 64, False, 0, True),       # conv_v3: 256-pixel tiles, one chunk
+    (2, 32, 32, 128, 64, 64, False, 0, True),     # conv_v3: concat input, three chunks
+    (1, 16, 32, 72, 0, 64, False, 0, True),       # conv_v3: channel count off the chunk grid
 ]
 
 
@@ -339,6 +342,36 @@ def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
         outs.append(yf.cpu())
     ops.set_use_v2(True)
     check("conv_v2_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=2e-3)
+
+
+def test_conv_v3_residual_and_dispatch(dev, monkeypatch):
+    """The 256-pixel kernel with a residual operand (ResnetBlock.block2 + x) against conv_v2 on the same inputs
+    (HSIDM_NO_V3=1), which the previous test ties to v1."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Ci, Co = 5, 32, 32, 64, 64
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    pk = ops.PackedConv(w.to(dev), torch.randn(Co, generator=g).to(dev), "bf16")
+    x = torch.randn(B, H, W, Ci, generator=g).to(dev, torch.bfloat16)
+    res = torch.randn(B, H, W, Co, generator=g).to(dev, torch.bfloat16)
+    ab = torch.stack([1 + 0.1 * torch.randn(B, Ci, generator=g), 0.1 * torch.randn(B, Ci, generator=g)], 2).contiguous().to(dev)
+    film = torch.randn(B, Co, generator=g).to(dev)
+    outs, slabs = [], []
+    for no_v3 in (True, False):
+        if no_v3:
+            monkeypatch.setenv("HSIDM_NO_V3", "1")
+        else:
+            monkeypatch.delenv("HSIDM_NO_V3")
+        y = ops.conv2d(x, pk, gn_ab=ab, transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
+        torch.cuda.synchronize()
+        slab, nsplit = y._hsidm_stats
+        yf = y.float()
+        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
+        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), no_v3
+        outs.append(yf.cpu())
+        slabs.append(nsplit)
+    assert slabs == [8 * 2, 4 * 2]                       # 8x16 tiles x 2 wave rows vs 16x16 tiles x 2 pixel halves
+    check("conv_v3_vs_v2_residual", "bf16", outs[1], outs[0], tol=2e-3)
 
 
 UP4_CASES = [  # B, H, W, Cin, Cout  (input grid)

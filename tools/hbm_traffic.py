@@ -24,6 +24,8 @@ def label(name):
     if m:
         bn, xf, im = map(int, m.groups())
         return "conv1x1_g bn%d 8x16 k%d s1%s" % (bn, 3 if im else 1, " gn" if xf == 1 else "")
+    if "conv_v3_kernel" in name:
+        return "conv_v3 bn64 8x16 k3 s1 gn+silu"
     return None
 
 

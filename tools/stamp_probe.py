@@ -56,6 +56,12 @@ def main():
         ep1 = a[:, :, 13][ok]
         pre = a[:, :, 10][ok]
         ch = [a[:, :, 1 + c][ok] for c in range(8) if (a[:, :, 1 + c][ok] > 0).all()]
+        if os.environ.get("HSIDM_PROBE_V3"):
+            e = lambda k: a[:, :, k][ok]
+            print("item %d: commit=%6.0f issue=%6.0f bar1=%6.0f mfma=%6.0f bar2=%6.0f | epilogue=%6.0f bar3=%6.0f | total=%6.0f" % (
+                it, np.median(e(1) - e(0)), np.median(e(2) - e(1)), np.median(e(3) - e(2)), np.median(e(4) - e(3)),
+                np.median(e(5) - e(4)), np.median(e(14) - e(12)), np.median(e(13) - e(14)), np.median(e(13) - e(0))))
+            continue
         line = "item %d: n=%4d  start@%8.0f  loop=%7.0f  (last pre-barrier->barrier %6.0f)  epilogue=%7.0f" % (
             it, ok.sum(), np.median(start - t0), np.median(ep0 - start), np.median(ep0 - pre), np.median(ep1 - ep0))
         e = lambda k: a[:, :, k][ok]
