@@ -157,6 +157,25 @@ def test_unet_full_size_golden(dev, prec):
     check("unet_full", prec, y, g["full.y"], tol={"fp32": 1e-3, "bf16": 8e-2}[prec])
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_unet_shipped_width_on_a_non_square_batch(dev, prec):
+    """The shipped channel plan (64-128-256-512-512, attention where the map is image_size/8) on a 3 x 6 x 64 x 96 batch:
+    every specialised kernel sees shapes other than the benchmark's (16x16 tiles on a 4x6 grid, parity-folded up/down
+    sampling of non-square maps, attention over 96 tokens on the panel kernel, two-image tiles with an odd batch), checked
+    against the oracle UNet on the CPU."""
+    from hsi_dmgasr_amd.sr3_modules import unet
+    from oracle import sr3_unet
+    cfg = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8], attn_res=[8],
+               res_blocks=1, image_size=64)
+    u = unet.UNet(dropout=0.2, precision=prec, **cfg).to(dev).eval()
+    sd = fill_synth(u, "unet_wide.")
+    x = synth_tensor("unet_wide.x", (3, 6, 64, 96))
+    gam = np.array([[0.8], [0.3], [0.02]], dtype=np.float32)
+    y = u(G(x, dev), G(gam, dev))
+    want = sr3_unet.unet_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(gam))
+    check("unet_wide_nonsquare", prec, y, want, tol={"fp32": 1e-3, "bf16": 8e-2}[prec])
+
+
 def test_philox_matches_oracle(dev):
     from hsi_dmgasr_amd import ops
     from oracle import philox
