@@ -16,6 +16,7 @@ HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 #undef HSIDM_DECL
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
+int conv_v2_slots();
 int conv_v3_run(ConvV2Params& p, hipStream_t s);
 void conv_v2_set_stamps(unsigned long long* p);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
@@ -87,6 +88,10 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     }
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
+        // 8x8 maps: two-image tiles halve the work items; when those would leave half of the co-resident workgroup slots
+        // empty, one-image 64-pixel tiles keep two workgroups on every CU at the same staging cost per pixel
+        if (path == PATH_V2 && tile_kind == 1 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 128 && Hout <= 8 && Wout <= 8 &&
+            (long long)d->B * ((d->Cout + 127) / 128) <= conv_v2_slots()) tile_kind = 2;
         // 64-cout GN+SiLU layers on whole 16x16 tiles: the 256-pixel kernel (conv_v3.hip); HSIDM_NO_V3=1: diagnostic A/B switch
         if (path == PATH_V2 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 64 && d->Cout == 64 && Hout % 16 == 0 &&
             Wout % 16 == 0 && !getenv("HSIDM_NO_V3")) path = PATH_V3;
@@ -110,7 +115,7 @@ extern "C" int hsidm_conv_kernel_id(const hsidm_conv_desc* d) {
     int Hout, Wout, tile_kind, path;
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
-    return path | ((path == PATH_G1 ? 0 : tile_kind) << 4) | (d->bn << 8);
+    return path | ((path == PATH_G1 ? 0 : tile_kind) << 4) | (d->bn << 8);      /* tile kinds: 0 8x16, 1 8x8 of two images, 2 8x8 of one */
 }
 
 extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {

@@ -66,8 +66,9 @@ struct V2Cfg {
     static constexpr bool UP4 = SP_ == 1, DN4 = SP_ == 2;
     static constexpr bool FR = SP_ != 0;                        // 4-tap chunks, fragment-granular weight ring
     static constexpr int NT = FR ? 4 : 9;                       // taps per channel chunk
-    static constexpr int BM = 128, BK = 64;
-    static_assert(TH * TW * NI == BM, "tile");
+    static constexpr int BM = TH * TW * NI, BK = 64;           // 128 pixels; 64 for the one-image 8x8 tile (maps of 8x8 pixels
+                                                                // at batches too small to fill the GPU with two-image tiles)
+    static_assert(BM == 128 || (BM == 64 && BN_ == 128), "tile");
     static constexpr int WN = BN / 32, WM = 4 / WN, MR = BM / WM / 32;
     static constexpr int HROWS = TH + 2, HCOLS = TW + 2, HPIX = HROWS * HCOLS;
     static constexpr int PSTR = BK + 8, VPP = BK / 8;

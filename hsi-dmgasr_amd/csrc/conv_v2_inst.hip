@@ -7,6 +7,8 @@ namespace hsidm {
 static int g_slots = 0;      // co-resident workgroups: 2 per CU
 unsigned long long* g_stamps = nullptr;   // diagnostic builds only
 
+int conv_v2_slots();
+
 template <typename C>
 static int run_v2(ConvV2Params& p, hipStream_t s) {
     constexpr size_t lds = C::LDS_BYTES;
@@ -18,13 +20,7 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    if (g_slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        const char* e = getenv("HSIDM_V2_WGS_PER_CU");       // diagnostic: 1 = one workgroup per CU (overlap experiments)
-        g_slots = ((e && e[0] == '1') ? 1 : 2) * cus;
-    }
+    conv_v2_slots();
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("HSIDM_V2_ABL"); abl = e ? atoi(e) : 0; }
     p.abl = abl;
@@ -48,7 +44,18 @@ void conv_v2_set_stamps(unsigned long long* p) { g_stamps = p; }
 
 int conv_v2_subs(int tile_kind, int bn) {
     const int wm = 4 / (bn / 32);
+    if (tile_kind == 2) return wm;                             // one-image 8x8 tile (bn = 128: one entry)
     return tile_kind == 0 ? wm : (wm >= 2 ? wm / 2 : 1);
+}
+
+int conv_v2_slots() {
+    if (g_slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g_slots = 2 * cus;
+    }
+    return g_slots;
 }
 
 #define V2(BN, TH, TW, NI, XF) run_v2<V2Cfg<BN, TH, TW, NI, XF>>(p, s)
@@ -65,6 +72,7 @@ int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s) {
     }
     if (xf != XF_NONE && xf != XF_AFFINE_SILU) return -2;
     const bool x = xf == XF_AFFINE_SILU;
+    if (tile_kind == 2) return (x && bn == 128) ? V2(128, 8, 8, 1, XF_AFFINE_SILU) : -2;
     if (tile_kind == 0) {
         switch (bn) {
             case 128: return x ? V2(128, 8, 16, 1, XF_AFFINE_SILU) : V2(128, 8, 16, 1, XF_NONE);

@@ -185,7 +185,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         k_total = pw.cin * (4 if folded else (16 if planes else pw.ksize * pw.ksize)) + pw.proj_cin      # multiplications actually executed
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
         label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "-", "conv1x1_g", "conv_v3")[kid & 15], kid >> 8,
-                                            "8x8x2" if (kid >> 4) & 1 else "8x16", pw.ksize, stride,
+                                            ("8x16", "8x8x2", "8x8")[(kid >> 4) & 3], pw.ksize, stride,
                                             " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else "") +
                                             (" up4" if folded else (" ups" if ups else (" dn4" if planes else ""))),
                                             " nchw" if pw.out_nchw else "")

@@ -19,7 +19,7 @@ def label(name):
         re.search(r"conv_v2_kernelINS_5V2CfgILi(\d+)ELi8ELi(\d+)ELi(\d)ELi(\d)ELi(\d)", name)
     if m:
         bn, tw, ni, xf, up4 = map(int, m.groups())
-        return "conv_v2 bn%d %s k3 s1%s" % (bn, "8x8x2" if ni == 2 else "8x16", " gn+silu" if xf == 2 else (" up4" if up4 == 1 else (" dn4" if up4 == 2 else "")))
+        return "conv_v2 bn%d %s k3 s1%s" % (bn, "8x8x2" if ni == 2 else ("8x16" if tw == 16 else "8x8"), " gn+silu" if xf == 2 else (" up4" if up4 == 1 else (" dn4" if up4 == 2 else "")))
     m = re.search(r"conv1x1_g_kernel<(\d+), (\d), (\d)>", name) or re.search(r"conv1x1_g_kernelILi(\d+)ELi(\d)ELi(\d)", name)
     if m:
         bn, xf, im = map(int, m.groups())
