@@ -144,13 +144,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             int m = set_m0[S] + 64 * h;
             m = m < p.M ? m : p.M - 1;
             const int b = m / p.HW;
-            const f32x4* ab = p.gn_ab + (((size_t)b * ctot + set_cc[S]) >> 1);
+            const int nb = p.M / p.HW;                          // fp16x2 half of the GroupNorm table (conv_v2.h: gn_params)
+            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * nb * ctot + (size_t)b * ctot + set_cc[S]);
+            const u32x4 lo = t[0], hi = t[1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = ab[q];
-                abh[h][2 * q] = pack_h2(t[0], t[1]);
-                abh[h][2 * q + 1] = pack_h2(t[2], t[3]);
-            }
+            for (int k = 0; k < 4; ++k) { abh[h][k] = lo[k]; abh[h][4 + k] = hi[k]; }
         }
     };
     auto commit = [&](int S, int i, int buf) __attribute__((always_inline)) {

@@ -248,6 +248,14 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                                    // transformed value is rounded to bf16 (8 bits) anyway; halves the registers held across taps
     bool st_cok = true;
     int st_c = 0, st_cs = 0, st_cl = 0, st_plane = 0;
+    // (scale, shift) of 8 consecutive channels of image b: two 16-byte loads from the fp16x2 half of the GroupNorm table
+    // (hsidm_gn_finalize writes it behind the fp32 pairs), consumed at commit time: nothing waits on them when they are requested
+    auto gn_params = [&](int b, int c) __attribute__((always_inline)) {
+        const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * p.B * ctot + (size_t)b * ctot + c);
+        const u32x4 lo = t[0], hi = t[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
+    };
     const bf16* st_src = p.src0;
     auto halo_begin = [&](int chunk) __attribute__((always_inline)) {
         // channel slice of the chunk being staged (+ its GroupNorm parameters).  Loads are UNCONDITIONAL (clamped
@@ -265,15 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         if (cc < p.C0) { st_src = p.src0; st_cs = p.C0; st_cl = cc; }
         else           { st_src = p.src1; st_cs = p.C1; st_cl = cc - p.C0; }
         st_c = cc;
-        if (C::XF != XF_NONE && NI == 1) {
-            const f32x4* ab = p.gn_ab + (((size_t)st_b0 * ctot + cc) >> 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = ab[q];
-                abh[2 * q] = pack_h2(t[0], t[1]);
-                abh[2 * q + 1] = pack_h2(t[2], t[3]);
-            }
-        }
+        if (C::XF != XF_NONE && NI == 1) gn_params(st_b0, cc);
     };
     auto halo_issue_one = [&](int i) __attribute__((always_inline)) {
         if (HSIDM_ABL(4)) return;
@@ -291,13 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         if (part == 0 && C::XF != XF_NONE && NI > 1 && !(HSIDM_ABL(2))) {
             const int img = (tid / VPP + i * (256 / VPP)) / HPIX;
             const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
-            const f32x4* ab = p.gn_ab + (((size_t)bb * ctot + st_c) >> 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = ab[q];
-                abh[2 * q] = pack_h2(t[0], t[1]);
-                abh[2 * q + 1] = pack_h2(t[2], t[3]);
-            }
+            gn_params(bb, st_c);
         }
         {
             const unsigned w = hreg[i % NH][part];

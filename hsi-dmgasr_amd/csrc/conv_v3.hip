@@ -96,12 +96,11 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         int cs;
         if (cc < p.C0) { src = p.src0 + cc; cs = p.C0; }
         else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
-        const f32x4* ab = p.gn_ab + (((size_t)st_b * ctot + cc) >> 1);
+        {   // fp16x2 half of the GroupNorm table (conv_v2.h: gn_params)
+            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * p.B * ctot + (size_t)st_b * ctot + cc);
+            const u32x4 lo = t[0], hi = t[1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t = ab[q];
-            abh[2 * q] = pack_h2(t[0], t[1]);
-            abh[2 * q + 1] = pack_h2(t[2], t[3]);
+            for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
         }
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {

@@ -113,7 +113,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
     if (t < cw) {
         const int c = c0 + t, g = t / cpg;
         const float sc = gr[g] * gamma[c];
-        ab[(size_t)b * C + c] = make_float2(sc, beta[c] - gm[g] * sc);
+        const float sh = beta[c] - gm[g] * sc;
+        ab[(size_t)b * C + c] = make_float2(sc, sh);
+        // second half of the table: the same pair as fp16x2, the form the bf16 conv kernels consume (no conversion, and no
+        // wait on a parameter load, between requesting a chunk and staging it)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 hh = {(_Float16)sc, (_Float16)sh};
+        reinterpret_cast<unsigned*>(ab + (size_t)gridDim.y * C)[(size_t)b * C + c] = __builtin_bit_cast(unsigned, hh);
     }
 }
 

@@ -349,7 +349,7 @@ def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
     outs = []
     for use_v2 in (False, True):
         ops.set_use_v2(use_v2)
-        y = ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=ops.XF_AFFINE_SILU if xf else ops.XF_NONE,
+        y = ops.conv2d(x0, pk, x1=x1, gn_ab=ops.gn_table(ab) if xf else None, transform=ops.XF_AFFINE_SILU if xf else ops.XF_NONE,
                        film=film, ups=ups, proj_x0=px, stats=True)
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
@@ -381,7 +381,7 @@ def test_conv_v3_residual_and_dispatch(dev, monkeypatch):
             monkeypatch.setenv("HSIDM_NO_V3", "1")
         else:
             monkeypatch.delenv("HSIDM_NO_V3")
-        y = ops.conv2d(x, pk, gn_ab=ab, transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
+        y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab), transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
         yf = y.float()
@@ -535,7 +535,7 @@ def test_conv1x1_gemm_kernels_match_v1(dev, case):
     outs = []
     for use_v2 in (False, True):
         ops.set_use_v2(use_v2)
-        y = ops.conv2d(x0, pk, x1=x1, res=res, stats=True, gn_ab=ab if affine else None,
+        y = ops.conv2d(x0, pk, x1=x1, res=res, stats=True, gn_ab=ops.gn_table(ab) if affine else None,
                        transform=ops.XF_AFFINE if affine else ops.XF_NONE)
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats

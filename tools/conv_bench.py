@@ -70,7 +70,7 @@ def main():
         x0 = torch.randn(B, H, H, C0, generator=g).to(dev, dt)
         x1 = torch.randn(B, H, H, C1, generator=g).to(dev, dt) if C1 else None
         px = torch.randn(B, H, H, pj, generator=g).to(dev, dt) if pj else None
-        ab = torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev)
+        ab = ops.gn_table(torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev))
         xf = ops.XF_AFFINE_SILU if (ks == 3 and st == 1 and not up and not args.no_xf and C0 > 8) else ops.XF_NONE
         best = 1e9
         for _ in range(args.reps + 1):

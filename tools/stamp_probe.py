@@ -30,7 +30,7 @@ def main():
     pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), "bf16")
     x0 = torch.randn(B, H, H, C0, generator=g).to(dev, torch.bfloat16)
     x1 = torch.randn(B, H, H, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
-    ab = torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev)
+    ab = ops.gn_table(torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev))
     xf = ops.XF_AFFINE_SILU if not up else ops.XF_NONE
     stamps = torch.zeros(512 * 4 * 8 * 16, dtype=torch.int64, device=dev)
     L = _lib.lib()
