@@ -11,5 +11,5 @@ for pass in "$p1" "$p2" "$p3"; do
   i=$((i+1))
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out/pass$i -o p -- python tools/conv_bench.py --batch $batch --reps 1 --only $shape > $out.log 2>&1
   f=$(find $out/pass$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -A12 "conv_v2\|conv1x1\|conv<"
+  [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -A12 "conv_v\|conv1x1\|conv<"
 done
