@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         // ---- epilogue: buffer 1 is free (the last chunk of an item has odd parity), buffer 0 holds the next item's chunk 0
         const int m0 = (item / p.n_slices) * 128;
         bf16* scr = xt + TILE + wave * (64 * SCR_STR);
-        int lane_e = lane;
+        int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
         const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
@@ -292,12 +292,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                     const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
                     float a8[8], a4[4], a2[2];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) a8[i] = (hi0 ? vs2[i] : vs1[i]) + __shfl_xor(hi0 ? vs1[i] : vs2[i], 4, 64);
+                    for (int i = 0; i < 8; ++i) a8[i] = (hi0 ? vs2[i] : vs1[i]) + lane_xor<4>(hi0 ? vs1[i] : vs2[i], lane_e);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a4[i] = (hi1 ? a8[i + 4] : a8[i]) + __shfl_xor(hi1 ? a8[i] : a8[i + 4], 8, 64);
+                    for (int i = 0; i < 4; ++i) a4[i] = (hi1 ? a8[i + 4] : a8[i]) + lane_xor<8>(hi1 ? a8[i] : a8[i + 4], lane_e);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a2[i] = (hi2 ? a4[i + 2] : a4[i]) + __shfl_xor(hi2 ? a4[i] : a4[i + 2], 16, 64);
-                    const float a1 = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], 32, 64);
+                    for (int i = 0; i < 2; ++i) a2[i] = (hi2 ? a4[i + 2] : a4[i]) + lane_xor<16>(hi2 ? a4[i] : a4[i + 2], lane_e);
+                    const float a1 = (hi3 ? a2[1] : a2[0]) + lane_xor<32>(hi3 ? a2[0] : a2[1], lane_e);
                     const int idx = ((lane_e >> 2) & 1) * 8 + ((lane_e >> 3) & 1) * 4 + ((lane_e >> 4) & 1) * 2 + (lane_e >> 5);
                     const int grp = mp >> 6;                           // 64-pixel group: image = grp / (HW/64)
                     float* dst = reinterpret_cast<float*>(p.stats + (size_t)grp * p.Cout + n0 + wn * 32);

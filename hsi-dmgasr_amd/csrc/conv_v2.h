@@ -131,6 +131,23 @@ __device__ __forceinline__ float silu_fast(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
 }
 
+// Lane id recomputed where it is needed.  `volatile` keeps the two instructions in place: the builtin form is loop-invariant,
+// so the compiler hoisted it, then spilled the result and paid an s_waitcnt vmcnt(0) for every reload.
+__device__ __forceinline__ int lane_id_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// value of lane (l ^ M).  M < 32: ds_swizzle in bit-mask mode (the pattern is an immediate: no address register; the address
+// registers of __shfl_xor were hoisted out of the item loop, spilled, and reloaded behind the epilogue's stores).  M = 32: one
+// ds_bpermute with the address built from the caller's (freshly recomputed) lane id.
+template <int M>
+__device__ __forceinline__ float lane_xor(float v, int lane_now) {
+    if (M < 32) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (M << 10) | 0x1f));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane_now ^ 32) << 2, __float_as_int(v)));
+}
+
 template <typename C>
 __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
@@ -367,7 +384,6 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     // the values have long landed when the epilogue's own `s_waitcnt vmcnt(4)` names them.
     const int n = n0 + wn * 32 + lr;
     const bool nok = n < p.Cout;
-    const int nn = nok ? n : 0;
     auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
         float v;
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
@@ -382,6 +398,12 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
         float ep_add[NI], ep_bias = 0.f;                       // landed by the epilogue (see above)
         {
+            // the lane's channel is recomputed from the hardware lane id here: kept as a loop-invariant 64-bit address
+            // (p.film + n, p.bias + n) it was spilled, and each reload cost an s_waitcnt vmcnt(0) at the start of every item
+            int lane_s = lane_id_now();
+            asm volatile("" : "+v"(lane_s));
+            const int n_s = n0 + wn * 32 + (lane_s & 31);
+            const int nn = n_s < p.Cout ? n_s : 0;
             int par_;
             const int fb0 = (item_tile(item, par_) / tiles_per_img) * NI;
 #pragma unroll
@@ -484,12 +506,9 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             constexpr int SCR_STR = 40;                                       // bf16 per pixel row: 32 couts + 16 B pad
             constexpr int NV = 2 * MR;                                        // 16-B vectors per lane and item
             bf16* scr = halo + (cur ^ 1) * C::HALO_ELEMS + wave * (64 * SCR_STR);
-            // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU)
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));                                 // keep these lane constants out of the main loop's registers
-            const int pl0 = lane_e >> 2, cq = lane_e & 3;
-            const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
-            const unsigned lane_el = (unsigned)((US * (pl0 >> LTW) * p.Wout + US * (pl0 & (TW - 1))) * p.Cout + cq * 8);
+            // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU).  The lane
+            // constants are rebuilt from the hardware lane id at the top of every pass: kept across the passes they were
+            // spilled, and each reload was an s_waitcnt vmcnt(0) behind the previous pass's output stores.
             auto vec_base = [&](int g, int v4) __attribute__((always_inline)) -> size_t {
                 const int pbase = wm * (C::BM / WM) + g * 32;
                 const int img = pbase / (TH * TW);
@@ -508,6 +527,11 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     const int pbase = wm * (C::BM / WM) + g * 32;
                     const int img = pbase / (TH * TW);                         // a pass never straddles two images
                     const int b = b0 + img;
+                    int lane_e = lane_id_now();
+                    asm volatile("" : "+v"(lane_e));
+                    const int pl0 = lane_e >> 2, cq = lane_e & 3;
+                    const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
+                    const unsigned lane_el = (unsigned)((US * (pl0 >> LTW) * p.Wout + US * (pl0 & (TW - 1))) * p.Cout + cq * 8);
                     if (RES) {                                                 // requested first: the latency hides behind the transposition
 #pragma unroll
                         for (int v4 = 0; v4 < 4; ++v4)
@@ -559,14 +583,14 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                         float a8[8], a4[4], a2[2];
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            a8[i] = (hi0 ? vs2[i] : vs1[i]) + __shfl_xor(hi0 ? vs1[i] : vs2[i], 4, 64);
+                            a8[i] = (hi0 ? vs2[i] : vs1[i]) + lane_xor<4>(hi0 ? vs1[i] : vs2[i], lane_e);
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            a4[i] = (hi1 ? a8[i + 4] : a8[i]) + __shfl_xor(hi1 ? a8[i] : a8[i + 4], 8, 64);
+                            a4[i] = (hi1 ? a8[i + 4] : a8[i]) + lane_xor<8>(hi1 ? a8[i] : a8[i + 4], lane_e);
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            a2[i] = (hi2 ? a4[i + 2] : a4[i]) + __shfl_xor(hi2 ? a4[i] : a4[i + 2], 16, 64);
-                        const float a1 = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], 32, 64);
+                            a2[i] = (hi2 ? a4[i + 2] : a4[i]) + lane_xor<16>(hi2 ? a4[i] : a4[i + 2], lane_e);
+                        const float a1 = (hi3 ? a2[1] : a2[0]) + lane_xor<32>(hi3 ? a2[0] : a2[1], lane_e);
                         int sub;
                         if (NI == 1) sub = wm;
                         else if (WM == 1) sub = 0;

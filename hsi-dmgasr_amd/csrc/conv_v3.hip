@@ -163,8 +163,13 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
         const int b = item / tiles_per_img;
         float ep_add = 0.f, ep_bias = 0.f;                      // landed by the epilogue (conv_v2.h: untracked loads)
-        if (p.film) ep_add = untracked_load(p.film + (size_t)b * p.film_stride + n);
-        if (p.bias) ep_bias = untracked_load(p.bias + n);
+        {   // lane's channel from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
+            int lane_s = lane_id_now();
+            asm volatile("" : "+v"(lane_s));
+            const int n_s = wn * 32 + (lane_s & 31);
+            if (p.film) ep_add = untracked_load(p.film + (size_t)b * p.film_stride + n_s);
+            if (p.bias) ep_bias = untracked_load(p.bias + n_s);
+        }
 
         for (int chunk = 0; chunk < nch; ++chunk) {
             commit_all();                                       // hreg holds (item, chunk): transform -> LDS
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         ep_add += ep_bias;
         constexpr int SCR_STR = 40;
         bf16* scr = halo + wave * (64 * SCR_STR);
-        int lane_e = lane;
+        int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
         const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
@@ -266,12 +271,12 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
                 float a8[8], a4[4], a2[2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a8[i] = (hi0 ? vs2[i] : vs1[i]) + __shfl_xor(hi0 ? vs1[i] : vs2[i], 4, 64);
+                for (int i = 0; i < 8; ++i) a8[i] = (hi0 ? vs2[i] : vs1[i]) + lane_xor<4>(hi0 ? vs1[i] : vs2[i], lane_e);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a4[i] = (hi1 ? a8[i + 4] : a8[i]) + __shfl_xor(hi1 ? a8[i] : a8[i + 4], 8, 64);
+                for (int i = 0; i < 4; ++i) a4[i] = (hi1 ? a8[i + 4] : a8[i]) + lane_xor<8>(hi1 ? a8[i] : a8[i + 4], lane_e);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a2[i] = (hi2 ? a4[i + 2] : a4[i]) + __shfl_xor(hi2 ? a4[i] : a4[i + 2], 16, 64);
-                const float a1 = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], 32, 64);
+                for (int i = 0; i < 2; ++i) a2[i] = (hi2 ? a4[i + 2] : a4[i]) + lane_xor<16>(hi2 ? a4[i] : a4[i + 2], lane_e);
+                const float a1 = (hi3 ? a2[1] : a2[0]) + lane_xor<32>(hi3 ? a2[0] : a2[1], lane_e);
                 const int idx = ((lane_e >> 2) & 1) * 8 + ((lane_e >> 3) & 1) * 4 + ((lane_e >> 4) & 1) * 2 + (lane_e >> 5);
                 float* dst = reinterpret_cast<float*>(p.stats + ((size_t)b * (tiles_per_img * WM) + tr * WM + wm) * p.Cout + wn * 32);
                 dst[(cq * 8 + (idx & 7)) * 2 + (idx >> 3)] = a1;
