@@ -136,11 +136,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         if (XF == XF_NONE || !set_ok[S]) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 1 && p.HW >= 128) {                        // a 128-pixel tile inside one image: one parameter set
-#pragma unroll
-                for (int k = 0; k < 8; ++k) abh[1][k] = abh[0][k];
-                break;
-            }
             int m = set_m0[S] + 64 * h;
             m = m < p.M ? m : p.M - 1;
             const int b = m / p.HW;
@@ -207,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             auto body = [&](auto par_tag) __attribute__((always_inline)) {
                 constexpr int PAR = decltype(par_tag)::value;
                 const bf16* hb = xt + PAR * TILE;
-                issue(PAR);
-                params_fetch(PAR ^ 1);
+                params_fetch(PAR ^ 1);                          // before the data requests: a later wait for the parameters then
+                issue(PAR);                                     // leaves those (and the weight ring) in flight
                 bf16x8 a[3][MR];
                 auto a_fetch = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
