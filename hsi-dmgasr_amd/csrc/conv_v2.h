@@ -251,9 +251,12 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const bool up = !FR && p.ups;
         const int hlim = DN4 ? p.Hout : (up ? 2 * p.Hin : p.Hin), wlim = DN4 ? p.Wout : (up ? 2 * p.Win : p.Win);
         const int sh = up ? 1 : 0;
+        int posv[MAXHV];                                        // all table reads first: one LDS round trip instead of MAXHV
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * 256 + tid];
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int pos = pos_tab[i * 256 + tid];
+            const int pos = posv[i];
             const int b = b0 + (pos >> 16);
             const int iy = oy0 + ((pos >> 8) & 255) - 1, ix = ox0 + (pos & 255) - 1;
             const bool ok = pos >= 0 && b < p.B && (unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim;

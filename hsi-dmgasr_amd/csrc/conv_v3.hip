@@ -80,9 +80,12 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int tr = it - b * tiles_per_img;
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
         st_b = b;
+        int posv[MAXHV];                                        // all table reads first: one LDS round trip instead of eleven
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * 256 + tid];
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int pos = pos_tab[i * 256 + tid];
+            const int pos = posv[i];
             const int iy = oy0 + ((pos >> 5) & 31) - 1, ix = ox0 + (pos & 31) - 1;
             const bool ok = pos >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             hv_pix[i] = ok ? (b * p.Hin + iy) * p.Win + ix : -1;
@@ -108,10 +111,16 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             hreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)pix * cs);
         }
     };
+    // dead slots of the last (partial) vector round store into the row padding instead of being branched around, so the
+    // eleven transforms form one basic block the scheduler can interleave (conv_v2.h: dead_off)
+    const int dead_off = (tid % HROWS) * RP + HCOLS * PSTR + ((tid >> 5) % ((RP - HCOLS * PSTR) / 8)) * 8;
     auto commit_all = [&]() __attribute__((always_inline)) {
+        int posv[MAXHV];                                        // table reads before the first halo store (they may alias for the compiler)
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * 256 + tid];
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
-            const int pos = pos_tab[i * 256 + tid];
+            const int pos = posv[i];
             float v[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             const bool live = st_cok && hv_pix[i] >= 0;         // zero padding stays zero (pad AFTER activation)
 #pragma unroll
             for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
-            if (pos >= 0) *reinterpret_cast<u32x4*>(halo + (pos >> 10)) = ou;
+            *reinterpret_cast<u32x4*>(halo + (pos >= 0 ? (pos >> 10) : dead_off)) = ou;
         }
     };
 
