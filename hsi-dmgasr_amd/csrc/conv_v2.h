@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         return mt >> 2;
     };
     int wnext = 0;                                              // step (within an item) of the next weight fetch
-    int w_item = item, w_base = 0;                              // UP4: item the ring fetches for, first step of its parity
+    int w_base = 0, w_base_nx = 0;                              // UP4: first weight step of the parity of the item the ring fetches for /
+                                                                // of the item after it (set at every item start: no division in f_issue)
     if (UP4) { int par; item_tile(item, par); w_base = par * p.steps_per_item; }
     auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
         const bf16* src = wlane + (size_t)wnext * wstep_stride;
@@ -205,10 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         if (kk == 3) {
             if (wnext + 1 == p.steps_per_item) {
                 wnext = 0;
-                w_item += G;
-                int par;
-                item_tile(w_item < p.total_items ? w_item : (int)blockIdx.x, par);
-                w_base = par * p.steps_per_item;
+                w_base = w_base_nx;
             } else wnext += 1;
         }
     };
@@ -416,6 +414,11 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 if (p.film) ep_add[q] = untracked_load(p.film + (size_t)fb * p.film_stride + nn);
             }
             if (p.bias) ep_bias = untracked_load(p.bias + nn);
+        }
+        if (UP4) {                                             // the ring wraps to the next item's weights during this item
+            int par_nx;
+            item_tile(item + G < p.total_items ? item + G : (int)blockIdx.x, par_nx);
+            w_base_nx = par_nx * p.steps_per_item;
         }
         int par = 0;
         const int it_tile = item_tile(item, par);
