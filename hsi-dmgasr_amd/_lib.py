@@ -59,6 +59,9 @@ SIGNATURES = {
     "hsidm_resample_axis": [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp],
     "hsidm_minmax_workspace_bytes": [_i32],
     "hsidm_minmax_normalize": [_vp, _vp, _i32, _i64, _vp, _vp],
+    "hsidm_augment": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "hsidm_color_correction_workspace_bytes": [_i32, _i32],
+    "hsidm_color_correction": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
 }
 
 _lib = None

@@ -1,5 +1,6 @@
-"""Patch preparation on the device: min-max normalisation and the MATLAB-compatible bicubic x1/n, xn pair that turns a
-ground-truth cube into the network's inputs (reference HStest.py:37-60, HStrain.py:49-70, imsize.py:35-158).
+"""Patch preparation on the device: min-max normalisation, the MATLAB-compatible bicubic x1/n, xn pair that turns a
+ground-truth cube into the network's inputs (reference HStest.py:37-60, HStrain.py:49-70, imsize.py:35-158) and the
+training set's crop + 8-way augmentation (HStrain.py:51-82, utils.py:3-28).
 
 The tap tables are host arithmetic (float64, once per length pair, cached on the device); the resampling itself runs in
 csrc/degrade.hip through hsidm_resample_axis / hsidm_minmax_normalize.  Cubes are NCHW fp32 device tensors [P, C, H, W].
@@ -92,3 +93,42 @@ def minmax_normalize(x):
     out = torch.empty_like(x)
     _lib.check(L.hsidm_minmax_normalize(_lib.ptr(x), _lib.ptr(out), P, x.numel() // P, _lib.ptr(ws), _lib.stream_ptr()), "minmax_normalize")
     return out
+
+
+def augment(x, mode):
+    """One of the 8 training augmentations (utils.py:3-28) on the spatial axes of x [..., H, W]: 0 identity, 1 flipud,
+    2 rot90, 3 flipud(rot90), 4 rot180, 5 flipud(rot180), 6 rot270, 7 flipud(rot270); quarter turns swap H and W."""
+    mode = int(mode)
+    if not 0 <= mode <= 7:
+        raise ValueError("augmentation mode %r: the reference defines modes 0..7 (utils.py:3-28)" % (mode,))
+    x = x.to(torch.float32).contiguous()
+    H, W = x.shape[-2], x.shape[-1]
+    oh, ow = (W, H) if mode in (2, 3, 6, 7) else (H, W)
+    out = torch.empty(x.shape[:-2] + (oh, ow), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsidm_augment(_lib.ptr(x), _lib.ptr(out), x.numel() // (H * W), H, W, mode, _lib.stream_ptr()), "augment")
+    return out
+
+
+def training_items(cubes, rows, cols, modes, n_scale=4, lr_size=32, normalize=True):
+    """HSTrainingData.__getitem__ (HStrain.py:26-82) for a batch: cubes [P, C, H, W] raw; per item p a crop origin
+    (rows[p], cols[p]) and an augmentation mode.  Returns {'HR', 'SR', 'LR'} as the reference's dict: HR = the
+    gt_size = lr_size * n_scale crop, LR = its bicubic x1/n, SR = LR resized back, all three augmented the same way,
+    LR and SR clamped to [0, 1] (the crop origins and modes are the caller's random draws, HStrain.py:53-55, 28-31)."""
+    gt_all = minmax_normalize(cubes) if normalize else cubes.to(torch.float32).contiguous()
+    size = lr_size * n_scale
+    P, C, H, W = gt_all.shape
+    if len(rows) != P or len(cols) != P or len(modes) != P:
+        raise ValueError("training_items: one (row, col, mode) per cube")
+    for r, c in zip(rows, cols):
+        if not (0 <= r <= H - size and 0 <= c <= W - size):
+            raise ValueError("crop origin (%d, %d) outside a %dx%d cube for a %d-pixel patch" % (r, c, H, W, size))
+    gt = torch.stack([gt_all[p, :, rows[p]:rows[p] + size, cols[p]:cols[p] + size] for p in range(P)]).contiguous()
+    ms = imresize(gt, (lr_size, lr_size))
+    lms = imresize(ms, (size, size), clamp01=True)           # made from the unclamped LR, as HStrain.py:60-62 does
+    ms = ms.clamp_(0.0, 1.0)
+    out = {"HR": [], "SR": [], "LR": []}
+    for p in range(P):
+        out["HR"].append(augment(gt[p], modes[p]))
+        out["SR"].append(augment(lms[p], modes[p]))
+        out["LR"].append(augment(ms[p], modes[p]))
+    return {k: torch.stack(v) for k, v in out.items()}

@@ -33,3 +33,23 @@ def as_dicts(table):
     """[P, 5] tensor -> list of {name: float} (one host synchronisation)."""
     rows = table.detach().cpu().tolist()
     return [dict(zip(NAMES, r)) for r in rows]
+
+
+def color_correction(guide, pred, num_channels=None):
+    """eval_hsi.py:259-274 (caller sr_gae.py:340): match each band of pred [P, C, H, W] to the mean and (population)
+    standard deviation of the same band of guide [P, C, h, w], clip to [0, 1].  Bands >= num_channels come back zero, as the
+    reference leaves them; None corrects every band."""
+    if guide.dim() != 4 or pred.dim() != 4 or guide.shape[:2] != pred.shape[:2]:
+        raise ValueError("expected guide [P, C, h, w] and pred [P, C, H, W], got %s and %s" % (tuple(guide.shape), tuple(pred.shape)))
+    guide = guide.to(torch.float32).contiguous()
+    pred = pred.to(torch.float32).contiguous()
+    P, C, H, W = pred.shape
+    nch = C if num_channels is None else int(num_channels)
+    if nch > C:
+        raise IndexError("num_channels %d exceeds the cube's %d bands" % (nch, C))   # the reference indexes band c and raises
+    L = _lib.lib()
+    ws = torch.empty(L.hsidm_color_correction_workspace_bytes(P, C) // 8, dtype=torch.float64, device=pred.device)
+    out = torch.empty_like(pred)
+    _lib.check(L.hsidm_color_correction(_lib.ptr(guide), guide.shape[2] * guide.shape[3], _lib.ptr(pred), _lib.ptr(out), P, C, H * W, nch,
+                                        _lib.ptr(ws), _lib.stream_ptr()), "color_correction")
+    return out

@@ -227,6 +227,17 @@ int hsidm_resample_axis(const float* src, float* dst, int64_t outer, int in_len,
 /* out = (x - min) / (max - min) per cube, x [P][n] fp32; workspace: hsidm_minmax_workspace_bytes(P) bytes. */
 int hsidm_minmax_workspace_bytes(int P);
 int hsidm_minmax_normalize(const float* x, float* out, int P, int64_t n, void* workspace, void* stream);
+/* The 8 training-set augmentations of utils.py:3-28 (caller HStrain.py:65) on the two spatial axes of src [outer][H][W]:
+ * mode 0 identity, 1 flipud, 2 rot90 (counter-clockwise), 3 flipud(rot90), 4 rot180, 5 flipud(rot180), 6 rot270,
+ * 7 flipud(rot270).  dst is [outer][H][W] for modes 0, 1, 4, 5 and [outer][W][H] for 2, 3, 6, 7; dst != src. */
+int hsidm_augment(const float* src, float* dst, int64_t outer, int H, int W, int mode, void* stream);
+/* Per-band mean / standard-deviation matching (eval_hsi.py:259-274, caller sr_gae.py:340):
+ * out[p][c] = clip((x[p][c] - mean x) / std x * std guide + mean guide, 0, 1) for c < num_channels, 0 for the other
+ * bands (as the reference leaves them).  guide [P][C][guide_HW], x and out [P][C][HW], NCHW fp32; population standard
+ * deviation.  workspace: hsidm_color_correction_workspace_bytes(P, C) bytes. */
+int hsidm_color_correction_workspace_bytes(int P, int C);
+int hsidm_color_correction(const float* guide, int guide_HW, const float* x, float* out, int P, int C, int HW,
+                           int num_channels, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

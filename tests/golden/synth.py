@@ -55,3 +55,12 @@ def imresize_input(tag):
     """(H, W, C) float32 cube in [0, 1) for the resize goldens (imresize.npz)."""
     shape, _ = IMRESIZE_CASES[tag]
     return (np.abs(synth_tensor("imresize_%s" % tag, shape)) % 1.0).astype(np.float32)
+
+
+AUGMENT_SHAPE = (6, 9, 3)
+COLOR_CASES = {"a/all": 31, "b/all": 8, "b/first5": 5}     # metric_pair tag / label -> num_channels
+
+
+def augment_input():
+    """(H, W, C) float32, non-square so that quarter turns are visible in the shape (augment.npz)."""
+    return synth_tensor("augment.x", AUGMENT_SHAPE).astype(np.float32)

@@ -5,7 +5,8 @@ import os
 import numpy as np
 import torch
 
-from synth import IMRESIZE_CASES, METRIC_CASES, imresize_input, metric_pair, synth_param, synth_tensor  # noqa: F401  tests/golden/synth.py (path added by conftest)
+from synth import (AUGMENT_SHAPE, COLOR_CASES, IMRESIZE_CASES, METRIC_CASES, augment_input, imresize_input, metric_pair,
+                   synth_param, synth_tensor)  # noqa: F401  tests/golden/synth.py (path added by conftest)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

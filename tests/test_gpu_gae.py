@@ -171,3 +171,67 @@ def test_validation_iteration_end_to_end(dev):
     assert abs(got["mpsnr"] - om.mpsnr(gt, yy)) < 0.01 and abs(got["sam"] - om.sam_degrees(gt, yy)) < 0.01
     assert abs(got["rmse"] - om.rmse(gt, yy)) < 1e-4 and abs(got["cc"] - om.cross_correlation(gt, yy)) < 1e-3
     assert abs(base[0, 0].item() - om.mpsnr(gt, lms)) < 1e-3                    # bicubic baseline row
+
+
+def test_augmentation_on_device(dev):
+    """hsidm_augment against outputs of the reference's utils.data_augmentation: bit-exact, every mode, non-square planes."""
+    from helpers import augment_input
+    from hsi_dmgasr_amd import degrade
+    g = load_npz("augment.npz")
+    x = torch.from_numpy(augment_input().transpose(2, 0, 1).copy()).to(dev)         # (C, H, W)
+    for mode in range(8):
+        got = degrade.augment(x, mode).cpu().numpy().transpose(1, 2, 0)
+        assert got.shape == g["aug.%d" % mode].shape and np.array_equal(got, g["aug.%d" % mode])
+    batch = torch.randn(3, 5, 32, 48, device=dev)
+    for mode in range(8):                                                          # batched, larger, against numpy directly
+        want = np.stack([np.stack([{0: lambda a: a, 1: np.flipud, 2: np.rot90, 3: lambda a: np.flipud(np.rot90(a)),
+                                    4: lambda a: np.rot90(a, 2), 5: lambda a: np.flipud(np.rot90(a, 2)),
+                                    6: lambda a: np.rot90(a, 3), 7: lambda a: np.flipud(np.rot90(a, 3))}[mode](c)
+                                   for c in cube]) for cube in batch.cpu().numpy()])
+        assert np.array_equal(degrade.augment(batch, mode).cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        degrade.augment(x, 8)
+
+
+def test_training_items_on_device(dev):
+    """degrade.training_items = HSTrainingData.__getitem__ (HStrain.py:26-82) for given crop origins and modes, against the same
+    chain assembled from the oracle pieces (min-max, crop, imresize pair, augmentation, clamps)."""
+    from hsi_dmgasr_amd import degrade
+    from oracle import augment as oa, imresize as oi
+    rng = np.random.default_rng(5)
+    raw = (rng.standard_normal((2, 4, 72, 80)) * 300 + 900).astype(np.float32)
+    rows, cols, modes = [3, 8], [11, 0], [6, 3]
+    got = degrade.training_items(torch.from_numpy(raw).to(dev), rows, cols, modes, n_scale=2, lr_size=32)
+    for p in range(2):
+        img = raw[p].transpose(1, 2, 0)
+        img = (img - img.min()) / (img.max() - img.min())
+        gt = img[rows[p]:rows[p] + 64, cols[p]:cols[p] + 64, :]
+        ms = oi.imresize(gt, (32, 32))
+        lms = oi.imresize(ms, (64, 64))
+        want = {"HR": oa.data_augmentation(gt, modes[p]), "SR": np.clip(oa.data_augmentation(lms, modes[p]), 0, 1),
+                "LR": np.clip(oa.data_augmentation(ms, modes[p]), 0, 1)}
+        for k in want:
+            err = np.abs(got[k][p].cpu().numpy() - want[k].transpose(2, 0, 1)).max()
+            assert err < 3e-6, (k, p, err)
+    with pytest.raises(ValueError):
+        degrade.training_items(torch.from_numpy(raw).to(dev), [9, 0], [0, 0], [0, 0], n_scale=2, lr_size=32)   # 9 + 64 > 72
+
+
+def test_color_correction_on_device(dev):
+    """hsidm_color_correction against outputs of the reference's eval_hsi.color_correction."""
+    from helpers import COLOR_CASES, metric_pair
+    from hsi_dmgasr_amd import metrics
+    g = load_npz("augment.npz")
+    for tag, nch in COLOR_CASES.items():
+        t, p = metric_pair(tag.split("/")[0])
+        tt = torch.from_numpy(t.transpose(2, 0, 1)[None].copy()).to(dev)
+        pp = torch.from_numpy(p.transpose(2, 0, 1)[None].copy()).to(dev)
+        got = metrics.color_correction(torch.cat([tt, tt.flip(1)]), torch.cat([pp, pp.flip(1)]), nch if nch != t.shape[2] else None)
+        want = g["cc.%s" % tag].transpose(2, 0, 1)
+        err = np.abs(got[0].cpu().numpy() - want).max()
+        log_err("color_correction." + tag, "fp32", float(err))
+        assert err < 2e-6
+        if nch == t.shape[2]:
+            assert np.abs(got[1].flip(0).cpu().numpy() - want).max() < 2e-6       # cubes of a batch are independent
+    with pytest.raises(IndexError):
+        metrics.color_correction(tt, pp, 99)
