@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             if (chunk == 0) HSIDM_STAMP(it, 2);
             lds_barrier();
             if (chunk == 0) HSIDM_STAMP(it, 3);
+            HSIDM_SETPRIO(1);
             bf16x8 a[3][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            HSIDM_SETPRIO(0);
             if (chunk == 0) HSIDM_STAMP(it, 4);
             lds_barrier();                                      // every wave is done reading: the tile may be overwritten
             if (chunk == 0) HSIDM_STAMP(it, 5);
