@@ -45,6 +45,7 @@ struct ConvV2Params {
     int tiles_x, tiles_y;
     int m_tiles, n_slices, total_items, steps_per_item;
     int up_m;               // UP4 kernels: XCDs per cout slice when the L2-friendly (tile, parity) order applies, else 0
+    int xcd_m;              // other kernels: XCDs per cout slice when each of them walks a contiguous range of pixel tiles, else 0
     unsigned long long* stamps;   // diagnostic build (HSIDM_V2_STAMPS): [block][wave][item<8][slot<16] s_memtime
     int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };
@@ -190,7 +191,9 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     // of ONE XCD (blocks b, b+8, b+16, b+24), so its L2 fetches the tile once.
     auto item_tile = [&](int it, int& par) __attribute__((always_inline)) -> int {
         const int mt = it / p.n_slices;
-        if (!UP4) { par = 0; return mt; }
+        // blocks of one XCD (b % 8) that share a cout slice hold tiles mt = x, x + m, x + 2m, ... (m = 8 / n_slices); re-ordered so
+        // that each XCD walks a contiguous range, neighbouring tiles - which share halo rows and columns - meet in one L2
+        if (!UP4) { par = 0; return p.xcd_m > 0 ? (mt % p.xcd_m) * (p.m_tiles / p.xcd_m) + mt / p.xcd_m : mt; }
         if (p.up_m > 0) { par = (mt / p.up_m) & 3; return (mt / (4 * p.up_m)) * p.up_m + mt % p.up_m; }
         par = mt & 3;
         return mt >> 2;

@@ -31,6 +31,10 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     p.m_tiles = C::UP4 ? 4 * tiles : tiles;
     p.up_m = 0;
     if (C::UP4 && 8 % p.n_slices == 0 && tiles % (8 / p.n_slices) == 0) p.up_m = 8 / p.n_slices;
+    static int no_xcd_map = -1;
+    if (no_xcd_map < 0) no_xcd_map = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
+    p.xcd_m = 0;
+    if (!C::UP4 && !no_xcd_map && 8 % p.n_slices == 0 && p.m_tiles % (8 / p.n_slices) == 0) p.xcd_m = 8 / p.n_slices;
     p.total_items = p.m_tiles * p.n_slices;
     int lcm = 8;
     while (lcm % p.n_slices) lcm += 8;

@@ -15,6 +15,7 @@
 //   * weights stream through conv_v2's 3-step register ring, epilogue / statistics / FiLM handling are conv_v2's.
 // Requirements (api.hip falls back to conv_v2 otherwise): Cout == 64, H % 16 == 0, W % 16 == 0, no upsampling.
 #include "conv_v2.h"
+#include <cstdlib>
 #include "../../include/hsidm.h"
 
 namespace hsidm {
@@ -75,7 +76,14 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     unsigned abh[8];
     int st_item = item, st_chunk = 0, st_b = 0;
     bool st_valid = true, st_cok = true;
-    auto describe = [&](int it) __attribute__((always_inline)) {
+    // work item -> pixel tile.  Blocks b, b+8, b+16, ... share an XCD (and its L2); with the identity map they would hold tiles
+    // 8 apart while the tiles in between - the ones that share their halo rows and columns - sit on the other seven XCDs.
+    // xcd_m = 8 when the tile count allows: XCD x walks the contiguous range [x*M/8, (x+1)*M/8), 64 neighbouring tiles at a time.
+    auto tile_of = [&](int it) __attribute__((always_inline)) -> int {
+        return p.xcd_m > 0 ? (it % p.xcd_m) * (p.m_tiles / p.xcd_m) + it / p.xcd_m : it;
+    };
+    auto describe = [&](int it_) __attribute__((always_inline)) {
+        const int it = tile_of(it_);
         const int b = it / tiles_per_img;
         const int tr = it - b * tiles_per_img;
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
@@ -170,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
-        const int b = item / tiles_per_img;
+        const int tile = tile_of(item);
+        const int b = tile / tiles_per_img;
         float ep_add = 0.f, ep_bias = 0.f;                      // landed by the epilogue (conv_v2.h: untracked loads)
         {   // lane's channel from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
             int lane_s = lane_id_now();
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         HSIDM_STAMP(it, 12);
 
         // ---- epilogue (conv_v2's vector epilogue; the halo buffer is free between the two barriers) ------------------------
-        const int tr = item - b * tiles_per_img;
+        const int tr = tile - b * tiles_per_img;
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
         asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add), "+v"(ep_bias));       // older than the 8 weight + 11 halo requests in flight
         ep_add += ep_bias;
@@ -325,6 +334,9 @@ int conv_v3_run(ConvV2Params& p, hipStream_t s) {
     p.m_tiles = p.B * p.tiles_x * p.tiles_y;
     p.total_items = p.m_tiles;
     p.up_m = 0;
+    static int no_xcd_map = -1;
+    if (no_xcd_map < 0) no_xcd_map = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
+    p.xcd_m = (p.m_tiles % 8 == 0 && !no_xcd_map) ? 8 : 0;
     p.abl = 0;
     p.stamps = g_stamps;
     int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;

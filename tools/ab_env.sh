@@ -1,0 +1,10 @@
+#!/bin/bash
+# In-box A/B of an environment switch of libhsidm.so on the headline benchmark:  STEPS=200 ROUNDS=3 bash tools/ab_env.sh HSIDM_NO_XCD_MAP=1
+steps=${STEPS:-200}; rounds=${ROUNDS:-3}
+for r in $(seq $rounds); do
+  for v in "" "$@"; do
+    if [ -z "$v" ]; then tag=default; run() { python bench.py --steps $steps --warmup 10 --no-cpu-baseline 2>/dev/null; }
+    else tag=$v; run() { env "$v" python bench.py --steps $steps --warmup 10 --no-cpu-baseline 2>/dev/null; }; fi
+    run | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('$tag', round(d['ms_per_step'],3), 'ms/step', round(d['value'],1))"
+  done
+done
