@@ -47,7 +47,7 @@ def build_model(dev, precision):
     return gd
 
 
-def conv_roofline(run, reps=3):
+def conv_roofline(run, batch, reps=3):
     """Roofline of the DOMINANT kernel of one step.  Every conv launch of one eager step is bracketed with HIP events
     on the launch stream (best of `reps`); launches are grouped by the kernel the C ABI dispatches to
     (hsidm_conv_kernel_id) and the group with the largest total time is reported:
@@ -79,6 +79,8 @@ def conv_roofline(run, reps=3):
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/README.md
     if os.path.exists(tf):
         traffic = json.load(open(tf)).get(name)
+        if traffic is not None and traffic.get("batch_per_gpu") not in (None, batch):
+            traffic = None                                      # counters were collected at another batch: not this run's traffic
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     # the launch closest to the HBM roof (north-star: "fraction of the HBM roofline on the fused ResnetBlock kernel"): a 3x3
     # GN+SiLU conv of the 128x128 level; algorithmic bytes = activations in + out + weights, against the 8 TB/s spec
@@ -152,9 +154,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--patches", type=int, default=24,
-                    help="CAVE patches per GPU (x5 spectral groups = batch); 24 fills the 512 workgroup slots of every UNet level "
-                         "(sweep in DESIGN.md)")
+    ap.add_argument("--patches", type=int, default=48,
+                    help="CAVE patches per GPU (x5 spectral groups = batch of 240 latents); throughput saturates around here: "
+                         "120 latents -3 %, 640 latents +2 % (sweep in DESIGN.md)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -212,7 +214,7 @@ def main():
 
         roof = None
         if rank == 0 and not args.no_roofline:
-            roof = conv_roofline(run)
+            roof = conv_roofline(run, batch)
     log('roofline done')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -13,7 +13,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cp $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $out/fetch.csv
 cp $(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $out/write.csv
-python tools/hbm_traffic.py $out/fetch.csv $out/write.csv > $out/hbm_traffic.json 2> $out/hbm.err
+batch=$(python -c "import json; print(json.loads(open('$out/bench.json').read().strip().splitlines()[-1])['config']['batch_per_gpu'])")
+python tools/hbm_traffic.py $out/fetch.csv $out/write.csv $batch > $out/hbm_traffic.json 2> $out/hbm.err
 rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 cat $out/bench.json | cut -c1-600
 head -30 $out/kernel_stats.csv | cut -c1-150
