@@ -12,7 +12,8 @@
 //     SiLUs / packs it into the other buffer in the shadow of that tap's MFMAs
 //     (nothing is consumed right after its load, so no wait drains the weight ring); one LDS-only
 //     barrier per chunk; A fragments are double-buffered across the four k-slices of a tap;
-//   * SiLU uses v_exp + v_rcp (5 VALU per element instead of an IEEE division);
+//   * SiLU uses v_exp + v_rcp on u = log2(e)*y, which the GroupNorm table delivers pre-scaled (silu_log2e: 4 VALU per
+//     element after the affine map instead of an IEEE division; the factor is removed from the accumulators);
 //   * the workgroup is persistent: it walks (pixel tile, cout slice) work items round-robin so the
 //     weight ring and the halo prefetch run across tile boundaries; a block always works on the same
 //     cout slice, and blocks sharing an XCD (blockIdx % 8) share that slice -> each L2 streams
@@ -139,6 +140,13 @@ __device__ __forceinline__ float h2_hi(unsigned u) { return (float)__builtin_bit
 __device__ __forceinline__ float silu_fast(float y) {
     // y * sigmoid(y) with v_exp_f32 / v_rcp_f32 (about 1e-6 relative; the result is rounded to bf16)
     return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+}
+// The staging transform works on u = log2(e) * y (the GroupNorm table's third part is pre-multiplied): u / (1 + 2^-u) =
+// log2(e) * y * sigmoid(y) without the multiplication that turns y into an exp2 argument - one VALU instruction less per
+// staged element, in kernels bound by VALU issue.  The factor leaves on the fp32 accumulators (epilogue: fma(acc, ln 2, bias)).
+constexpr float kLn2 = 0.693147181f;
+__device__ __forceinline__ float silu_log2e(float u) {
+    return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
 }
 
 // Lane id recomputed where it is needed.  `volatile` keeps the two instructions in place: the builtin form is loop-invariant,
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     // (scale, shift) of 8 consecutive channels of image b: two 16-byte loads from the fp16x2 half of the GroupNorm table
     // (hsidm_gn_finalize writes it behind the fp32 pairs), consumed at commit time: nothing waits on them when they are requested
     auto gn_params = [&](int b, int c) __attribute__((always_inline)) {
-        const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * p.B * ctot + (size_t)b * ctot + c);
+        const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)3 * p.B * ctot + (size_t)b * ctot + c);
         const u32x4 lo = t[0], hi = t[1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             cm_v[2 * part + 1] = __uint_as_float(w & 0xffff0000u);
             if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
 #pragma unroll
-                for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_fast(fmaf(cm_v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+                for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_log2e(fmaf(cm_v[k], h2_lo(abh[k]), h2_hi(abh[k])));
             }
         }
         if (part == 3) {
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             const int row = (j & 3) + 8 * (j >> 2);
-                            float v = acc[g + m2][j] + ep_add[NI == 1 ? 0 : img];
+                            float v = C::XF != XF_NONE ? fmaf(acc[g + m2][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j] + ep_add[NI == 1 ? 0 : img];
                             if (LEAKY) v = v > 0.f ? v : 0.01f * v;
                             scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
                         }
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                 const int q = pbase + row - img * (TH * TW);
                 const int ty = q / TW, tx = q - ty * TW;
                 const int oy = oyb + US * ty, ox = oxb + US * tx;
-                float v = acc[mr][j] + ep_add[NI == 1 ? 0 : img];
+                float v = C::XF != XF_NONE ? fmaf(acc[mr][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[mr][j] + ep_add[NI == 1 ? 0 : img];
                 if (!(nok && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
                 if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;

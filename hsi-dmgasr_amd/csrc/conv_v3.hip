@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         int cs;
         if (cc < p.C0) { src = p.src0 + cc; cs = p.C0; }
         else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
-        {   // fp16x2 half of the GroupNorm table (conv_v2.h: gn_params)
-            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * p.B * ctot + (size_t)st_b * ctot + cc);
+        {   // log2(e)-scaled fp16x2 part of the GroupNorm table (conv_v2.h: gn_params, silu_log2e)
+            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)3 * p.B * ctot + (size_t)st_b * ctot + cc);
             const u32x4 lo = t[0], hi = t[1];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 v[2 * k + 1] = __uint_as_float(hreg[i][k] & 0xffff0000u);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = silu_fast(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+            for (int k = 0; k < 8; ++k) v[k] = silu_log2e(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
             bf16x8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int row = (j & 3) + 8 * (j >> 2);
-                        float v = acc[g + m2][j] + ep_add;
+                        float v = fmaf(acc[g + m2][j], kLn2, ep_add);   // the staged activations carry log2(e) (silu_log2e)
                         if (LEAKY) v = v > 0.f ? v : 0.01f * v;
                         scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
                     }

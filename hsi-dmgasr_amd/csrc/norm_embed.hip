@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const h2 hh = {(_Float16)sc, (_Float16)sh};
         reinterpret_cast<unsigned*>(ab + (size_t)gridDim.y * C)[(size_t)b * C + c] = __builtin_bit_cast(unsigned, hh);
+        // third part: log2(e) * (scale, shift), for the kernels that follow the affine map with SiLU: u = log2(e) * y feeds
+        // v_exp_f32 directly (y * sigmoid(y) = u / (1 + 2^-u) / log2(e)); they undo the factor on their fp32 accumulators
+        const h2 hs = {(_Float16)(sc * 1.44269504f), (_Float16)(sh * 1.44269504f)};
+        reinterpret_cast<unsigned*>(ab + (size_t)gridDim.y * C)[(size_t)(gridDim.y + b) * C + c] = __builtin_bit_cast(unsigned, hs);
     }
 }
 

@@ -237,7 +237,7 @@ def gn_scale_shift(x0, x1, gamma, beta, groups, precision, eps=1e-5):
     C1 = 0 if x1 is None else x1.shape[3]
     p0, n0 = _partials(x0, precision)
     p1, n1 = _partials(x1, precision) if x1 is not None else (None, 0)
-    ab = torch.empty(B * (C0 + C1) * 3, dtype=torch.float32, device=x0.device)      # fp32 pairs + fp16x2 copies (hsidm.h)
+    ab = torch.empty(B * (C0 + C1) * 4, dtype=torch.float32, device=x0.device)      # fp32 pairs + two fp16x2 parts (hsidm.h)
     _lib.check(_lib.lib().hsidm_gn_finalize(_lib.ptr(p0), n0, C0, _lib.ptr(p1), n1, C1, B, H * W, groups,
                                             _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(ab),
                                             _lib.stream_ptr()), "gn_finalize")
@@ -246,10 +246,12 @@ def gn_scale_shift(x0, x1, gamma, beta, groups, precision, eps=1e-5):
 
 def gn_table(scale_shift):
     """[B, C, 2] fp32 (scale, shift) -> the table layout hsidm_gn_finalize produces and the conv kernels read: the fp32 pairs
-    followed by their fp16x2 copies (for callers that bring their own normalisation parameters, e.g. tests)."""
+    followed by their fp16x2 copies and the fp16x2 copies of log2(e) * (scale, shift) (for callers that bring their own
+    normalisation parameters, e.g. tests)."""
     ss = scale_shift.to(torch.float32).contiguous()
     packed = ss.to(torch.float16).contiguous().view(torch.int32).reshape(-1)          # (scale, shift) -> one 32-bit word
-    return torch.cat([ss.reshape(-1), packed.view(torch.float32)]).contiguous()
+    scaled = (ss * 1.44269504).to(torch.float16).contiguous().view(torch.int32).reshape(-1)
+    return torch.cat([ss.reshape(-1), packed.view(torch.float32), scaled.view(torch.float32)]).contiguous()
 
 
 def channel_partials(x, precision):

@@ -52,7 +52,7 @@ typedef struct hsidm_conv_phase {
     const void*  src0;        /* NHWC [B][Hin][Win][C0]                                             */
     const void*  src1;        /* NHWC [B][Hin][Win][C1] or NULL                                     */
     const float* gn_ab;       /* GroupNorm table of hsidm_gn_finalize: [B][C0+C1][2] fp32 (scale, shift)
-                                 followed by [B][C0+C1] fp16x2 copies of the same pairs; or NULL        */
+                                 followed by its two fp16x2 parts (see hsidm_gn_finalize); or NULL      */
     int32_t C0, C1;           /* multiples of 8                                                     */
     int32_t transform;        /* HSIDM_XF_*                                                         */
     int32_t ntaps;            /* 9 (3x3) or 1 (1x1)                                                 */
@@ -127,8 +127,9 @@ int hsidm_conv_bk(int prec);
  * `part` is [B][nsplit][C][2] floats; hsidm_conv2d's `stats` output has this layout, so a tensor produced by
  * a convolution needs no statistics pass.  finalize takes the two halves of a channel concat separately
  * (part1 may be NULL): GroupNorm groups may straddle the seam (e.g. 192 = 128 + 64 channels, 6 per group).
- * gn_ab (12 * B * C bytes): [B][C][2] fp32 (scale, shift), then [B][C] fp16x2 copies of the same pairs (what the bf16
- * convolution kernels read).
+ * gn_ab (16 * B * C bytes): [B][C][2] fp32 (scale, shift), then [B][C] fp16x2 copies of the same pairs, then [B][C]
+ * fp16x2 copies of log2(e) * (scale, shift) (what the bf16 kernels read: the affine-only ones the first copy, the
+ * GroupNorm+SiLU ones the pre-scaled copy, whose factor they remove from their fp32 accumulators).
  */
 int hsidm_gn_partial(int prec, const void* src0, const void* src1, int C0, int C1, int B, int HW,
                      int nsplit, float* part, void* stream);
