@@ -573,6 +573,10 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                             const int row = (j & 3) + 8 * (j >> 2);
                             float v = C::XF != XF_NONE ? fmaf(acc[g + m2][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j] + ep_add[NI == 1 ? 0 : img];
                             if (LEAKY) v = v > 0.f ? v : 0.01f * v;
+                            // no residual: statistics from the fp32 values in the accumulator layout (the lane owns one cout: 2 VALU
+                            // per value, one exchange between the lane halves) instead of unpacking the stored vectors and the
+                            // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
+                            if (!RES) { s1[NI == 1 ? 0 : img] += v; s2[NI == 1 ? 0 : img] = fmaf(v, v, s2[NI == 1 ? 0 : img]); }
                             scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
                         }
                     }
@@ -597,11 +601,13 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                             }
                         }
                         if (!HSIDM_ABL(1)) *reinterpret_cast<bf16x8*>(p.out + vec_base(g, v4) + lane_el) = o;
+                        if (RES) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                            for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                        }
                     }
                     HSIDM_STAMP(it, 11);
-                    if (p.stats && (NI == 2 || g + 2 >= MR)) {
+                    if (RES && p.stats && (NI == 2 || g + 2 >= MR)) {
                         // Lanes with equal (lane & 3) hold the same 8 couts: fold the 16 of them together with a halving
                         // butterfly -- at every level a lane hands the half of its values its partner keeps and receives
                         // the half it keeps itself: 8+4+2+1 = 15 cross-lane moves instead of 4*16, and every lane ends
@@ -658,12 +664,14 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             }
         }
         }
-        if (p.stats && !full) {
+        if (p.stats && (!full || !p.res)) {
             // wave partial over its pixels: combine the two lane halves, lanes 0..31 write one entry each
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
-                const float a = s1[q] + __shfl_xor(s1[q], 32, 64);
-                const float d = s2[q] + __shfl_xor(s2[q], 32, 64);
+                int lane_w = lane_id_now();                               // rebuilt here, not kept across the item (see lane_xor)
+                asm volatile("" : "+v"(lane_w));
+                const float a = s1[q] + lane_xor<32>(s1[q], lane_w);
+                const float d = s2[q] + lane_xor<32>(s2[q], lane_w);
                 int img, sub;
                 if (NI == 1) { img = 0; sub = wm; }
                 else if (WM == 1) { img = q; sub = 0; }

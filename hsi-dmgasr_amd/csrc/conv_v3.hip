@@ -247,6 +247,11 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             constexpr bool RES = decltype(res_tag)::value != 0;
             bf16x8 rv[RES ? 4 : 1];
             float vs1[8], vs2[8];
+            // Without a residual the statistics are taken from the fp32 values before they are rounded for the store: the lane
+            // owns one cout there, so 2 VALU per value and one exchange between the lane halves replace the unpacking of the
+            // stored vectors and the 15-move butterfly (the rounding noise is zero-mean, 2^-9 relative: invisible to GroupNorm).
+            // With a residual the stored sum only exists in the vector domain.
+            float as1 = 0.f, as2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
 #pragma unroll
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         const int row = (j & 3) + 8 * (j >> 2);
                         float v = fmaf(acc[g + m2][j], kLn2, ep_add);   // the staged activations carry log2(e) (silu_log2e)
                         if (LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        if (!RES) { as1 += v; as2 = fmaf(v, v, as2); }   // statistics in the accumulator layout (see below)
                         scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
                     }
 #pragma unroll
@@ -283,11 +289,18 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         }
                     }
                     *reinterpret_cast<bf16x8*>(p.out + vec_base(v4) + lane_el) = o;
+                    if (RES) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                        for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                    }
                 }
             }
-            if (p.stats) {                                                          // one entry per (image, tile, pixel half)
+            if (p.stats && !RES) {
+                const float a = as1 + lane_xor<32>(as1, lane_e), d = as2 + lane_xor<32>(as2, lane_e);
+                if (lh_e == 0)
+                    p.stats[((size_t)b * (tiles_per_img * WM) + tr * WM + wm) * p.Cout + wn * 32 + lr_e] = make_float2(a, d);
+            }
+            if (p.stats && RES) {                                                   // one entry per (image, tile, pixel half)
                 const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
                 float a8[8], a4[4], a2[2];
 #pragma unroll

@@ -41,3 +41,21 @@ def check(name, precision, got, want, tol=None):
     tol = TOL[precision] if tol is None else tol
     assert e < tol, "%s [%s]: rel err %.3e >= %.1e" % (name, precision, e, tol)
     return e
+
+
+def assert_stats(slab, y, tag=None):
+    """Statistics slab [B, nsplit, C, 2] of a convolution against (sum, sum of squares) of its stored NHWC output y.
+    conv_v2 / conv_v3 / conv1x1_g may sum a residual-free conv's fp32 values BEFORE the bf16 rounding of the store: the two
+    sides then differ by the sum of HW zero-mean rounding errors of at most 2^-9 |y| each, bounded here at 6 sigma (kernels
+    that sum the stored values pass the same bound trivially)."""
+    yf = y.float()
+    want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)         # [B, C, 2]
+    got = slab.sum(dim=1)
+    n_px = yf.shape[1] * yf.shape[2]
+    ymax = float(yf.abs().max())
+    noise = 6.0 * n_px ** 0.5 * 2.0 ** -9 * ymax / 3 ** 0.5
+    err = (got - want).abs()
+    lim0 = 2e-2 + noise + 2e-3 * want[..., 0].abs()
+    lim1 = 2e-2 + 2.0 * ymax * noise + 2e-3 * want[..., 1].abs()
+    assert bool((err[..., 0] <= lim0).all()), (tag, float(err[..., 0].max()))
+    assert bool((err[..., 1] <= lim1).all()), (tag, float(err[..., 1].max()))

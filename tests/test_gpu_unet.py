@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import check, fill_synth
+from gpu_util import assert_stats, check, fill_synth
 from helpers import jload, load_npz, sub_shapes, synth_sd, synth_tensor
 
 pytestmark = pytest.mark.gpu
@@ -353,7 +353,7 @@ CONV_CASES = [  # B, H, W, C0, C1, Cout, ups, proj_cin, xf
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
     """The persistent bf16 kernel (conv_v2) against the v1 kernel on identical inputs, and the statistics slab
-    of both against sums of the stored output."""
+    of both against sums of the stored output (for conv_v2 / conv_v3 up to the store's rounding noise, see below)."""
     from hsi_dmgasr_amd import ops
     B, H, W, C0, C1, Co, ups, pj, xf = case
     g = torch.Generator().manual_seed(sum(case[:6]))
@@ -375,10 +375,8 @@ def test_conv_v2_matches_v1_and_emits_statistics(dev, case):
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
         yf = y.float()
-        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)         # [B, C, 2]
-        got = slab.sum(dim=1)
         assert slab.shape == (B, nsplit, Co, 2)
-        assert torch.allclose(got, want, rtol=2e-3, atol=2e-2), (use_v2, (got - want).abs().max().item())
+        assert_stats(slab, y, use_v2)
         outs.append(yf.cpu())
     ops.set_use_v2(True)
     check("conv_v2_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=2e-3)
@@ -406,8 +404,7 @@ def test_conv_v3_residual_and_dispatch(dev, monkeypatch):
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
         yf = y.float()
-        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
-        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), no_v3
+        assert_stats(slab, y, no_v3)
         outs.append(yf.cpu())
         slabs.append(nsplit)
     assert slabs == [8 * 2, 4 * 2]                       # 8x16 tiles x 2 wave rows vs 16x16 tiles x 2 pixel halves
@@ -447,8 +444,7 @@ def test_folded_upsample_conv_matches_addressed_upsample(dev, case):
         slab, nsplit = y._hsidm_stats
         yf = y.float()
         assert y.shape == (B, 2 * H, 2 * W, Co) and slab.shape == (B, nsplit, Co, 2)
-        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
-        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), fold
+        assert_stats(slab, y, fold)
         outs.append(yf.cpu())
     ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest"),
                                      w, bias, padding=1).permute(0, 2, 3, 1)
@@ -488,8 +484,7 @@ def test_stride2_conv_over_parity_planes_matches_v1_and_torch(dev, case):
         slab, nsplit = y._hsidm_stats
         yf = y.float()
         assert y.shape == (B, H // 2, W // 2, Co)
-        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
-        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), use_v2
+        assert_stats(slab, y, use_v2)
         outs.append(yf.cpu())
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, bias, stride=2, padding=1).permute(0, 2, 3, 1)
     check("dn4_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
@@ -520,8 +515,7 @@ def test_eight_channel_conv_as_tap_major_gemm(dev, case):
             ops.set_use_v2(True)
         slab, nsplit = y._hsidm_stats
         yf = y.float()
-        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
-        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), use_v2
+        assert_stats(slab, y, use_v2)
         outs.append(yf.cpu())
     ref = torch.nn.functional.conv2d(x.float()[..., :Ci].permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1)
     check("stem_gemm_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
@@ -561,8 +555,7 @@ def test_conv1x1_gemm_kernels_match_v1(dev, case):
         torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
         yf = y.float()
-        want = torch.stack([yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))], dim=2)
-        assert torch.allclose(slab.sum(dim=1), want, rtol=2e-3, atol=2e-2), use_v2
+        assert_stats(slab, y, use_v2)
         outs.append(yf.cpu())
     ops.set_use_v2(True)
     # with a residual the vector epilogue rounds the conv result to bf16 before the add (v1 adds in fp32): <= 1 bf16 ulp
