@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     if (RES) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            o[k] = (bf16)fmaf(p.res_scale, f[k], (float)rv[v4][k]);
-                            f[k] = (float)o[k];
+                            f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
+                            o[k] = (bf16)f[k];
                         }
                     }
                     *reinterpret_cast<bf16x8*>(p.out + vec_base(v4) + lane_el) = o;
