@@ -192,10 +192,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     const float bias = p.bias ? p.bias[n] : 0.f;                // Cout % BN == 0 on this path
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
         for (int chunk = 0; chunk < p.nch; chunk += 2) {
             // body(PAR): MFMAs on buffer PAR, commits the chunk held in register set PAR^1 into buffer PAR^1, requests the
             // chunk after that into set PAR (whose previous content was committed one body ago)
@@ -216,9 +212,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                     const int u = PAR * 4 + kk;                 // position in the two-chunk trip: the weight ring's period
                     if (kk + 2 < 4) a_fetch(kk + 2);
                     f_issue(fring[(u + 6) % 8], (u + 6) % 4);
+                    if (u == 0 && chunk == 0) {                // first k-slice of the item: C = 0 as the MFMA's inline constant
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3][mr], fring[u % 8], acc[mr], 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], fring[0], zero, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3][mr], fring[u % 8], acc[mr], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk == 1) { commit(PAR ^ 1, 0, PAR ^ 1); commit(PAR ^ 1, 1, PAR ^ 1); }
                     if (kk == 2) { commit(PAR ^ 1, 2, PAR ^ 1); commit(PAR ^ 1, 3, PAR ^ 1); }

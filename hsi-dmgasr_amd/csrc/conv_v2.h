@@ -413,10 +413,6 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         HSIDM_STAMP(it, 0);
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
         float ep_add[NI], ep_bias = 0.f;                       // landed by the epilogue (see above)
         {
             // the lane's channel is recomputed from the hardware lane id here: kept as a loop-invariant 64-bit address
@@ -487,9 +483,17 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                             halo_commit_one((tap - 2) * 4 + kk, cur ^ 1);
                         }
                     }
+                    if (u == 0 && chunk == 0) {
+                        // first k-slice of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], FR ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], FR ? fring[0] : ring[0][0], zero, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], FR ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA

@@ -174,10 +174,6 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         HSIDM_STAMP(it, 0);
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
         const int tile = tile_of(item);
         const int b = tile / tiles_per_img;
         float ep_add = 0.f, ep_bias = 0.f;                      // landed by the epilogue (conv_v2.h: untracked loads)
@@ -217,9 +213,17 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = tap * 4 + kk;
                     if (u + 2 < 36) a_fetch(u + 2);
+                    if (u == 0 && chunk == 0) {
+                        // first k-slice of the item: C = 0 as the MFMA's inline constant instead of 64 v_mov per lane and item
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], ring[0][0], zero, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
