@@ -258,9 +258,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 for (int m2 = 0; m2 < 2; ++m2) {
                     if (m2 >= nm) break;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
+                    for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
                         const int row = (j & 3) + 8 * (j >> 2);
-                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)(acc[g + m2][j] + bias);
+                        const bf16x2 pr = cvt_pair(acc[g + m2][j] + bias, acc[g + m2][j + 1] + bias);
+                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
+                        scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                     }
                 }
                 float vs1[8], vs2[8];

@@ -145,6 +145,14 @@ __device__ __forceinline__ float silu_fast(float y) {
 // log2(e) * y * sigmoid(y) without the multiplication that turns y into an exp2 argument - one VALU instruction less per
 // staged element, in kernels bound by VALU issue.  The factor leaves on the fp32 accumulators (epilogue: fma(acc, ln 2, bias)).
 constexpr float kLn2 = 0.693147181f;
+// two fp32 -> one packed bf16 pair (v_cvt_pk_bf16_f32); storing the halves separately uses ds_write_b16 / ds_write_b16_d16_hi,
+// i.e. one conversion per two epilogue values instead of one each
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x2 cvt_pair(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_convertvector(v, bf16x2);
+}
 __device__ __forceinline__ float silu_log2e(float u) {
     return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
 }
@@ -573,15 +581,21 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
                     for (int m2 = 0; m2 < 2; ++m2) {
                         if (m2 >= nm) break;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
+                        for (int j = 0; j < 16; j += 2) {                       // rows row, row + 1 of the 32-row tile
                             const int row = (j & 3) + 8 * (j >> 2);
-                            float v = C::XF != XF_NONE ? fmaf(acc[g + m2][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j] + ep_add[NI == 1 ? 0 : img];
-                            if (LEAKY) v = v > 0.f ? v : 0.01f * v;
-                            // no residual: statistics from the fp32 values in the accumulator layout (the lane owns one cout: 2 VALU
-                            // per value, one exchange between the lane halves) instead of unpacking the stored vectors and the
-                            // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
-                            if (!RES) { s1[NI == 1 ? 0 : img] += v; s2[NI == 1 ? 0 : img] = fmaf(v, v, s2[NI == 1 ? 0 : img]); }
-                            scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
+                            float v[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                v[e] = C::XF != XF_NONE ? fmaf(acc[g + m2][j + e], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j + e] + ep_add[NI == 1 ? 0 : img];
+                                if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+                                // no residual: statistics from the fp32 values in the accumulator layout (the lane owns one cout: 2 VALU
+                                // per value, one exchange between the lane halves) instead of unpacking the stored vectors and the
+                                // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
+                                if (!RES) { s1[NI == 1 ? 0 : img] += v[e]; s2[NI == 1 ? 0 : img] = fmaf(v[e], v[e], s2[NI == 1 ? 0 : img]); }
+                            }
+                            const bf16x2 pr = cvt_pair(v[0], v[1]);
+                            scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
+                            scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                         }
                     }
                     HSIDM_STAMP(it, 9);

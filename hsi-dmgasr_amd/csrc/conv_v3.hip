@@ -271,12 +271,18 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
+                    for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
                         const int row = (j & 3) + 8 * (j >> 2);
-                        float v = fmaf(acc[g + m2][j], kLn2, ep_add);   // the staged activations carry log2(e) (silu_log2e)
-                        if (LEAKY) v = v > 0.f ? v : 0.01f * v;
-                        if (!RES) { as1 += v; as2 = fmaf(v, v, as2); }   // statistics in the accumulator layout (see below)
-                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = (bf16)v;
+                        float v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            v[e] = fmaf(acc[g + m2][j + e], kLn2, ep_add);       // the staged activations carry log2(e) (silu_log2e)
+                            if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+                            if (!RES) { as1 += v[e]; as2 = fmaf(v[e], v[e], as2); }   // statistics in the accumulator layout (see below)
+                        }
+                        const bf16x2 pr = cvt_pair(v[0], v[1]);
+                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
+                        scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                     }
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
