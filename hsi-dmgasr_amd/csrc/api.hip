@@ -111,11 +111,26 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     return HSIDM_OK;
 }
 
+// Cout slice a conv_v2 launch works on.  Packed for 128-cout slices, a GroupNorm+SiLU conv whose Cout is a multiple of 256 runs
+// 256-cout items on 8 waves (one workgroup per CU, conv_v2.h NW = 8): the staged halo tile is transformed once per 256 couts
+// instead of once per 128 (measured at batch 240: 16x16 level +7 %, 8x8 level +11 %, 32x32 level +1..2 %, step +1.5 %).
+// Only when that still occupies half of the CUs: the items are half as many and the slots are one per CU.  HSIDM_V2_BN256=0 disables it.
+static int v2_slice(const hsidm_conv_desc* d, int Hout, int Wout, int tile_kind, int path) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("HSIDM_V2_BN256"); on = e ? atoi(e) : 1; }
+    if (!on || path != PATH_V2 || tile_kind == 2 || d->bn != 128 || d->stride != 1 || d->ups ||
+        d->ph[0].transform != HSIDM_XF_AFFINE_SILU || d->Cout % 256) return d->bn;
+    const int TW = tile_kind == 0 ? 16 : 8;
+    const long long tiles = (long long)((d->B + (tile_kind == 1)) / (tile_kind == 1 ? 2 : 1)) * ((Wout + TW - 1) / TW) * ((Hout + 7) / 8);
+    return tiles * (d->Cout / 256) >= conv_v2_slots() / 4 ? 256 : d->bn;       // at least half of the CUs get an item
+}
+
 extern "C" int hsidm_conv_kernel_id(const hsidm_conv_desc* d) {
     int Hout, Wout, tile_kind, path;
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
-    return path | ((path == PATH_G1 ? 0 : tile_kind) << 4) | (d->bn << 8);      /* tile kinds: 0 8x16, 1 8x8 of two images, 2 8x8 of one */
+    /* tile kinds: 0 8x16, 1 8x8 of two images, 2 8x8 of one; bits 8.. = couts per work item */
+    return path | ((path == PATH_G1 ? 0 : tile_kind) << 4) | (v2_slice(d, Hout, Wout, tile_kind, path) << 8);
 }
 
 extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
@@ -199,6 +214,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         const bool dn4 = d->stride == 2;
         if (dn4) v.nchunks = 4 * p.ph[0].nchunks;
         v.steps_per_item = dn4 ? v.nchunks * 4 : (up4 ? p.ph[0].nchunks * 4 : steps);
+        if (!dn4 && !up4 && v2_slice(d, Hout, Wout, tile_kind, path) == 256) return conv_v2_run(tile_kind, 256, d->ph[0].transform, v, s);
         return conv_v2_run(tile_kind, d->bn, dn4 ? -2 : (up4 ? -1 : d->ph[0].transform), v, s);
     }
     p.w_hi = reinterpret_cast<const bf16*>(d->w_hi);

@@ -62,20 +62,23 @@ struct ConvV2Params {
 // columns).  The K loop walks the four (row parity, column parity) planes of the input; a staged halo pixel (iy, ix) of
 // plane (ry, rx) is in[2*iy + ry][2*ix + rx] and every plane contributes the window {iy-1, iy} x {ix-1, ix} with zero
 // weights where the plane has no tap (16/9 of the minimal MFMAs, on convs that are 1 % of the step's FLOPs).
-template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0>
+template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4>
 struct V2Cfg {
     static constexpr int BN = BN_, TH = TH_, TW = TW_, NI = NI_, XF = XF_;
+    // NW = 8: 512 threads, one workgroup per CU, 256 couts per item - the eight waves share one staged (transformed) halo tile,
+    // so the GroupNorm+SiLU transform is paid once per 256 couts instead of once per 128
+    static constexpr int NW = NW_, NTHR = 64 * NW_;
     static constexpr bool UP4 = SP_ == 1, DN4 = SP_ == 2;
     static constexpr bool FR = SP_ != 0;                        // 4-tap chunks, fragment-granular weight ring
     static constexpr int NT = FR ? 4 : 9;                       // taps per channel chunk
     static constexpr int BM = TH * TW * NI, BK = 64;           // 128 pixels; 64 for the one-image 8x8 tile (maps of 8x8 pixels
                                                                 // at batches too small to fill the GPU with two-image tiles)
     static_assert(BM == 128 || (BM == 64 && BN_ == 128), "tile");
-    static constexpr int WN = BN / 32, WM = 4 / WN, MR = BM / WM / 32;
+    static constexpr int WN = BN / 32, WM = NW / WN, MR = BM / WM / 32;
     static constexpr int HROWS = TH + 2, HCOLS = TW + 2, HPIX = HROWS * HCOLS;
     static constexpr int PSTR = BK + 8, VPP = BK / 8;
     static constexpr int HVEC = NI * HPIX * VPP;
-    static constexpr int MAXHV = (HVEC + 255) / 256;
+    static constexpr int MAXHV = (HVEC + NTHR - 1) / NTHR;
     static constexpr int NH = FR ? MAXHV : 4;                   // raw staging registers (vectors in flight)
     static_assert(MAXHV <= 7, "one staged vector per tap 2..8");
     static_assert(!FR || XF_ == 0, "the up/downsample convs have no GroupNorm prologue");
@@ -87,7 +90,9 @@ struct V2Cfg {
     static_assert(RP >= HCOLS * PSTR, "row pitch");
     static constexpr int HALO_ELEMS = NI * HROWS * RP;
     // two halo buffers + the per-thread table of halo positions (MAXHV packed ints per thread, see describe)
-    static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2 + (size_t)MAXHV * 256 * 4;
+    static constexpr size_t POS_BYTES = (size_t)MAXHV * NTHR * 4;
+    // NW = 8: the epilogue's transposition patches (8 x 5 KiB) do not fit the free halo buffer: a region of their own
+    static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2 + POS_BYTES + (NW == 8 ? (size_t)NW * 64 * 40 * 2 : 0);
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
@@ -175,11 +180,12 @@ __device__ __forceinline__ float lane_xor(float v, int lane_now) {
 }
 
 template <typename C>
-__global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
+__global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
     constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK, RP = C::RP, HROWS = C::HROWS;
     constexpr int MAXHV = C::MAXHV, NT = C::NT, NH = C::NH;
     constexpr bool UP4 = C::UP4, DN4 = C::DN4, FR = C::FR;
+    constexpr int NTHR = C::NTHR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* halo = reinterpret_cast<bf16*>(smem_raw);          // [2][HALO_ELEMS]
@@ -242,14 +248,14 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     // ---- halo staging state ---------------------------------------------------------------------------------
     const int cv = tid % VPP;
     auto hv_lds = [&](int i) __attribute__((always_inline)) -> int {   // LDS offset of staged vector i (halo pixel tid/VPP + i*256/VPP)
-        const int hp = tid / VPP + i * (256 / VPP);
+        const int hp = tid / VPP + i * (NTHR / VPP);
         const int row = hp / HCOLS;                            // (image, halo row) pairs are consecutive rows of the LDS image
         return row * RP + (hp - row * HCOLS) * PSTR + cv * 8;
     };
-    const bool last_live = tid + (MAXHV - 1) * 256 < C::HVEC;  // the last vector slot is partial
+    const bool last_live = tid + (MAXHV - 1) * NTHR < C::HVEC;  // the last vector slot is partial
     int hv_pix[MAXHV];                                          // for the tile being STAGED
     auto hv_pos = [&](int i, int t) __attribute__((always_inline)) -> int {   // img<<16 | hy<<8 | hx, or -1 (dead slot); recomputed, not kept
-        const int hp = t / VPP + i * (256 / VPP);
+        const int hp = t / VPP + i * (NTHR / VPP);
         const int img = hp / HPIX;
         const int r = hp - img * HPIX;
         const int hy = r / HCOLS, hx = r - hy * HCOLS;
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     // constants), keeping them in registers made the allocator spill.  They live in LDS instead: one ds_read per vector.
     int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2);
 #pragma unroll
-    for (int i = 0; i < MAXHV; ++i) pos_tab[i * 256 + tid] = hv_pos(i, tid);
+    for (int i = 0; i < MAXHV; ++i) pos_tab[i * NTHR + tid] = hv_pos(i, tid);
     int st_b0 = 0;
     auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {   // tile origin on the staged grid
         int par_;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
         const int sh = up ? 1 : 0;
         int posv[MAXHV];                                        // all table reads first: one LDS round trip instead of MAXHV
 #pragma unroll
-        for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * 256 + tid];
+        for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * NTHR + tid];
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
             const int pos = posv[i];
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
     float cm_v[8];
     auto halo_commit_part = [&](int i, int buf, int part) __attribute__((always_inline)) {
         if (part == 0 && C::XF != XF_NONE && NI > 1 && !(HSIDM_ABL(2))) {
-            const int img = (tid / VPP + i * (256 / VPP)) / HPIX;
+            const int img = (tid / VPP + i * (NTHR / VPP)) / HPIX;
             const int bb = (st_b0 + img < p.B) ? st_b0 + img : st_b0;
             gn_params(bb, st_c);
         }
@@ -545,7 +551,8 @@ __global__ __launch_bounds__(256, 2) void conv_v2_kernel(const ConvV2Params p) {
             constexpr int LTW = (TW == 16) ? 4 : 3;
             constexpr int SCR_STR = 40;                                       // bf16 per pixel row: 32 couts + 16 B pad
             constexpr int NV = 2 * MR;                                        // 16-B vectors per lane and item
-            bf16* scr = halo + (cur ^ 1) * C::HALO_ELEMS + wave * (64 * SCR_STR);
+            bf16* scr = (C::NW == 8 ? reinterpret_cast<bf16*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2 + C::POS_BYTES) : halo + (cur ^ 1) * C::HALO_ELEMS) +
+                        wave * (64 * SCR_STR);
             // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU).  The lane
             // constants are rebuilt from the hardware lane id at the top of every pass: kept across the passes they were
             // spilled, and each reload was an s_waitcnt vmcnt(0) behind the previous pass's output stores.

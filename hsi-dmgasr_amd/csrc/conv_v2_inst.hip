@@ -12,7 +12,7 @@ int conv_v2_slots();
 template <typename C>
 static int run_v2(ConvV2Params& p, hipStream_t s) {
     constexpr size_t lds = C::LDS_BYTES;
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static_assert(C::NW == 8 ? lds <= 160 * 1024 : lds <= 80 * 1024, "two workgroups per CU (one with 8 waves)");
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v2_kernel<C>),
@@ -38,9 +38,10 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     p.total_items = p.m_tiles * p.n_slices;
     int lcm = 8;
     while (lcm % p.n_slices) lcm += 8;
-    int G = (p.total_items < g_slots ? p.total_items : g_slots) / lcm * lcm;
+    const int slots = C::NW == 8 ? g_slots / 2 : g_slots;
+    int G = (p.total_items < slots ? p.total_items : slots) / lcm * lcm;
     if (G == 0) G = p.total_items;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v2_kernel<C>), dim3(G), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v2_kernel<C>), dim3(G), dim3(C::NTHR), lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -76,6 +77,10 @@ int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s) {
     }
     if (xf != XF_NONE && xf != XF_AFFINE_SILU) return -2;
     const bool x = xf == XF_AFFINE_SILU;
+    if (bn == 256) {         // 8 waves, one workgroup per CU: the staged tile is transformed once per 256 couts
+        if (!x || tile_kind == 2) return -2;
+        return tile_kind == 0 ? run_v2<V2Cfg<256, 8, 16, 1, XF_AFFINE_SILU, 0, 8>>(p, s) : run_v2<V2Cfg<256, 8, 8, 2, XF_AFFINE_SILU, 0, 8>>(p, s);
+    }
     if (tile_kind == 2) return (x && bn == 128) ? V2(128, 8, 8, 1, XF_AFFINE_SILU) : -2;
     if (tile_kind == 0) {
         switch (bn) {

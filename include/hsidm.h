@@ -115,7 +115,7 @@ int hsidm_conv2d(const hsidm_conv_desc* d, void* stream);
 /* Number of partial entries per image that hsidm_conv2d(d) writes into d->stats (>0), or an error code. */
 int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d);
 /* Which kernel hsidm_conv2d(d) dispatches to, for measurement tools: bits 0-3 = 0 LDS-tiled (conv_igemm), 1 persistent 3x3
- * (conv_v2), 3 LDS-staged 1x1 GEMM (conv1x1_g), 4 256-pixel 3x3 (conv_v3); bits 4-5 = tile (0: 8x16, 1: 8x8 of two images, 2: 8x8 of one image); bits 8.. = cout slice.
+ * (conv_v2), 3 LDS-staged 1x1 GEMM (conv1x1_g), 4 256-pixel 3x3 (conv_v3); bits 4-5 = tile (0: 8x16, 1: 8x8 of two images, 2: 8x8 of one image); bits 8.. = couts per work item (256: the 8-wave form of a 128-packed GroupNorm+SiLU conv).
  * <0 on error. */
 int hsidm_conv_kernel_id(const hsidm_conv_desc* d);
 /* K-chunk (input channels per packed step) of a precision mode: 64 for BF16, 32 for F32X3. */

@@ -17,7 +17,7 @@ import sys
 
 def label(name):
     """Kernel name -> the label ops.conv2d's probe gives the same launches (bench.py groups by it)."""
-    m = re.search(r"conv_v2_kernel.*V2Cfg<(\d+), 8, (\d+), (\d), (\d), (\d)>", name) or \
+    m = re.search(r"conv_v2_kernel.*V2Cfg<(\d+), 8, (\d+), (\d), (\d), (\d)(?:, \d)?>", name) or \
         re.search(r"conv_v2_kernelINS_5V2CfgILi(\d+)ELi8ELi(\d+)ELi(\d)ELi(\d)ELi(\d)", name)
     if m:
         bn, tw, ni, xf, up4 = map(int, m.groups())
