@@ -221,12 +221,18 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
 //   * K and V stream through a double-buffered LDS image in 64-channel chunks with row-contiguous 16-byte loads, shared
 //     by the 4 waves (128 queries) of the workgroup: K and V are read twice per image instead of eight times;
 //   * O^T tiles have the query on the lane and 4 consecutive channels per register quad: 8-byte stores, no epilogue pass.
+#ifndef HSIDM_ATT_VRS
+#define HSIDM_ATT_VRS 80
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <int NKT, int NW>
-__global__ __launch_bounds__(64 * NW) void attention_v2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int C, float scale) {
+__global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attention_v2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int C, float scale) {
     constexpr int N = 32 * NKT, T = 64 * NW, NV = N * 8 / T;
-    constexpr int KRS = 72, VRS = 96;                      // bf16 per key row: 144 B (ds_read_b128 fragments) / 192 B (transposed reads)
+    // bf16 per key row: 144 B (ds_read_b128 fragments) / 160 B (transposed reads: the four key rows a 16-lane group touches start
+    // 40 banks apart - banks 0, 40, 16, 56, eight each: conflict-free like the 192-byte pitch, and two 256-key buffers are exactly
+    // 80 KiB, so that two workgroups fit a CU: 480 workgroups of a 240-image batch are resident at once instead of in two rounds)
+    constexpr int KRS = 72, VRS = HSIDM_ATT_VRS;
     constexpr int BUFE = N * VRS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* buf = reinterpret_cast<bf16*>(smem_raw);         // [2][BUFE]
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(64 * NW) void attention_v2_kernel(const bf16* __res
 
 template <int NKT, int NW>
 static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * 32 * NKT * 96 * 2;
+    constexpr size_t lds = (size_t)2 * 32 * NKT * HSIDM_ATT_VRS * 2;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_v2_kernel<NKT, NW>),
