@@ -17,7 +17,7 @@ HSIDM_DECL(conv_run_f32x3_k3s1nchw)
 int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 int conv_v2_slots();
-int conv_v3_run(ConvV2Params& p, hipStream_t s);
+int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s);
 void conv_v2_set_stamps(unsigned long long* p);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
@@ -86,6 +86,10 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         if (d->ksize != 3 || xf != HSIDM_XF_NONE || (d->bn != 64 && d->bn != 128) || (d->Hin & 1) || (d->Win & 1)) return HSIDM_E_UNSUPPORTED;
         path = PATH_V2;
     }
+    // fp32 NCHW output (the UNet's final Block, 64 -> 3): one padded 32-cout slice on the 256-pixel kernel (conv_v3.hip, WN = 1)
+    if (d->prec == HSIDM_BF16 && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
+        xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 32 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
+        !d->stats && d->act == HSIDM_ACT_NONE && !getenv("HSIDM_NO_V3")) path = PATH_V3;
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
         // 8x8 maps: two-image tiles halve the work items; when those would leave half of the co-resident workgroup slots
@@ -209,7 +213,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
         if (path == PATH_V3) {
             v.steps_per_item = steps;
-            return conv_v3_run(v, s);
+            return conv_v3_run(v, d->out_nchw, s);
         }
         const bool dn4 = d->stride == 2;
         if (dn4) v.nchunks = 4 * p.ph[0].nchunks;

@@ -22,7 +22,6 @@ namespace hsidm {
 
 namespace v3 {
 constexpr int TH = 16, TW = 16, BM = 256, BN = 64, BK = 64;
-constexpr int WN = 2, WM = 2, MR = 4;
 constexpr int HROWS = TH + 2, HCOLS = TW + 2, HPIX = HROWS * HCOLS;      // 18 x 18
 constexpr int PSTR = BK + 8, VPP = BK / 8;
 constexpr int RP = 1408;                                                   // halo row pitch: 2816 B = 0 mod 256 (conv_v2.h)
@@ -31,8 +30,14 @@ constexpr int HALO_ELEMS = HROWS * RP;
 constexpr size_t LDS_BYTES = (size_t)HALO_ELEMS * 2 + (size_t)MAXHV * 256 * 4;
 }  // namespace v3
 
+// WN_ = 2: the 64-cout layers (waves = 2 pixel halves x 2 cout halves, 4 MFMA tiles per wave).
+// WN_ = 1, NCHW_: the UNet's final Block (GroupNorm + SiLU + conv 64 -> 3, reference unet.py:231,262): one 32-cout slice of which
+//   3 couts exist, waves = 4 pixel quarters, 2 MFMA tiles per wave, fp32 NCHW output straight from the accumulators (no FiLM,
+//   residual or statistics) - the last launch of a bf16 step that ran on the generic kernel (415 us at batch 240).
+template <int WN_, bool NCHW_>
 __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using namespace v3;
+    constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* halo = reinterpret_cast<bf16*>(smem_raw);
     int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)HALO_ELEMS * 2);
@@ -148,10 +153,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         }
     };
 
-    // ---- MFMA fragment bases: MFMA tile mr = tile rows 8 wm + 2 mr, +1; lane = (row lr/16, column lr%16) ------------------
+    // ---- MFMA fragment bases: MFMA tile mr = tile rows (16/WM) wm + 2 mr, +1; lane = (row lr/16, column lr%16) ------------------
     int abase[MR];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * 8 + mr * 2 + (lr >> 4)) * RP + (lr & 15) * PSTR + 8 * lh;
+    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (16 / WM) + mr * 2 + (lr >> 4)) * RP + (lr & 15) * PSTR + 8 * lh;
     f32x16 acc[MR];
 
     const int n = wn * 32 + lr;                                 // Cout == 64: every lane's cout exists
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         {   // lane's channel from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
             int lane_s = lane_id_now();
             asm volatile("" : "+v"(lane_s));
-            const int n_s = wn * 32 + (lane_s & 31);
+            const int n_raw = wn * 32 + (lane_s & 31);
+            const int n_s = (!NCHW_ || n_raw < p.Cout) ? n_raw : 0;         // NCHW_: 3 of the slice's 32 couts exist
             if (p.film) ep_add = untracked_load(p.film + (size_t)b * p.film_stride + n_s);
             if (p.bias) ep_bias = untracked_load(p.bias + n_s);
         }
@@ -239,6 +245,26 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
         asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add), "+v"(ep_bias));       // older than the 8 weight + 11 halo requests in flight
         ep_add += ep_bias;
+        if constexpr (NCHW_) {
+            // fp32 NCHW straight from the accumulator layout: lane = cout (3 live lanes per half), register j = pixel row
+            // (j&3) + 8(j>>2) + 4(lane>>5) of the 32-pixel MFMA tile = two tile rows of 16
+            int lane_o = lane_id_now();
+            asm volatile("" : "+v"(lane_o));
+            const int n_o = lane_o & 31, lh_o = lane_o >> 5;
+            if (n_o < p.Cout) {
+                float* plane = reinterpret_cast<float*>(p.out) + ((size_t)b * p.Cout + n_o) * p.Hout * p.Wout;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int row = (j & 3) + 8 * (j >> 2) + 4 * lh_o;
+                        const int oy = oy0 + wm * (16 / WM) + mr * 2 + (row >> 4), ox = ox0 + (row & 15);
+                        plane[(size_t)oy * p.Wout + ox] = fmaf(acc[mr][j], kLn2, ep_add);
+                    }
+            }
+            HSIDM_STAMP(it, 13);
+            continue;                                                               // no transposition patch: no barrier
+        }
         constexpr int SCR_STR = 40;
         bf16* scr = halo + wave * (64 * SCR_STR);
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
 #pragma unroll
             for (int g = 0; g < MR; g += 2) {                                      // a pass = 4 tile rows x 16 columns
-                const int row0 = oy0 + wm * 8 + g * 2;
+                const int row0 = oy0 + wm * (16 / WM) + g * 2;
                 auto vec_base = [&](int v4) __attribute__((always_inline)) -> size_t {
                     return (((size_t)b * p.Hout + row0 + v4) * p.Wout + ox0) * p.Cout + wn * 32;
                 };
@@ -336,15 +362,22 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 static int g3_slots = 0;
 extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds)
 
-// Cout == 64, Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller)
-int conv_v3_run(ConvV2Params& p, hipStream_t s) {
+// Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller); nchw = 0: Cout == 64, NHWC bf16 out;
+// nchw = 1: Cout <= 32 (one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
+template <int WN_, bool NCHW_>
+static int launch_v3(ConvV2Params& p, int G, hipStream_t s) {
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v3_kernel<WN_, NCHW_>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)v3::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
+int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s) {
     if (g3_slots == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -364,8 +397,7 @@ int conv_v3_run(ConvV2Params& p, hipStream_t s) {
     p.stamps = g_stamps;
     int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;
     if (G == 0) G = p.total_items;
-    hipLaunchKernelGGL(conv_v3_kernel, dim3(G), dim3(256), v3::LDS_BYTES, s, p);
-    return (int)hipGetLastError();
+    return nchw ? launch_v3<1, true>(p, G, s) : launch_v3<2, false>(p, G, s);
 }
 
 }  // namespace hsidm

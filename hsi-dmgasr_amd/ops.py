@@ -63,7 +63,7 @@ class PackedConv:
         # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
         self.w_v2 = None
         self.tap_major = False
-        if prec == _lib.BF16 and not out_nchw and proj_weight is None:
+        if prec == _lib.BF16 and proj_weight is None and (not out_nchw or (kh == 3 and self.bn == 32)):
             wv = self.w_hi
             self.tap_major = kh == 3 and cin == 8
             if self.tap_major:                       # stem-like convs: tap-major GEMM (conv1x1_g IM mode), k = 8*tap + c -> 128

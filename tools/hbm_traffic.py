@@ -27,7 +27,8 @@ def label(name):
         bn, xf, im = map(int, m.groups())
         return "conv1x1_g bn%d 8x16 k%d s1%s" % (bn, 3 if im else 1, " gn" if xf == 1 else "")
     if "conv_v3_kernel" in name:
-        return "conv_v3 bn64 8x16 k3 s1 gn+silu"
+        nchw = "<1, true>" in name or "ILi1ELb1E" in name
+        return "conv_v3 bn32 8x16 k3 s1 gn+silu nchw" if nchw else "conv_v3 bn64 8x16 k3 s1 gn+silu"
     return None
 
 
