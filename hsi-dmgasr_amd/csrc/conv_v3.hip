@@ -27,7 +27,12 @@ constexpr int PSTR = BK + 8, VPP = BK / 8;
 constexpr int RP = 1408;                                                   // halo row pitch: 2816 B = 0 mod 256 (conv_v2.h)
 constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;               // 2592 vectors, 11 per thread
 constexpr int HALO_ELEMS = HROWS * RP;
-constexpr size_t LDS_BYTES = (size_t)HALO_ELEMS * 2 + (size_t)MAXHV * 256 * 4;
+constexpr int SCR_STR = 40;                                                // bf16 per row of an epilogue patch: 32 couts + 16 B pad
+// halo tile + halo position table + one 32-pixel x 32-cout transposition patch per wave.  The patches have a region of their own
+// (they used to sit in the halo tile): a wave leaves its epilogue for the next item's commit without a workgroup barrier
+constexpr size_t PATCH_OFF = (size_t)HALO_ELEMS * 2 + (size_t)MAXHV * 256 * 4;
+constexpr size_t LDS_BYTES = PATCH_OFF + (size_t)4 * 32 * SCR_STR * 2;
+static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 }  // namespace v3
 
 // WN_ = 2: the 64-cout layers (waves = 2 pixel halves x 2 cout halves, 4 MFMA tiles per wave).
@@ -265,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             HSIDM_STAMP(it, 13);
             continue;                                                               // no transposition patch: no barrier
         }
-        constexpr int SCR_STR = 40;
-        bf16* scr = halo + wave * (64 * SCR_STR);
+        bf16* scr = reinterpret_cast<bf16*>(smem_raw + PATCH_OFF) + wave * (32 * SCR_STR);
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
             constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
             constexpr bool RES = decltype(res_tag)::value != 0;
-            bf16x8 rv[RES ? 4 : 1];
+            bf16x8 rv[RES ? 2 : 1];
             float vs1[8], vs2[8];
             // Without a residual the statistics are taken from the fp32 values before they are rounded for the store: the lane
             // owns one cout there, so 2 VALU per value and one exchange between the lane halves replace the unpacking of the
@@ -285,33 +289,31 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
 #pragma unroll
-            for (int g = 0; g < MR; g += 2) {                                      // a pass = 4 tile rows x 16 columns
+            for (int g = 0; g < MR; ++g) {                                         // a pass = one MFMA tile = 2 tile rows x 16 columns
                 const int row0 = oy0 + wm * (16 / WM) + g * 2;
                 auto vec_base = [&](int v4) __attribute__((always_inline)) -> size_t {
                     return (((size_t)b * p.Hout + row0 + v4) * p.Wout + ox0) * p.Cout + wn * 32;
                 };
                 if (RES) {
 #pragma unroll
-                    for (int v4 = 0; v4 < 4; ++v4) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(v4) + lane_el);
+                    for (int v4 = 0; v4 < 2; ++v4) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(v4) + lane_el);
                 }
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                     for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
                         const int row = (j & 3) + 8 * (j >> 2);
                         float v[2];
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            v[e] = fmaf(acc[g + m2][j + e], kLn2, ep_add);       // the staged activations carry log2(e) (silu_log2e)
+                            v[e] = fmaf(acc[g][j + e], kLn2, ep_add);       // the staged activations carry log2(e) (silu_log2e)
                             if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                             if (!RES) { as1 += v[e]; as2 = fmaf(v[e], v[e], as2); }   // statistics in the accumulator layout (see below)
                         }
                         const bf16x2 pr = cvt_pair(v[0], v[1]);
-                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
-                        scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
+                        scr[row * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
+                        scr[(row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                     }
 #pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4) {
+                for (int v4 = 0; v4 < 2; ++v4) {
                     const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
                     float f[8];
 #pragma unroll
@@ -353,8 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         };
         if (p.act == ACT_LEAKY) { if (p.res) run(SlotTag<1>{}, SlotTag<1>{}); else run(SlotTag<1>{}, SlotTag<0>{}); }
         else                    { if (p.res) run(SlotTag<0>{}, SlotTag<1>{}); else run(SlotTag<0>{}, SlotTag<0>{}); }
-        HSIDM_STAMP(it, 14);
-        lds_barrier();                                                              // the patch is the halo tile of the next commit
+        HSIDM_STAMP(it, 14);                                                        // no barrier: the patches do not alias the halo tile
         HSIDM_STAMP(it, 13);
     }
 }
