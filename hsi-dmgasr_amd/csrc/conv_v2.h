@@ -663,7 +663,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             if (p.act == ACT_LEAKY) { if (p.res) run(SlotTag<1>{}, SlotTag<1>{}); else run(SlotTag<1>{}, SlotTag<0>{}); }
             else                    { if (p.res) run(SlotTag<0>{}, SlotTag<1>{}); else run(SlotTag<0>{}, SlotTag<0>{}); }
             HSIDM_STAMP(it, 14);
-            lds_barrier();                                                   // the patch is part of the next staging buffer
+            if (C::NW != 8) lds_barrier();                                   // the patch is part of the next staging buffer (NW = 8: a region of its own)
         } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
