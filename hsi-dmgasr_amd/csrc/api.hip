@@ -120,8 +120,8 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
 // instead of once per 128 (measured at batch 240: 16x16 level +7 %, 8x8 level +11 %, 32x32 level +1..2 %, step +1.5 %).
 // Only when that still occupies half of the CUs: the items are half as many and the slots are one per CU.  HSIDM_V2_BN256=0 disables it.
 static int v2_slice(const hsidm_conv_desc* d, int Hout, int Wout, int tile_kind, int path) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("HSIDM_V2_BN256"); on = e ? atoi(e) : 1; }
+    const char* e = getenv("HSIDM_V2_BN256");                  // read per launch: the tests switch it
+    const int on = e ? atoi(e) : 1;
     if (!on || path != PATH_V2 || tile_kind == 2 || d->bn != 128 || d->stride != 1 || d->ups ||
         d->ph[0].transform != HSIDM_XF_AFFINE_SILU || d->Cout % 256) return d->bn;
     const int TW = tile_kind == 0 ? 16 : 8;

@@ -411,6 +411,84 @@ def test_conv_v3_residual_and_dispatch(dev, monkeypatch):
     check("conv_v3_vs_v2_residual", "bf16", outs[1], outs[0], tol=2e-3)
 
 
+WIDE_CASES = [  # B, H, W, Cin, Cout, residual : GroupNorm+SiLU convs whose Cout is a multiple of 256
+    (40, 16, 16, 256, 512, False),     # 8x16 tiles, two 256-cout slices
+    (36, 16, 32, 128, 256, True),      # one slice, residual + statistics in the vector domain
+    (260, 8, 8, 128, 256, False),      # two-image 8x8 tiles
+    (4, 16, 16, 128, 256, False),      # too few items for one workgroup per CU: stays on the 128-cout form
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_256_cout_items_on_8_waves_match_the_128_cout_form(dev, monkeypatch, case):
+    """conv_v2's NW = 8 form (256 couts per item, one workgroup per CU) against the 4-wave 128-cout form on identical inputs
+    (HSIDM_V2_BN256=0): same staging, same K order, same epilogue per wave -> bit-identical output and statistics; and the
+    dispatch rule (hsidm_conv_kernel_id through the probe label)."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Ci, Co, with_res = case
+    g = torch.Generator().manual_seed(B + Ci + Co)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    pk = ops.PackedConv(w.to(dev), torch.randn(Co, generator=g).to(dev), "bf16")
+    x = torch.randn(B, H, W, Ci, generator=g).to(dev, torch.bfloat16)
+    res = torch.randn(B, H, W, Co, generator=g).to(dev, torch.bfloat16) if with_res else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, Ci, generator=g), 0.1 * torch.randn(B, Ci, generator=g)], 2).contiguous().to(dev)
+    film = torch.randn(B, Co, generator=g).to(dev)
+    outs, slabs, labels = [], [], []
+    for wide in (False, True):
+        if wide:
+            monkeypatch.delenv("HSIDM_V2_BN256", raising=False)
+        else:
+            monkeypatch.setenv("HSIDM_V2_BN256", "0")
+        recs = []
+        ops.set_conv_probe(recs)
+        y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab), transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
+        ops.set_conv_probe(None)
+        torch.cuda.synchronize()
+        slab, _ = y._hsidm_stats
+        assert_stats(slab, y, wide)
+        outs.append(y.float().cpu())
+        slabs.append(slab.float().cpu())
+        labels.append(recs[-1]["kernel"])
+    assert "bn128" in labels[0]
+    assert ("bn256" if B >= 36 else "bn128") in labels[1], labels
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(slabs[0], slabs[1])
+
+
+def test_final_block_conv_on_the_256_pixel_kernel(dev, monkeypatch):
+    """The UNet's last conv (GroupNorm + SiLU + 3x3, 64 -> 3, fp32 NCHW out; reference unet.py:231,262) on conv_v3<WN = 1, NCHW>
+    against the generic kernel (HSIDM_NO_V3=1) and against torch fp32."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(23)
+    B, H, W, Ci, Co = 3, 32, 48, 64, 3
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pk = ops.PackedConv(w.to(dev), bias.to(dev), "bf16", out_nchw=True)
+    assert pk.w_v2 is not None
+    x = torch.randn(B, H, W, Ci, generator=g).to(dev, torch.bfloat16)
+    ab = torch.stack([1 + 0.1 * torch.randn(B, Ci, generator=g), 0.1 * torch.randn(B, Ci, generator=g)], 2).contiguous()
+    outs, labels = [], []
+    for no_v3 in (True, False):
+        if no_v3:
+            monkeypatch.setenv("HSIDM_NO_V3", "1")
+        else:
+            monkeypatch.delenv("HSIDM_NO_V3")
+        recs = []
+        ops.set_conv_probe(recs)
+        y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab.to(dev)), transform=ops.XF_AFFINE_SILU)
+        ops.set_conv_probe(None)
+        torch.cuda.synchronize()
+        assert y.shape == (B, Co, H, W) and y.dtype == torch.float32
+        outs.append(y.cpu())
+        labels.append(recs[-1]["kernel"])
+    assert labels[0].startswith("conv_igemm") and labels[1].startswith("conv_v3") and labels[1].endswith("nchw"), labels
+    xf = x.float().cpu()
+    act = torch.nn.functional.silu(xf * ab[:, None, None, :, 0] + ab[:, None, None, :, 1]).to(torch.bfloat16).float()
+    want = torch.nn.functional.conv2d(act.permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), bias, padding=1)
+    check("final_conv_v3_vs_torch", "bf16", outs[1], want, tol=3e-3)
+    check("final_conv_v3_vs_v1", "bf16", outs[1], outs[0], tol=3e-3)
+
+
 UP4_CASES = [  # B, H, W, Cin, Cout  (input grid)
     (4, 16, 32, 128, 128),     # 8x16 tiles, one cout slice, L2-friendly (tile, parity) order (16 tiles % 8 == 0)
     (3, 16, 32, 64, 128),      # 12 tiles: plain order
