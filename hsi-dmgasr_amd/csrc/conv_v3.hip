@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
         const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
         const unsigned lane_el = (unsigned)(pl0 * p.Cout + cq * 8);                // pass pixel (row v4, column pl0): row part is uniform
+        const size_t row_stride = (size_t)p.Wout * p.Cout;
+        const size_t item_base = (((size_t)b * p.Hout + oy0 + wm * (16 / WM)) * p.Wout + ox0) * p.Cout + wn * 32;
         auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
             constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
             constexpr bool RES = decltype(res_tag)::value != 0;
@@ -290,9 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
 #pragma unroll
             for (int g = 0; g < MR; ++g) {                                         // a pass = one MFMA tile = 2 tile rows x 16 columns
-                const int row0 = oy0 + wm * (16 / WM) + g * 2;
+                // output address of the pass's vector v4: one 64-bit product chain per item (item_base), then multiples of the
+                // row stride - the per-vector chain cost ~25 scalar instructions, 200 per epilogue
                 auto vec_base = [&](int v4) __attribute__((always_inline)) -> size_t {
-                    return (((size_t)b * p.Hout + row0 + v4) * p.Wout + ox0) * p.Cout + wn * 32;
+                    return item_base + (size_t)(g * 2 + v4) * row_stride;
                 };
                 if (RES) {
 #pragma unroll
