@@ -47,6 +47,7 @@ struct ConvV2Params {
     int m_tiles, n_slices, total_items, steps_per_item;
     int up_m;               // UP4 kernels: XCDs per cout slice when the L2-friendly (tile, parity) order applies, else 0
     int xcd_m;              // other kernels: XCDs per cout slice when each of them walks a contiguous range of pixel tiles, else 0
+    int tpi_shift, tx_shift; // conv_v3: log2 of tiles per image / per tile row when those are powers of two, else -1
     unsigned long long* stamps;   // diagnostic build (HSIDM_V2_STAMPS): [block][wave][item<8][slot<16] s_memtime
     int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };

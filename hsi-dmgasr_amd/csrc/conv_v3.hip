@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     const int lr = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
+    // tile index -> (image, tile row, tile column): shifts when the tile grid is a power of two (the UNet's maps are); a division by
+    // a run-time value is ~20 scalar instructions, and an item needs eight of them
+    auto div_tpi = [&](int x) __attribute__((always_inline)) -> int { return p.tpi_shift >= 0 ? x >> p.tpi_shift : x / tiles_per_img; };
+    auto div_tx = [&](int x) __attribute__((always_inline)) -> int { return p.tx_shift >= 0 ? x >> p.tx_shift : x / p.tiles_x; };
     const int ctot = p.C0 + p.C1;
     const int nch = p.nchunks;
 
@@ -90,13 +94,14 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     // 8 apart while the tiles in between - the ones that share their halo rows and columns - sit on the other seven XCDs.
     // xcd_m = 8 when the tile count allows: XCD x walks the contiguous range [x*M/8, (x+1)*M/8), 64 neighbouring tiles at a time.
     auto tile_of = [&](int it) __attribute__((always_inline)) -> int {
-        return p.xcd_m > 0 ? (it % p.xcd_m) * (p.m_tiles / p.xcd_m) + it / p.xcd_m : it;
+        return p.xcd_m > 0 ? (it & 7) * (p.m_tiles >> 3) + (it >> 3) : it;     // xcd_m is 0 or 8
     };
     auto describe = [&](int it_) __attribute__((always_inline)) {
         const int it = tile_of(it_);
-        const int b = it / tiles_per_img;
+        const int b = div_tpi(it);
         const int tr = it - b * tiles_per_img;
-        const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+        const int try_ = div_tx(tr);
+        const int oy0 = try_ * TH, ox0 = (tr - try_ * p.tiles_x) * TW;
         st_b = b;
         int posv[MAXHV];                                        // all table reads first: one LDS round trip instead of eleven
 #pragma unroll
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         HSIDM_STAMP(it, 0);
         const int tile = tile_of(item);
-        const int b = tile / tiles_per_img;
+        const int b = div_tpi(tile);
         float ep_add = 0.f, ep_bias = 0.f;                      // landed by the epilogue (conv_v2.h: untracked loads)
         {   // lane's channel from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
             int lane_s = lane_id_now();
@@ -247,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 
         // ---- epilogue (conv_v2's vector epilogue; the halo buffer is free between the two barriers) ------------------------
         const int tr = tile - b * tiles_per_img;
-        const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+        const int try_e = div_tx(tr);
+        const int oy0 = try_e * TH, ox0 = (tr - try_e * p.tiles_x) * TW;
         asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add), "+v"(ep_bias));       // older than the 8 weight + 11 halo requests in flight
         ep_add += ep_bias;
         if constexpr (NCHW_) {
@@ -397,6 +403,9 @@ int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s) {
     static int no_xcd_map = -1;
     if (no_xcd_map < 0) no_xcd_map = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
     p.xcd_m = (p.m_tiles % 8 == 0 && !no_xcd_map) ? 8 : 0;
+    auto log2_or_neg = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
+    p.tpi_shift = log2_or_neg(p.tiles_x * p.tiles_y);
+    p.tx_shift = log2_or_neg(p.tiles_x);
     p.abl = 0;
     p.stamps = g_stamps;
     int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;
