@@ -84,10 +84,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     bool set_ok[2] = {false, false};
     int st_item = item, st_chunk = 0;
     bool st_valid = true;
+    // first pixel of an item's tile: item / n_slices is a ~20-instruction scalar division, and it was paid per staged chunk;
+    // the block's items are G apart and G % n_slices == 0, so the tile advances by a constant
+    const int m0_step = (G / p.n_slices) * 128;
+    int st_m0 = (item / p.n_slices) * 128, cur_m0 = st_m0;
     auto issue = [&](int S) __attribute__((always_inline)) {
         set_ok[S] = st_valid;
         if (!st_valid) return;
-        const int m0 = (st_item / p.n_slices) * 128;
+        const int m0 = st_m0;
         const int c = st_chunk * 64 + cv * 8;
         const int cc = c < ctot ? c : 0;                        // zero-weight padding: any finite data will do
         const bf16* src;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
             }
         }
-        if (++st_chunk == p.nch) { st_chunk = 0; st_item += G; }
+        if (++st_chunk == p.nch) { st_chunk = 0; st_item += G; st_m0 += m0_step; }
         st_valid = st_item < p.total_items;
     };
     unsigned abh[2][8];                                         // GroupNorm (scale, shift), fp16x2, for pixel halves 0-63 / 64-127
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         }
 
         // ---- epilogue: buffer 1 is free (the last chunk of an item has odd parity), buffer 0 holds the next item's chunk 0
-        const int m0 = (item / p.n_slices) * 128;
+        const int m0 = cur_m0;
+        cur_m0 += m0_step;
         bf16* scr = xt + TILE + wave * (64 * SCR_STR);
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
