@@ -47,7 +47,8 @@ struct ConvV2Params {
     int m_tiles, n_slices, total_items, steps_per_item;
     int up_m;               // UP4 kernels: XCDs per cout slice when the L2-friendly (tile, parity) order applies, else 0
     int xcd_m;              // other kernels: XCDs per cout slice when each of them walks a contiguous range of pixel tiles, else 0
-    int tpi_shift, tx_shift; // conv_v3: log2 of tiles per image / per tile row when those are powers of two, else -1
+    int tpi_shift, tx_shift; // log2 of tiles per image / per tile row when those are powers of two, else -1
+    int ns_shift, xm_shift;  // conv_v2: log2 of n_slices / of the XCD group count (xcd_m or up_m: 8 / n_slices) when powers of two, else -1
     unsigned long long* stamps;   // diagnostic build (HSIDM_V2_STAMPS): [block][wave][item<8][slot<16] s_memtime
     int abl;                // diagnostic ablation mask (HSIDM_V2_ABL): 1 no stores, 2 no transform, 4 no halo loads, 8 no weight loads, 16 no commits
 };
@@ -212,12 +213,26 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     bf16x8 ring[3][4];
     // item -> (pixel tile, output parity).  UP4 with up_m > 0: the four parities of one input tile are consecutive work
     // of ONE XCD (blocks b, b+8, b+16, b+24), so its L2 fetches the tile once.
+    // (divisions by run-time values are ~20 scalar instructions each and an item needs some twenty of them: shifts whenever the
+    // divisor is a power of two, which the UNet's tile grids, slice counts and XCD groups are)
+    auto div_ns = [&](int x) __attribute__((always_inline)) -> int { return p.ns_shift >= 0 ? x >> p.ns_shift : x / p.n_slices; };
+    auto div_tpi = [&](int x) __attribute__((always_inline)) -> int { return p.tpi_shift >= 0 ? x >> p.tpi_shift : x / (p.tiles_x * p.tiles_y); };
+    auto div_tx = [&](int x) __attribute__((always_inline)) -> int { return p.tx_shift >= 0 ? x >> p.tx_shift : x / p.tiles_x; };
     auto item_tile = [&](int it, int& par) __attribute__((always_inline)) -> int {
-        const int mt = it / p.n_slices;
+        const int mt = div_ns(it);
         // blocks of one XCD (b % 8) that share a cout slice hold tiles mt = x, x + m, x + 2m, ... (m = 8 / n_slices); re-ordered so
         // that each XCD walks a contiguous range, neighbouring tiles - which share halo rows and columns - meet in one L2
-        if (!UP4) { par = 0; return p.xcd_m > 0 ? (mt % p.xcd_m) * (p.m_tiles / p.xcd_m) + mt / p.xcd_m : mt; }
-        if (p.up_m > 0) { par = (mt / p.up_m) & 3; return (mt / (4 * p.up_m)) * p.up_m + mt % p.up_m; }
+        if (!UP4) {
+            par = 0;
+            if (p.xcd_m <= 0) return mt;
+            if (p.xm_shift >= 0) return (mt & (p.xcd_m - 1)) * (p.m_tiles >> p.xm_shift) + (mt >> p.xm_shift);
+            return (mt % p.xcd_m) * (p.m_tiles / p.xcd_m) + mt / p.xcd_m;
+        }
+        if (p.up_m > 0) {
+            if (p.xm_shift >= 0) { par = (mt >> p.xm_shift) & 3; return ((mt >> (p.xm_shift + 2)) << p.xm_shift) + (mt & (p.up_m - 1)); }
+            par = (mt / p.up_m) & 3;
+            return (mt / (4 * p.up_m)) * p.up_m + mt % p.up_m;
+        }
         par = mt & 3;
         return mt >> 2;
     };
@@ -271,11 +286,12 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     auto tile_coords = [&](int it, int& b0, int& oy0, int& ox0) __attribute__((always_inline)) {   // tile origin on the staged grid
         int par_;
         const int mt = item_tile(it, par_);
-        const int tg = mt / tiles_per_img;
+        const int tg = div_tpi(mt);
         const int tr = mt - tg * tiles_per_img;
         b0 = tg * NI;
-        oy0 = (tr / p.tiles_x) * TH;
-        ox0 = (tr % p.tiles_x) * TW;
+        const int try_ = div_tx(tr);
+        oy0 = try_ * TH;
+        ox0 = (tr - try_ * p.tiles_x) * TW;
     };
     auto describe = [&](int it) __attribute__((always_inline)) {
         int b0, oy0, ox0;
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             const int n_s = n0 + wn * 32 + (lane_s & 31);
             const int nn = n_s < p.Cout ? n_s : 0;
             int par_;
-            const int fb0 = (item_tile(item, par_) / tiles_per_img) * NI;
+            const int fb0 = div_tpi(item_tile(item, par_)) * NI;
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
                 const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
@@ -531,7 +547,8 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         HSIDM_STAMP(it, 12);
         int b0, oy0, ox0;
         tile_coords(item, b0, oy0, ox0);
-        const int trem = UP4 ? (it_tile % tiles_per_img) * 4 + par : it_tile % tiles_per_img;   // statistics slot in the image
+        const int it_rem = it_tile - div_tpi(it_tile) * tiles_per_img;
+        const int trem = UP4 ? it_rem * 4 + par : it_rem;   // statistics slot in the image
         constexpr int US = UP4 ? 2 : 1;                                       // output pixel = US * tile pixel + parity
         const int oyb = US * oy0 + py, oxb = US * ox0 + px;                  // (py = px = 0 unless UP4)
         const int lim_h = UP4 ? p.Hin : p.Hout, lim_w = UP4 ? p.Win : p.Wout;

@@ -35,6 +35,11 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     if (no_xcd_map < 0) no_xcd_map = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
     p.xcd_m = 0;
     if (!C::UP4 && !no_xcd_map && 8 % p.n_slices == 0 && p.m_tiles % (8 / p.n_slices) == 0) p.xcd_m = 8 / p.n_slices;
+    auto log2_or_neg = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (v > 0 && (1 << sh) == v) ? sh : -1; };
+    p.ns_shift = log2_or_neg(p.n_slices);
+    p.xm_shift = log2_or_neg(C::UP4 ? p.up_m : p.xcd_m);
+    p.tpi_shift = log2_or_neg(p.tiles_x * p.tiles_y);
+    p.tx_shift = log2_or_neg(p.tiles_x);
     p.total_items = p.m_tiles * p.n_slices;
     int lcm = 8;
     while (lcm % p.n_slices) lcm += 8;
