@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the denoising hot path: SR3 UNet p_sample steps over GAE-latent batches on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 from a plain shell: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process
+(before anything touches the GPU) and exits with its return code; under torch.distributed.run (RANK / WORLD_SIZE set) it is
+one rank per GPU over RCCL.  --total-patches P: strong scaling (BASELINE configs[3]: P patches sharded over the ranks).
 
 A "step" is one reverse-diffusion step (noise embedding + full 97.8 M-parameter UNet forward + fused
 posterior update) over this GPU's batch of latents: `--patches` CAVE patches x 5 spectral groups, each a
@@ -13,10 +17,16 @@ Extra objects in the line:
   roofline     - the implicit-GEMM conv kernel family (the dominant kernel): algorithmic FLOPs of its launches
                  in one step / their HIP-event durations, against the dense bf16 MFMA peak.
   cpu_baseline - the oracle (CPU restatement of the reference, oracle/) timed on this host, rank 0, N=1 only.
+  fp32_mode    - the same step in the fp32 ("bf16x3 split") parity mode: ms per step, throughput, dominant-kernel roofline
+                 (rank 0, N=1 only; the mode that carries the 1e-3 parity gate).
+  gae          - group-autoencoder encode / decode of this rank's patches (31 x 128 x 128 CAVE cubes): ms, TFLOP/s,
+                 fraction of the MFMA peak (the step before / after the chain, sr_gae.py:456,467).
+  rccl_ranks / allgather_ms - N > 1: ranks in the RCCL group and the time of the final all-gather of the SR cubes.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -47,7 +57,7 @@ def build_model(dev, precision):
     return gd
 
 
-def conv_roofline(run, batch, reps=3):
+def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1):
     """Roofline of the DOMINANT kernel of one step.  Every conv launch of one eager step is bracketed with HIP events
     on the launch stream (best of `reps`); launches are grouped by the kernel the C ABI dispatches to
     (hsidm_conv_kernel_id) and the group with the largest total time is reported:
@@ -81,7 +91,7 @@ def conv_roofline(run, batch, reps=3):
         traffic = json.load(open(tf)).get(name)
         if traffic is not None and traffic.get("batch_per_gpu") not in (None, batch):
             traffic = None                                      # counters were collected at another batch: not this run's traffic
-    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12       # algorithmic FLOPs (the fp32 mode issues `passes` MFMAs per product)
     # the launch closest to the HBM roof (north-star: "fraction of the HBM roofline on the fused ResnetBlock kernel"): a 3x3
     # GN+SiLU conv of the 128x128 level; algorithmic bytes = activations in + out + weights, against the 8 TB/s spec
     hb = max((r for r in best if r["ksize"] == 3 and r["stride"] == 1 and "gn+silu" in r["kernel"]), key=lambda r: r["bytes"] / r["ms"])
@@ -89,7 +99,7 @@ def conv_roofline(run, batch, reps=3):
                     algorithmic_bytes=hb["bytes"], achieved_GBps=hb["bytes"] / (hb["ms"] * 1e-3) / 1e9, peak_GBps=HBM_PEAK_GBPS,
                     frac=hb["bytes"] / (hb["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     tflops=hb["flops"] / (hb["ms"] * 1e-3) / 1e12)
-    return dict(bound="mfma", hbm_view=hbm_view, achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK_TFLOPS,
+    return dict(bound="mfma", hbm_view=hbm_view, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, mfma_passes_per_product=passes,
                 traffic=traffic, kernel=name, launches=dom["n"], avg_launch_us=dom["ms"] / dom["n"] * 1e3,
                 algorithmic_flops_per_launch=dom["flops"] / dom["n"], algorithmic_bytes_per_launch=dom["bytes"] / dom["n"],
                 share_of_conv_time=dom["ms"] / all_ms,
@@ -149,6 +159,47 @@ def usable_cpus():
     return max(1, n)
 
 
+def gae_bench(dev, patches, reps=5):
+    """Group-autoencoder encode / decode of `patches` CAVE cubes (31 x 128 x 128, G = 5 groups stacked on the batch axis),
+    pretrained-checkpoint architecture (n_subs 8, n_ovls 2, 64 features), fp32 parity mode and bf16."""
+    from hsi_dmgasr_amd import gae
+    out = {}
+    flops = dict(encode=41.3e9, decode=41.3e9 + 1.9e9)          # per patch at 128 x 128 (SURVEY Appendix B; decode includes the trunk)
+    x = torch.rand(patches, 31, 128, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+    for prec in ("bf16", "fp32"):
+        m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision=prec).to(dev).eval()
+        z = m.encode_batched(x)
+        rec = {}
+        for name, fn in (("encode", lambda: m.encode_batched(x)), ("decode", lambda: m.decode_batched(z, 31))):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e30
+            for _ in range(reps):
+                e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            tf = flops[name] * patches / (best * 1e-3) / 1e12
+            rec[name + "_ms"] = best
+            rec[name + "_tflops"] = tf
+            rec[name + "_frac_of_mfma_peak"] = tf / MFMA_BF16_PEAK_TFLOPS
+        out[prec] = rec
+        del m, z
+    out["patches"] = patches
+    out["cube"] = "31x128x128, G=5"
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: re-run under torch.distributed.run as a CHILD process (never exec:
+    nothing here has touched the GPU yet, and nothing will in this parent)."""
+    port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,19 +208,24 @@ def main():
     ap.add_argument("--patches", type=int, default=48,
                     help="CAVE patches per GPU (x5 spectral groups = batch of 240 latents); throughput saturates around here: "
                          "120 latents -3 %, 640 latents +2 % (sweep in DESIGN.md)")
+    ap.add_argument("--total-patches", type=int, default=0,
+                    help="strong scaling: this many patches in total, sharded contiguously over the ranks (BASELINE configs[3]: 64)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode object")
+    ap.add_argument("--no-gae", action="store_true", help="skip the group-autoencoder object")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     torch.set_num_threads(min(usable_cpus(), 64))      # the host may expose 256 CPUs behind a 16-CPU quota
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -184,11 +240,19 @@ def main():
     gd = build_model(dev, args.precision)
     log('model on device')
     parallel.broadcast_module_(gd, src=0)                  # one-time weight broadcast over xGMI
-    batch = args.patches * GROUPS
+    if args.total_patches:
+        lo, hi = parallel.shard_range(args.total_patches, rank, world)
+        patches, total_patches, scaling = hi - lo, args.total_patches, "strong"
+    else:
+        patches, total_patches, scaling = args.patches, args.patches * world, "weak"
+    if patches <= 0:
+        raise SystemExit("rank %d has no patches (--total-patches %d over %d ranks)" % (rank, args.total_patches, world))
+    batch = patches * GROUPS
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
     cond = torch.randn((batch, 3, 128, 128), generator=g).clamp(-2.5, 2.5).to(dev)   # GAE latent range
     run = gd.make_run(cond, wrap=True)
 
+    allgather_ms = None
     with torch.no_grad():
         for _ in range(max(args.warmup, 2)):               # >= 2: eager step, then graph capture + first replay
             run.step()
@@ -211,32 +275,74 @@ def main():
         dt = float(el.item())
         assert torch.isfinite(run.x).all(), "sampler state diverged"
         log('timed region done: %.3f s' % dt)
+        if use_dist:
+            # the path's one data collective: every rank ends with all SR cubes (here: cube-sized stand-ins for the decoded
+            # patches, 31 x 128 x 128 fp32 each = 2.0 MB per patch)
+            cubes = torch.zeros((patches, 31, 128, 128), dtype=torch.float32, device=dev)
+            parallel.all_gather_patches(cubes, total_patches)            # warm-up (communicator set-up)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            full = parallel.all_gather_patches(cubes, total_patches)
+            torch.cuda.synchronize()
+            allgather_ms = (time.perf_counter() - t1) * 1e3
+            assert full.shape[0] == total_patches
+            del cubes, full
 
         roof = None
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(run, batch)
     log('roofline done')
+    fp32 = None
+    if rank == 0 and world == 1 and not args.no_fp32 and args.precision == "bf16":
+        # the parity mode (fp32 storage, every product as three bf16 MFMAs) on the same workload and batch
+        del run
+        torch.cuda.empty_cache()
+        with torch.no_grad():
+            run32 = gd.make_run(cond, wrap=True, precision="fp32")
+            n32 = max(10, min(50, args.steps // 20))
+            for _ in range(3):
+                run32.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n32):
+                run32.step()
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t0
+            assert torch.isfinite(run32.x).all()
+            fp32 = dict(value=n32 * batch / d32, unit="denoise-steps*batch/s", ms_per_step=d32 / n32 * 1e3, steps=n32,
+                        dtype="fp32 storage, bf16 hi+lo split, 3 MFMA passes per product",
+                        roofline=None if args.no_roofline else conv_roofline(run32, batch, reps=2, passes=3))
+            del run32
+        torch.cuda.empty_cache()
+        log('fp32 mode done')
+    gae_rec = None
+    if rank == 0 and not args.no_gae:
+        with torch.no_grad():
+            gae_rec = gae_bench(dev, patches)
+        log('gae done')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
         log('cpu baseline done')
 
     if rank == 0:
-        total_batch = batch * world
+        total_batch = total_patches * GROUPS
         line = {
             "metric": "UNet denoise-steps/sec x batch, CAVE 31-band 16->128, 1000-step p_sample_loop",
             "value": args.steps * total_batch / dt,
             "unit": "denoise-steps*batch/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "fp32 (bf16x3 split)",
             "data": "synthetic (orthogonal-init weights seed 0, N(0,1) latents clipped to +-2.5, Philox noise)",
             "config": {"workload": "SR3 UNet 97.8M (6->3 ch, inner 64, mults 1-2-4-8-8, attn@16) p_sample step on "
-                                   "GAE latents 3x128x128, cosine T=1000, BASELINE configs[1]",
-                       "patches_per_gpu": args.patches, "groups_per_patch": GROUPS,
+                                   "GAE latents 3x128x128, cosine T=1000, BASELINE configs[%d]" % (3 if scaling == "strong" else 1),
+                       "patches_per_gpu": patches, "total_patches": total_patches, "groups_per_patch": GROUPS,
                        "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world},
-            "roofline": roof, "cpu_baseline": cpu,
+            "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": allgather_ms,
+            "roofline": roof, "fp32_mode": fp32, "gae": gae_rec, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if use_dist:

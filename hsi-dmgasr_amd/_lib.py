@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
 # name -> argtypes, exactly the prototypes of include/hsidm.h
 SIGNATURES = {
     "hsidm_version": [],
+    "hsidm_debug_switch": [C.c_char_p, _i32],
     "hsidm_conv_bk": [_i32],
     "hsidm_conv2d": [C.POINTER(ConvDesc), _vp],
     "hsidm_conv_stats_nsplit": [C.POINTER(ConvDesc)],
@@ -84,6 +85,24 @@ def lib():
         L.hsidm_error_string.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+class debug_switch:
+    """Context manager around hsidm_debug_switch (diagnostic A/B dispatch switches, include/hsidm.h):
+    ``with debug_switch("NO_V3", 1): ...`` restores the previous value on exit."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        self.old = lib().hsidm_debug_switch(self.name, self.value)
+        if self.old < 0:
+            check(self.old, "debug_switch")
+        return self
+
+    def __exit__(self, *exc):
+        lib().hsidm_debug_switch(self.name, self.old)
+        return False
 
 
 def check(code, what):

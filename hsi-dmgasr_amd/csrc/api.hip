@@ -1,6 +1,7 @@
 // C-ABI entry points: argument validation, tile selection and dispatch for the convolution.
 #include "conv_v2.h"
 #include <cstdlib>
+#include <cstring>
 #include "../../include/hsidm.h"
 
 namespace hsidm {
@@ -44,15 +45,38 @@ extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec 
 
 enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4 };
 
-// HSIDM_1X1=v1 (diagnostic): keep 1x1 convolutions on the generic kernel for A/B measurements
-static bool force_v1_1x1() {
-    static int mode = -1;
-    if (mode < 0) {
+// ---- diagnostic switches (common.h: DebugKey) ------------------------------------------------------
+namespace {
+struct DebugTable {
+    std::atomic<int> v[hsidm::DBG_COUNT];
+    DebugTable() {
+        auto env_int = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+        v[hsidm::DBG_NO_V3] = getenv("HSIDM_NO_V3") ? 1 : 0;
+        v[hsidm::DBG_V2_BN256] = env_int("HSIDM_V2_BN256", 1);
+        v[hsidm::DBG_ATTENTION_V1] = getenv("HSIDM_ATTENTION_V1") ? 1 : 0;
+        v[hsidm::DBG_NO_XCD_MAP] = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
         const char* e = getenv("HSIDM_1X1");
-        mode = (e && e[0] == 'v') ? 1 : 0;
+        v[hsidm::DBG_1X1_V1] = (e && e[0] == 'v') ? 1 : 0;
+        v[hsidm::DBG_V2_ABL] = env_int("HSIDM_V2_ABL", 0);
+        v[hsidm::DBG_NO_FUSED_PROJ] = getenv("HSIDM_NO_FUSED_PROJ") ? 1 : 0;
     }
-    return mode == 1;
+};
+DebugTable g_debug;          // constructed when the library is loaded
+const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "NO_FUSED_PROJ"};
+}  // namespace
+int hsidm::debug_get(int key) { return g_debug.v[key].load(std::memory_order_relaxed); }
+
+extern "C" int hsidm_debug_switch(const char* name, int value) {
+    if (!name) return HSIDM_E_BADARG;
+    for (int i = 0; i < hsidm::DBG_COUNT; ++i)
+        if (!strcmp(name, kDebugNames[i])) {
+            const int old = g_debug.v[i].exchange(value);
+            return old < 0 ? 0 : old;
+        }
+    return HSIDM_E_BADARG;
 }
+
+static bool force_v1_1x1() { return debug_get(DBG_1X1_V1) == 1; }
 
 static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
     if (!d) return HSIDM_E_BADARG;
@@ -89,7 +113,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     // fp32 NCHW output (the UNet's final Block, 64 -> 3): one padded 32-cout slice on the 256-pixel kernel (conv_v3.hip, WN = 1)
     if (d->prec == HSIDM_BF16 && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
         xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 32 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
-        !d->stats && d->act == HSIDM_ACT_NONE && !getenv("HSIDM_NO_V3")) path = PATH_V3;
+        !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
     if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
         // 8x8 maps: two-image tiles halve the work items; when those would leave half of the co-resident workgroup slots
@@ -98,7 +122,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
             (long long)d->B * ((d->Cout + 127) / 128) <= conv_v2_slots()) tile_kind = 2;
         // 64-cout GN+SiLU layers on whole 16x16 tiles: the 256-pixel kernel (conv_v3.hip); HSIDM_NO_V3=1: diagnostic A/B switch
         if (path == PATH_V2 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 64 && d->Cout == 64 && Hout % 16 == 0 &&
-            Wout % 16 == 0 && !getenv("HSIDM_NO_V3")) path = PATH_V3;
+            Wout % 16 == 0 && !debug_get(DBG_NO_V3)) path = PATH_V3;
         // 8 input channels (one 16-byte vector per pixel): w_v2 is the tap-major GEMM layout (include/hsidm.h), which only
         // the GEMM kernel reads
         if (d->ksize == 3 && d->ph[0].C0 + d->ph[0].C1 == 8) {
@@ -120,8 +144,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
 // instead of once per 128 (measured at batch 240: 16x16 level +7 %, 8x8 level +11 %, 32x32 level +1..2 %, step +1.5 %).
 // Only when that still occupies half of the CUs: the items are half as many and the slots are one per CU.  HSIDM_V2_BN256=0 disables it.
 static int v2_slice(const hsidm_conv_desc* d, int Hout, int Wout, int tile_kind, int path) {
-    const char* e = getenv("HSIDM_V2_BN256");                  // read per launch: the tests switch it
-    const int on = e ? atoi(e) : 1;
+    const int on = debug_get(DBG_V2_BN256);
     if (!on || path != PATH_V2 || tile_kind == 2 || d->bn != 128 || d->stride != 1 || d->ups ||
         d->ph[0].transform != HSIDM_XF_AFFINE_SILU || d->Cout % 256) return d->bn;
     const int TW = tile_kind == 0 ? 16 : 8;

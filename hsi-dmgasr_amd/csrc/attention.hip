@@ -193,13 +193,8 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
     const size_t reg0 = ((q_bytes > vt_bytes ? q_bytes : vt_bytes) + 15) & ~(size_t)15;
     const size_t lds = reg0 + (size_t)32 * SS * 4;
     if (lds > 160 * 1024) return HSIDM_E_UNSUPPORTED;
-    static bool attr_done = false;              // raise the dynamic-LDS cap once (not a stream operation)
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<ActT, SPLIT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static PerDeviceOnce once;                  // raise the dynamic-LDS cap once per device (not a stream operation)
+    if (int rc = raise_lds_cap(once, &attention_kernel<ActT, SPLIT>, 160 * 1024)) return rc;
     dim3 grid((N + 31) / 32, B);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_kernel<ActT, SPLIT>), grid, dim3(256), lds, s, (const ActT*)qkv, (ActT*)out, N, C,
                        1.0f / sqrtf((float)C));
@@ -365,13 +360,8 @@ __global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attentio
 template <int NKT, int NW>
 static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 32 * NKT * HSIDM_ATT_VRS * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_v2_kernel<NKT, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &attention_v2_kernel<NKT, NW>, lds)) return rc;
     dim3 grid(NKT / NW, B);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW>), grid, dim3(64 * NW), lds, s, (const bf16*)qkv, (bf16*)out, C,
                        1.0f / sqrtf((float)C));
@@ -383,7 +373,7 @@ static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStre
 extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int N, int C, void* stream) {
     if (!qkv || !out || B <= 0 || N <= 0 || C <= 0 || (C & 31)) return HSIDM_E_BADARG;
     if (N > 1024) return HSIDM_E_UNSUPPORTED;
-    if (prec == HSIDM_BF16 && (C & 63) == 0 && !getenv("HSIDM_ATTENTION_V1")) {     // (env: diagnostic A/B switch)
+    if (prec == HSIDM_BF16 && (C & 63) == 0 && !hsidm::debug_get(hsidm::DBG_ATTENTION_V1)) {     // (diagnostic A/B switch)
         if (N == 256) return hsidm::launch_attention_v2<8, 4>(qkv, out, B, C, (hipStream_t)stream);
         if (N == 64) return hsidm::launch_attention_v2<2, 2>(qkv, out, B, C, (hipStream_t)stream);
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace hsidm {
 
@@ -72,5 +73,43 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- host-side helpers ------------------------------------------------------------------------
+// One-time set-up per (call site, DEVICE): function attributes such as the dynamic-LDS cap belong to the device the
+// calling thread has current, so a process that drives several devices (one thread each, like nn.DataParallel) must
+// repeat them per device.  Lock-free; the guarded calls are idempotent, so a race only repeats one.
+struct PerDeviceOnce { std::atomic<uint64_t> mask{0}; };
+template <typename F>
+inline int per_device_once(PerDeviceOnce& st, F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (st.mask.load(std::memory_order_acquire) & bit) return 0;
+    const int rc = f();
+    if (rc) return rc;
+    st.mask.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+template <typename K>
+inline int raise_lds_cap(PerDeviceOnce& st, K kernel, size_t bytes) {
+    return per_device_once(st, [&] { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); });
+}
+// compute units of the calling thread's current device (cached per device)
+inline int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int c = cache[dev & 63].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cache[dev & 63].store(c, std::memory_order_relaxed);
+    return c;
+}
+// Diagnostic switches (A/B measurements and tests): set once from the environment when the library is loaded
+// (HSIDM_NO_V3, HSIDM_V2_BN256, HSIDM_ATTENTION_V1, HSIDM_NO_XCD_MAP, HSIDM_1X1, HSIDM_V2_ABL) and afterwards only through
+// hsidm_debug_switch(); the launch path never reads the environment.
+enum DebugKey { DBG_NO_V3 = 0, DBG_V2_BN256, DBG_ATTENTION_V1, DBG_NO_XCD_MAP, DBG_1X1_V1, DBG_V2_ABL, DBG_NO_FUSED_PROJ, DBG_COUNT };
+int debug_get(int key);
 
 }  // namespace hsidm

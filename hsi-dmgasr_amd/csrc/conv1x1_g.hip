@@ -315,24 +315,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     }
 }
 
-static int g1_slots = 0;
 
 template <int BN, int XF, int IM = 0>
 static int run_g1(C1gParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 128 * 72 * 2 + 2048;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_g_kernel<BN, XF, IM>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        done = true;
-    }
-    if (g1_slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        g1_slots = 2 * cus;
-    }
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM>, lds)) return rc;
+    const int g1_slots = 2 * device_cus();
     p.n_slices = p.Cout_pad / BN;
     p.m_tiles = (p.M + 127) / 128;
     p.total_items = p.m_tiles * p.n_slices;

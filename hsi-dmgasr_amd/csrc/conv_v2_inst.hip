@@ -4,7 +4,6 @@
 
 namespace hsidm {
 
-static int g_slots = 0;      // co-resident workgroups: 2 per CU
 unsigned long long* g_stamps = nullptr;   // diagnostic builds only
 
 int conv_v2_slots();
@@ -13,17 +12,10 @@ template <typename C>
 static int run_v2(ConvV2Params& p, hipStream_t s) {
     constexpr size_t lds = C::LDS_BYTES;
     static_assert(C::NW == 8 ? lds <= 160 * 1024 : lds <= 80 * 1024, "two workgroups per CU (one with 8 waves)");
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v2_kernel<C>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        done = true;
-    }
-    conv_v2_slots();
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("HSIDM_V2_ABL"); abl = e ? atoi(e) : 0; }
-    p.abl = abl;
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &conv_v2_kernel<C>, lds)) return rc;
+    const int g_slots = conv_v2_slots();
+    p.abl = debug_get(DBG_V2_ABL);
     p.stamps = g_stamps;
     const int imgs = (p.B + C::NI - 1) / C::NI;
     p.n_slices = p.Cout_pad / C::BN;
@@ -31,8 +23,7 @@ static int run_v2(ConvV2Params& p, hipStream_t s) {
     p.m_tiles = C::UP4 ? 4 * tiles : tiles;
     p.up_m = 0;
     if (C::UP4 && 8 % p.n_slices == 0 && tiles % (8 / p.n_slices) == 0) p.up_m = 8 / p.n_slices;
-    static int no_xcd_map = -1;
-    if (no_xcd_map < 0) no_xcd_map = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
+    const int no_xcd_map = debug_get(DBG_NO_XCD_MAP);
     p.xcd_m = 0;
     if (!C::UP4 && !no_xcd_map && 8 % p.n_slices == 0 && p.m_tiles % (8 / p.n_slices) == 0) p.xcd_m = 8 / p.n_slices;
     auto log2_or_neg = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (v > 0 && (1 << sh) == v) ? sh : -1; };
@@ -58,15 +49,7 @@ int conv_v2_subs(int tile_kind, int bn) {
     return tile_kind == 0 ? wm : (wm >= 2 ? wm / 2 : 1);
 }
 
-int conv_v2_slots() {
-    if (g_slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        g_slots = 2 * cus;
-    }
-    return g_slots;
-}
+int conv_v2_slots() { return 2 * device_cus(); }      // co-resident workgroups: 2 per CU
 
 #define V2(BN, TH, TW, NI, XF) run_v2<V2Cfg<BN, TH, TW, NI, XF>>(p, s)
 

@@ -369,39 +369,27 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     }
 }
 
-static int g3_slots = 0;
 extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds)
 
 // Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller); nchw = 0: Cout == 64, NHWC bf16 out;
 // nchw = 1: Cout <= 32 (one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
 template <int WN_, bool NCHW_>
 static int launch_v3(ConvV2Params& p, int G, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_v3_kernel<WN_, NCHW_>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)v3::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        done = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_>, v3::LDS_BYTES)) return rc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
 int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s) {
-    if (g3_slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        g3_slots = 2 * cus;
-    }
+    const int g3_slots = 2 * device_cus();
     p.tiles_x = p.Wout / v3::TW;
     p.tiles_y = p.Hout / v3::TH;
     p.n_slices = 1;
     p.m_tiles = p.B * p.tiles_x * p.tiles_y;
     p.total_items = p.m_tiles;
     p.up_m = 0;
-    static int no_xcd_map = -1;
-    if (no_xcd_map < 0) no_xcd_map = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
+    const int no_xcd_map = debug_get(DBG_NO_XCD_MAP);
     p.xcd_m = (p.m_tiles % 8 == 0 && !no_xcd_map) ? 8 : 0;
     auto log2_or_neg = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
     p.tpi_shift = log2_or_neg(p.tiles_x * p.tiles_y);

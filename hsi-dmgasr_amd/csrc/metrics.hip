@@ -28,14 +28,16 @@ __global__ __launch_bounds__(256) void band_stats_kernel(const float* __restrict
     const int c = blockIdx.x, p = blockIdx.y;
     const float* t = truth + ((size_t)p * C + c) * HW;
     const float* q = pred + ((size_t)p * C + c) * HW;
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // fp64 partials: CC is formed as E[tp] - E[t]E[p] over sqrt of two such differences, which for low-contrast bands
+    // (variance << mean^2) needs more digits than fp32 sums of ~HW/256 terms keep; the kernel is HBM-bound either way
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int i = threadIdx.x; i < HW; i += 256) {
-        const float a = t[i], b = q[i], d = a - b;
-        s[0] += a; s[1] += b; s[2] = fmaf(a, a, s[2]); s[3] = fmaf(b, b, s[3]); s[4] = fmaf(a, b, s[4]); s[5] = fmaf(d, d, s[5]);
+        const double a = t[i], b = q[i], d = a - b;
+        s[0] += a; s[1] += b; s[2] += a * a; s[3] += b * b; s[4] += a * b; s[5] += d * d;
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const double tot = block_sum_f64((double)s[k], red);
+        const double tot = block_sum_f64(s[k], red);
         if (threadIdx.x == 0) stats[((size_t)p * C + c) * 6 + k] = tot;
     }
 }

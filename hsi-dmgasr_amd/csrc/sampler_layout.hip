@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* __restrict_
                                                               int T, const float* __restrict__ noise, int64_t noise_stride, uint64_t seed,
                                                               int64_t n, float* __restrict__ snap, int32_t inter) {
     const int t = *t_ptr;
+    if (t < 0 || t >= T) return;            // a replay past the end of the chain (the host wrapper refuses it too) must not index the tables
     const float a = coef[t * 5 + 0], b = coef[t * 5 + 1], c1 = coef[t * 5 + 2], c2 = coef[t * 5 + 3];
     const float sigma = expf(0.5f * coef[t * 5 + 4]);
     const float* zsrc = noise ? noise + (int64_t)(T - 1 - t) * noise_stride : nullptr;

@@ -266,8 +266,17 @@ class GAE(nn.Module):
 def load_reference_checkpoint(path, precision="fp32", map_location="cpu"):
     """Read one of the reference's whole-module GAE pickles (torch.save(model), AE.py:637; resolved against
     __main__ / common there) WITHOUT the reference's code: every pickled class is replaced by a bare
-    nn.Module stub, the state_dict and group layout are read off it, and a GAE of this package is built."""
+    nn.Module stub, the state_dict and group layout are read off it, and a GAE of this package is built.
+
+    A whole-module pickle is code: unpickling resolves arbitrary globals.  Everything outside the reference's own modules
+    (stubbed) is therefore held to an allowlist - torch tensor/parameter rebuilders, torch.nn module classes, OrderedDict,
+    torch.device / dtype / Size / storage types - and anything else raises UnpicklingError.  Only load files you trust as much as
+    the reference's own GAE_pretrained/*.pth all the same."""
     stubs = {}
+    allowed = {("collections", "OrderedDict"), ("torch", "device"), ("torch", "Size"), ("torch", "dtype"),
+               ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_tensor_v2"),
+               ("torch._utils", "_rebuild_parameter_with_state"), ("torch.serialization", "_get_layout"),
+               ("numpy.core.multiarray", "scalar"), ("numpy", "dtype"), ("__builtin__", "set"), ("builtins", "set")}
 
     class _Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
@@ -275,6 +284,11 @@ def load_reference_checkpoint(path, precision="fp32", map_location="cpu"):
                 if name not in stubs:
                     stubs[name] = type(name, (nn.Module,), {"forward": lambda self, *a, **k: None})
                 return stubs[name]
+            ok = (module, name) in allowed or (module == "torch" and name.endswith("Storage")) or \
+                (module.startswith("torch.nn.modules.") and name[:1].isupper())
+            if not ok:
+                raise pickle.UnpicklingError("hsidm: refusing to resolve %s.%s from a GAE checkpoint (not on the allowlist)"
+                                             % (module, name))
             return super().find_class(module, name)
 
     class _PickleModule:

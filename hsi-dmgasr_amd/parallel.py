@@ -26,20 +26,22 @@ def broadcast_module_(module, src=0, bucket_bytes=256 << 20):
     per-peer, so few large messages beat 374 small ones) and broadcast from `src`."""
     if not (dist.is_available() and dist.is_initialized()):
         return module
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.is_floating_point()]
+    # the tensors themselves, not `.data`: copy_ below must bump `_version` so that packed-weight caches notice
+    tensors = list(module.parameters()) + [b for b in module.buffers() if b.is_floating_point()]
     bucket, size = [], 0
 
     def flush():
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([t.reshape(-1) for t in bucket])
-        dist.broadcast(flat, src=src)
-        off = 0
-        for t in bucket:
-            n = t.numel()
-            t.copy_(flat[off:off + n].view_as(t))
-            off += n
+        with torch.no_grad():
+            flat = torch.cat([t.detach().reshape(-1) for t in bucket])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in bucket:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
         bucket, size = [], 0
 
     dtype = None

@@ -100,6 +100,8 @@ class ReverseRun:
         ops.step_advance(self.t_ptr, self.T if self.wrap else 0)
 
     def step(self):
+        if not self.wrap and self.steps_done >= self.T:
+            raise RuntimeError("hsidm: the chain has run its %d steps (t would be -1); make a new run or use wrap=True" % self.T)
         if not (self.fused and self.gd.use_graph):
             self._enqueue()
         elif self.steps_done == 0:
@@ -215,13 +217,10 @@ class GaussianDiffusion(nn.Module):
     # ---------------------------------------------------------------------------------- reverse process
     def _denoise(self, cond, x, t_ptr, precision=None):
         fn = self.denoise_fn
-        if isinstance(fn, UNet):
-            return fn.forward_pair(cond, x, level_table=self._run_level, t_ptr=t_ptr, precision=precision)
-        # a foreign denoiser module: reference call convention (diffusion.py:154-161), host-side level
-        t = int(t_ptr.item())
-        lvl = torch.full((x.shape[0], 1), float(np.float32(self._run_level_host[t + 1])), device=x.device)
-        inp = torch.cat([cond, x], dim=1) if cond is not None else x
-        return fn(inp, lvl)
+        if not isinstance(fn, UNet):
+            raise TypeError("hsidm: denoise_fn must be hsi_dmgasr_amd.sr3_modules.unet.UNet (the reverse step is one captured "
+                            "chain of HIP kernels with a device-side step counter; there is no eager path for foreign modules)")
+        return fn.forward_pair(cond, x, level_table=self._run_level, t_ptr=t_ptr, precision=precision)
 
     def make_run(self, cond, shape=None, continous=False, x_T=None, noise=None, precision=None, wrap=False):
         """Device-resident reverse process over `cond` (see ReverseRun)."""
@@ -284,10 +283,9 @@ class GaussianDiffusion(nn.Module):
         x_noisy = self.q_sample(x_start, gamma, noise)
         fn = self.denoise_fn
         cond = x_in["SR"].contiguous() if self.conditional else None
-        if isinstance(fn, UNet):
-            x_recon = fn.forward_pair(cond, x_noisy, gamma=gamma)
-        else:
-            x_recon = fn(torch.cat([cond, x_noisy], dim=1) if cond is not None else x_noisy, gamma.view(b, -1))
+        if not isinstance(fn, UNet):
+            raise TypeError("hsidm: denoise_fn must be hsi_dmgasr_amd.sr3_modules.unet.UNet")
+        x_recon = fn.forward_pair(cond, x_noisy, gamma=gamma)
         if self.loss_type not in ("l1", "l2"):
             raise NotImplementedError()
         return ops.loss_sum(noise, x_recon.contiguous(), self.loss_type)

@@ -14,8 +14,6 @@ for naming / loading / initialisation; the arithmetic runs in libhsidm.so on NHW
 
 There is no eager fallback: inputs must be ROCm tensors and the library must be built.
 """
-import math
-
 import torch
 from torch import nn
 
@@ -55,24 +53,28 @@ class _PackCache:
         return hit[1]
 
 
+def _kernel_only(what):
+    raise RuntimeError("hsidm: %s holds parameters / names only; its arithmetic runs inside a fused kernel of the enclosing "
+                       "module (there is no eager path) - call the enclosing module" % what)
+
+
 class PositionalEncoding(nn.Module):
-    """Parameter-free sinusoidal embedding of the noise level (reference unet.py:18-31).  Inside UNet it is
-    evaluated by hsidm_noise_film; this standalone forward exists for interface parity only."""
+    """Parameter-free sinusoidal embedding of the noise level (reference unet.py:18-31): a placeholder in
+    ``noise_level_mlp`` that keeps the reference's module indices; evaluated by hsidm_noise_film (UNet.noise_embedding)."""
 
     def __init__(self, dim):
         super().__init__()
         self.dim = dim
 
     def forward(self, noise_level):
-        half = self.dim // 2
-        freq = torch.exp(-math.log(1e4) * torch.arange(half, dtype=noise_level.dtype, device=noise_level.device) / half)
-        ang = noise_level.unsqueeze(1) * freq.unsqueeze(0)
-        return torch.cat([ang.sin(), ang.cos()], dim=-1)
+        _kernel_only("PositionalEncoding")
 
 
 class Swish(nn.Module):
+    """x * sigmoid(x) (reference unet.py:53-55): fused into the operand staging of the following convolution."""
+
     def forward(self, x):
-        return x * torch.sigmoid(x)
+        _kernel_only("Swish")
 
 
 class FeatureWiseAffine(nn.Module):
@@ -86,8 +88,8 @@ class FeatureWiseAffine(nn.Module):
         self.use_affine_level = use_affine_level
         self.noise_func = nn.Sequential(nn.Linear(in_channels, out_channels))
 
-    def forward(self, x, noise_embed):   # interface parity; UNet never calls this
-        return x + self.noise_func(noise_embed).view(x.shape[0], -1, 1, 1)
+    def forward(self, x, noise_embed):
+        _kernel_only("FeatureWiseAffine")
 
 
 class _HipModule(nn.Module):

@@ -64,3 +64,31 @@ COLOR_CASES = {"a/all": 31, "b/all": 8, "b/first5": 5}     # metric_pair tag / l
 def augment_input():
     """(H, W, C) float32, non-square so that quarter turns are visible in the shape (augment.npz)."""
     return synth_tensor("augment.x", AUGMENT_SHAPE).astype(np.float32)
+
+
+def chain_cubes(hw=128, bands=31):
+    """(hr, sr) float32 [1, bands, hw, hw] in [0, 1] for the full-size chain golden (chain.npz): hr = a band- and space-smoothed
+    uniform cube, sr = its 7x7 box blur (a stand-in for the bicubic-degraded input; only its range and smoothness matter)."""
+    rng = np.random.Generator(np.random.PCG64(20))
+    c = rng.random((bands + 2, hw + 8, hw + 8)).astype(np.float64)
+    c = (c[:-2] + c[1:-1] + c[2:]) / 3.0
+
+    def box(a, k):
+        cs = np.cumsum(np.cumsum(np.pad(a, ((0, 0), (1, 0), (1, 0))), axis=1), axis=2)
+        return (cs[:, k:, k:] - cs[:, :-k, k:] - cs[:, k:, :-k] + cs[:, :-k, :-k]) / (k * k)
+
+    hr = box(c, 3)                                  # (bands, hw+6, hw+6)
+    sr = box(hr, 7)                                 # (bands, hw, hw)
+    hr = hr[:, 3:-3, 3:-3]
+    lo, hi = hr.min(), hr.max()
+    hr = (hr - lo) / (hi - lo)
+    sr = np.clip((sr - lo) / (hi - lo), 0.0, 1.0)
+    return hr[None].astype(np.float32), sr[None].astype(np.float32)
+
+
+CHAIN_T = 20          # the reference's shipped chain length (config/sr_sr3_16_128.json:96-107)
+
+
+def chain_noise(group, k, shape=(1, 3, 128, 128)):
+    """Noise tensor k of spectral group `group` in the chain golden: k = 0 is x_T, k = 1..T-1 the per-step draws in loop order."""
+    return synth_tensor("chain.noise.g%d.k%d" % (group, k), shape)

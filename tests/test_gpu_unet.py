@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from gpu_util import assert_stats, check, fill_synth
+from hsi_dmgasr_amd import _lib
 from helpers import jload, load_npz, sub_shapes, synth_sd, synth_tensor
 
 pytestmark = pytest.mark.gpu
@@ -330,10 +331,9 @@ def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
     ref = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
     got = ops.attention(qkv.to(dev), "bf16")
     torch.cuda.synchronize()
-    monkeypatch.setenv("HSIDM_ATTENTION_V1", "1")
-    old = ops.attention(qkv.to(dev), "bf16")
-    torch.cuda.synchronize()
-    monkeypatch.delenv("HSIDM_ATTENTION_V1")
+    with _lib.debug_switch("ATTENTION_V1", 1):
+        old = ops.attention(qkv.to(dev), "bf16")
+        torch.cuda.synchronize()
     check("attention%s" % (shape,), "bf16", got.reshape(B, H * W, C), ref, tol=1e-2)
     check("attention_panel%s" % (shape,), "bf16", old.reshape(B, H * W, C), ref, tol=1e-2)
 
@@ -396,12 +396,9 @@ def test_conv_v3_residual_and_dispatch(dev, monkeypatch):
     film = torch.randn(B, Co, generator=g).to(dev)
     outs, slabs = [], []
     for no_v3 in (True, False):
-        if no_v3:
-            monkeypatch.setenv("HSIDM_NO_V3", "1")
-        else:
-            monkeypatch.delenv("HSIDM_NO_V3")
-        y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab), transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
-        torch.cuda.synchronize()
+        with _lib.debug_switch("NO_V3", int(no_v3)):
+            y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab), transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
+            torch.cuda.synchronize()
         slab, nsplit = y._hsidm_stats
         yf = y.float()
         assert_stats(slab, y, no_v3)
@@ -435,15 +432,12 @@ def test_256_cout_items_on_8_waves_match_the_128_cout_form(dev, monkeypatch, cas
     film = torch.randn(B, Co, generator=g).to(dev)
     outs, slabs, labels = [], [], []
     for wide in (False, True):
-        if wide:
-            monkeypatch.delenv("HSIDM_V2_BN256", raising=False)
-        else:
-            monkeypatch.setenv("HSIDM_V2_BN256", "0")
         recs = []
-        ops.set_conv_probe(recs)
-        y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab), transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
-        ops.set_conv_probe(None)
-        torch.cuda.synchronize()
+        with _lib.debug_switch("V2_BN256", int(wide)):
+            ops.set_conv_probe(recs)
+            y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab), transform=ops.XF_AFFINE_SILU, film=film, res=res, stats=True)
+            ops.set_conv_probe(None)
+            torch.cuda.synchronize()
         slab, _ = y._hsidm_stats
         assert_stats(slab, y, wide)
         outs.append(y.float().cpu())
@@ -469,15 +463,12 @@ def test_final_block_conv_on_the_256_pixel_kernel(dev, monkeypatch):
     ab = torch.stack([1 + 0.1 * torch.randn(B, Ci, generator=g), 0.1 * torch.randn(B, Ci, generator=g)], 2).contiguous()
     outs, labels = [], []
     for no_v3 in (True, False):
-        if no_v3:
-            monkeypatch.setenv("HSIDM_NO_V3", "1")
-        else:
-            monkeypatch.delenv("HSIDM_NO_V3")
         recs = []
-        ops.set_conv_probe(recs)
-        y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab.to(dev)), transform=ops.XF_AFFINE_SILU)
-        ops.set_conv_probe(None)
-        torch.cuda.synchronize()
+        with _lib.debug_switch("NO_V3", int(no_v3)):
+            ops.set_conv_probe(recs)
+            y = ops.conv2d(x, pk, gn_ab=ops.gn_table(ab.to(dev)), transform=ops.XF_AFFINE_SILU)
+            ops.set_conv_probe(None)
+            torch.cuda.synchronize()
         assert y.shape == (B, Co, H, W) and y.dtype == torch.float32
         outs.append(y.cpu())
         labels.append(recs[-1]["kernel"])

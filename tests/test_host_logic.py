@@ -210,3 +210,45 @@ def test_two_rank_gloo_broadcast_shard_gather(tmp_path):
     want = torch.arange(30, dtype=torch.float32).reshape(5, 2, 3) * 2 + 1
     assert torch.equal(r0["got"], want) and torch.equal(r1["got"], want)     # every rank holds all patches, in order
     assert r0["calls"] == [3] and r1["calls"] == [2]
+
+
+REF_CKPTS = "/root/reference/GAE_pretrained"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CKPTS), reason="the reference's checkpoints only exist in the build container")
+@pytest.mark.parametrize("name,groups,colors", [("Cav", 5, 31), ("Har", 5, 31), ("Pav", 9, 102), ("Chi", 11, 128)])
+def test_reference_gae_pickles_load_without_the_reference_code(name, groups, colors):
+    """gae.load_reference_checkpoint on the four whole-module pickles the reference ships: group layout,
+    108 tensors, values equal to the pickled module's state_dict (CAVE: equal to the committed gae_cav_state.npz)."""
+    from hsi_dmgasr_amd import gae
+    g = gae.load_reference_checkpoint(os.path.join(REF_CKPTS, "GAE_4_%s.pth" % name))
+    assert g.G == groups and g.end_idx[-1] == colors and len(g.state_dict()) == 108
+    if name == "Cav":
+        want = load_npz("gae_cav_state.npz")
+        for k, v in g.state_dict().items():
+            assert np.array_equal(v.numpy(), want[k]), k
+
+
+def test_checkpoint_loader_refuses_globals_outside_its_allowlist(tmp_path):
+    """A crafted 'checkpoint' whose pickle resolves os.system must not be unpickled."""
+    import pickle
+    from hsi_dmgasr_amd import gae
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    p = tmp_path / "evil.pth"
+    torch.save(Evil(), str(p))
+    with pytest.raises(pickle.UnpicklingError, match="allowlist"):
+        gae.load_reference_checkpoint(str(p))
+
+
+def test_bench_strong_scaling_shards_cover_all_patches():
+    """bench.py --total-patches 64 (BASELINE configs[3]): contiguous shards, every patch exactly once, at 1/2/4/8 ranks."""
+    from hsi_dmgasr_amd import parallel
+    for world in (1, 2, 4, 8, 3):
+        spans = [parallel.shard_range(64, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 64
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
