@@ -63,7 +63,28 @@ SIGNATURES = {
     "hsidm_augment": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "hsidm_color_correction_workspace_bytes": [_i32, _i32],
     "hsidm_color_correction": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    # training step
+    "hsidm_gn_act_apply": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _u64, _u32, _vp, _vp],
+    "hsidm_gn_act_bwd_workspace_floats": [_i32, _i32, _i32, _i32],
+    "hsidm_gn_act_bwd": [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp, _vp, _vp,
+                         _vp, _vp, _vp, _vp],
+    "hsidm_conv_wgrad_workspace_bytes": [_i32] * 11,
+    "hsidm_conv_wgrad": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
+                         _i64, _vp],
+    "hsidm_add": [_i32, _vp, _vp, _vp, _i64, _vp],
+    "hsidm_zero_insert2": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "hsidm_sum2x2": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "hsidm_colsum": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "hsidm_loss_grad": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
+    "hsidm_noise_film_bwd_workspace_floats": [_i32, _i32, _i32],
+    "hsidm_noise_film_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hsidm_bgemm": [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp],
+    "hsidm_softmax_rows": [_vp, _i64, _i32, _vp],
+    "hsidm_softmax_bwd_rows": [_vp, _vp, _i64, _i32, _f32, _vp],
+    "hsidm_gather_pack": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hsidm_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
 }
+RESTYPE_I64 = {"hsidm_conv_wgrad_workspace_bytes"}
 
 _lib = None
 
@@ -80,7 +101,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = _i32
+            fn.restype = _i64 if name in RESTYPE_I64 else _i32
         L.hsidm_error_string.argtypes = [_i32]
         L.hsidm_error_string.restype = C.c_char_p
         _lib = L

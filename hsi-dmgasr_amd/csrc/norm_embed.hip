@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
         var = var > 0.0 ? var : 0.0;
         gm[t] = (float)mean;
         gr[t] = (float)(1.0 / sqrt(var + (double)eps));
+        // fourth part of the table: (mean, rstd) per (image, group), read by the backward pass (hsidm_gn_act_bwd)
+        float2* mr = reinterpret_cast<float2*>(reinterpret_cast<float*>(ab) + (size_t)4 * gridDim.y * C);
+        mr[(size_t)b * groups + blockIdx.x * gpb + t] = make_float2(gm[t], gr[t]);
     }
     __syncthreads();
     if (t < cw) {

@@ -1,0 +1,286 @@
+// Weight gradient of the path's convolutions (the reference gets it from autograd in model/model.py:55):
+//   dw[co][ci][ky][kx] = sum over (b, y, x) of dy[b][y][x][co] * a[b][s*y + ky - 1][s*x + kx - 1][ci]
+// as an implicit GEMM whose contraction axis is the PIXEL axis: D[co][ci] (per tap) += dY^T[co][pixel] * A[pixel (+tap)][ci].
+// Both operands are NHWC (channels contiguous), i.e. the contraction index is the strided one for both.  bf16 mode: a pixel tile
+// of dY and the halo tile of A are staged row-major in LDS ([pixel][64 channels], 192-byte rows) and BOTH MFMA operands are
+// fetched with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major: conflict-free at this
+// pitch), so no transposed copy of either tensor is ever written.  fp32 mode: the same tiles in fp32 and the exact fp32 matrix
+// instruction v_mfma_f32_32x32x2_f32, whose operands are one element per lane.
+// Work decomposition: workgroup = (64 couts x 64 cins x all taps) x a contiguous range of pixel tiles (split K); a wave owns a
+// 32 x 32 corner for all taps (9 accumulator tiles); partial sums go to a workspace [split][tap][cout][cin] with plain stores and
+// a second kernel adds the splits in order into the PyTorch layout [cout][cin][ky][kx]: deterministic, no atomics.
+#include "common.h"
+#include "../../include/hsidm.h"
+#include <type_traits>
+
+namespace hsidm {
+
+struct WgradParams {
+    const void* a0; const void* a1; const void* dy;
+    float* ws;
+    int C0, C1, Cin, Cout;             // tensor channel counts (multiples of 8)
+    int B, Hin, Win, Hout, Wout;
+    int tiles_x, tiles_y, ksteps, nsplit;
+    int cin_tiles, Cin_pad, Cout_pad;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// MODE 0: stride 1 (3x3 pad 1, or 1x1);  1: the input is read through a nearest x2 upsample;  2: stride 2 (3x3 pad 1)
+template <typename T, int TH, int TW, int NT, int MODE>
+struct WgCfg {
+    static constexpr bool F32 = std::is_same<T, float>::value;
+    static constexpr int EPV = F32 ? 4 : 8;                  // elements per 16-byte vector
+    static constexpr int VPP = 64 / EPV;                     // vectors per pixel (64 channels)
+    static constexpr int PITCH = F32 ? 68 : 96;              // elements per LDS pixel row
+    static constexpr int NPIX = TH * TW;
+    static constexpr int HH = NT == 1 ? TH : (MODE == 2 ? 2 * TH + 1 : TH + 2);
+    static constexpr int HWD = NT == 1 ? TW : (MODE == 2 ? 2 * TW + 1 : TW + 2);
+    static constexpr int NHALO = HH * HWD;
+    static constexpr int NV_D = (NPIX * VPP + 255) / 256;
+    static constexpr int NV_A = (NHALO * VPP + 255) / 256;
+    static constexpr size_t LDS_BYTES = (size_t)(NPIX + NHALO) * PITCH * sizeof(T);
+};
+
+template <typename T, int TH, int TW, int NT, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    using C = WgCfg<T, TH, TW, NT, MODE>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* ld = reinterpret_cast<T*>(smem_raw);                  // dY tile  [NPIX][PITCH]
+    T* la = ld + C::NPIX * C::PITCH;                         // A halo   [NHALO][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ct = blockIdx.x;
+    const int co0 = (ct / p.cin_tiles) * 64, ci0 = (ct % p.cin_tiles) * 64;
+    const int split = blockIdx.y;
+    const int per = (p.ksteps + p.nsplit - 1) / p.nsplit;
+    const int s_begin = split * per, s_end = min(p.ksteps, s_begin + per);
+    const int tpi = p.tiles_x * p.tiles_y;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    u32x4 rd[C::NV_D], ra[C::NV_A];
+    auto issue = [&](int step) __attribute__((always_inline)) {
+        const int b = step / tpi, r = step - b * tpi;
+        const int ty0 = (r / p.tiles_x) * TH, tx0 = (r % p.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < C::NV_D; ++i) {
+            const int v = tid + i * 256;
+            const int pix = v / C::VPP, cv = v % C::VPP;
+            const int y = ty0 + pix / TW, x = tx0 + pix % TW, c = co0 + cv * C::EPV;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (pix < C::NPIX && y < p.Hout && x < p.Wout && c < p.Cout)
+                val = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dy) + ((size_t)(b * p.Hout + y) * p.Wout + x) * p.Cout + c);
+            rd[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < C::NV_A; ++i) {
+            const int v = tid + i * 256;
+            const int pix = v / C::VPP, cv = v % C::VPP;
+            const int hy = pix / C::HWD, hx = pix % C::HWD;
+            int gy, gx;
+            if (NT == 1) { gy = ty0 + hy; gx = tx0 + hx; }
+            else if (MODE == 2) { gy = 2 * ty0 - 1 + hy; gx = 2 * tx0 - 1 + hx; }
+            else { gy = ty0 - 1 + hy; gx = tx0 - 1 + hx; }
+            bool ok = pix < C::NHALO && gy >= 0 && gx >= 0;
+            if (MODE == 1) { ok = ok && gy < 2 * p.Hin && gx < 2 * p.Win; gy >>= 1; gx >>= 1; }
+            else ok = ok && gy < p.Hin && gx < p.Win;
+            const int c = ci0 + cv * C::EPV;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (ok && c < p.Cin) {
+                const size_t px = (size_t)(b * p.Hin + gy) * p.Win + gx;
+                const T* src = c < p.C0 ? reinterpret_cast<const T*>(p.a0) + px * p.C0 + c
+                                        : reinterpret_cast<const T*>(p.a1) + px * p.C1 + (c - p.C0);
+                val = *reinterpret_cast<const u32x4*>(src);
+            }
+            ra[i] = val;
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::NV_D; ++i) {
+            const int v = tid + i * 256;
+            if (v < C::NPIX * C::VPP) *reinterpret_cast<u32x4*>(ld + (v / C::VPP) * C::PITCH + (v % C::VPP) * C::EPV) = rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::NV_A; ++i) {
+            const int v = tid + i * 256;
+            if (v < C::NHALO * C::VPP) *reinterpret_cast<u32x4*>(la + (v / C::VPP) * C::PITCH + (v % C::VPP) * C::EPV) = ra[i];
+        }
+    };
+
+    if (s_begin < s_end) issue(s_begin);
+    for (int step = s_begin; step < s_end; ++step) {
+        __syncthreads();                                     // the previous step's readers are done with the tiles
+        commit();
+        __syncthreads();
+        if (step + 1 < s_end) issue(step + 1);
+        if constexpr (!C::F32) {
+            // k index of an MFMA k-group (16 pixels): k = 8h + j  <->  pixel (row kg, x = 8h + j) for TW = 16,
+            //                                                        pixel (row 2kg + h, x = j) for TW = 8
+            const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
+            const int py = TW == 16 ? 0 : h, px = (TW == 16 ? 8 * h : 0) + q;      // this lane's address duty, relative to the k-group
+            const int coff = 16 * g1 + 4 * pq;
+            const T* abase = ld + (py * TW + px) * C::PITCH + 32 * wm + coff;
+            const int sp = MODE == 2 ? 2 : 1;
+            const T* bbase = la + (sp * py * C::HWD + sp * px) * C::PITCH + 32 * wn + coff;
+            constexpr int NKG = C::NPIX / 16, RPG = TW == 16 ? 1 : 2;              // k-groups per tile, tile rows per k-group
+            typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+#pragma unroll
+            for (int kg = 0; kg < NKG; ++kg) {
+                const T* ap = abase + kg * RPG * TW * C::PITCH;
+                const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap));
+                const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + 4 * C::PITCH));
+                const s16x8 af = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int ky = NT == 1 ? 0 : t / 3, kx = NT == 1 ? 0 : t % 3;
+                    const T* bp = bbase + ((sp * kg * RPG + ky) * C::HWD + kx) * C::PITCH;
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bp));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bp + 4 * sp * C::PITCH));
+                    const s16x8 bf = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            // exact fp32: one element per lane, k = lane >> 5 -> two consecutive pixels of a tile row per instruction
+            const int h = lane >> 5, r = lane & 31;
+            const int sp = MODE == 2 ? 2 : 1;
+#pragma unroll 4
+            for (int pp = 0; pp < C::NPIX / 2; ++pp) {
+                const int pix = 2 * pp + h;
+                const int y = pix / TW, x = pix % TW;
+                const float av = ld[pix * C::PITCH + 32 * wm + r];
+                const T* brow = la + (sp * y * C::HWD + sp * x) * C::PITCH + 32 * wn + r;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int ky = NT == 1 ? 0 : t / 3, kx = NT == 1 ? 0 : t % 3;
+                    const float bv = brow[(ky * C::HWD + kx) * C::PITCH];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial sums: ws[split][tap][co][ci]; register j of a lane = row (j&3) + 8(j>>2) + 4(lane>>5), column lane & 31
+    const int n = ci0 + 32 * wn + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* dst = p.ws + ((size_t)(split * NT + t) * p.Cout_pad) * p.Cin_pad;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = co0 + 32 * wm + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+            dst[(size_t)m * p.Cin_pad + n] = acc[t][j];
+        }
+    }
+}
+
+// dw[co][ci][tap] = sum over splits (in order) of ws[split][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
+                                                           int Cout_w, int Cin_w, float* __restrict__ dw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Cout_w * Cin_w) return;
+    const int co = (int)(i / Cin_w), ci = (int)(i % Cin_w);
+    for (int t = 0; t < NT; ++t) {
+        float a = 0.f;
+        for (int s = 0; s < nsplit; ++s) a += ws[((size_t)(s * NT + t) * Cout_pad + co) * Cin_pad + ci];
+        dw[i * NT + t] = a;
+    }
+}
+
+struct WgPlan { int TW, TH, tiles_x, tiles_y, ksteps, nsplit, cin_tiles, cout_tiles, Cin_pad, Cout_pad, NT, mode; size_t ws_bytes; };
+
+static int wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize, int stride, int ups, WgPlan& pl) {
+    const int Cin = C0 + C1;
+    if (C0 <= 0 || (C0 & 7) || C1 < 0 || (C1 & 7) || Cout <= 0 || (Cout & 7) || B <= 0 || Hin <= 0 || Win <= 0) return HSIDM_E_BADARG;
+    if (ksize != 3 && ksize != 1) return HSIDM_E_BADARG;
+    if (stride != 1 && stride != 2) return HSIDM_E_BADARG;
+    if (ksize == 1 && (stride != 1 || ups)) return HSIDM_E_UNSUPPORTED;
+    if (ups && stride != 1) return HSIDM_E_UNSUPPORTED;
+    const int eh = ups ? 2 * Hin : (stride == 2 ? (Hin + 1) / 2 : Hin), ew = ups ? 2 * Win : (stride == 2 ? (Win + 1) / 2 : Win);
+    if (eh != Hout || ew != Wout) return HSIDM_E_BADARG;
+    pl.NT = ksize * ksize;
+    pl.mode = ups ? 1 : (stride == 2 ? 2 : 0);
+    pl.TW = Wout >= 16 ? 16 : 8;
+    pl.TH = stride == 2 ? 4 : 8;
+    pl.tiles_x = (Wout + pl.TW - 1) / pl.TW;
+    pl.tiles_y = (Hout + pl.TH - 1) / pl.TH;
+    pl.ksteps = B * pl.tiles_x * pl.tiles_y;
+    pl.cin_tiles = (Cin + 63) / 64;
+    pl.cout_tiles = (Cout + 63) / 64;
+    pl.Cin_pad = pl.cin_tiles * 64;
+    pl.Cout_pad = pl.cout_tiles * 64;
+    const int tiles = pl.cin_tiles * pl.cout_tiles;
+    int ns = (2 * device_cus() + tiles - 1) / tiles;                 // about two workgroups per CU
+    const size_t per_split = (size_t)pl.NT * pl.Cout_pad * pl.Cin_pad * sizeof(float);
+    const size_t cap = (size_t)64 << 20;                              // partial sums are written and read once each
+    if ((size_t)ns * per_split > cap) ns = (int)(cap / per_split);
+    if (ns > pl.ksteps) ns = pl.ksteps;
+    if (ns < 1) ns = 1;
+    const int per = (pl.ksteps + ns - 1) / ns;
+    pl.nsplit = (pl.ksteps + per - 1) / per;                          // no empty split
+    pl.ws_bytes = (size_t)pl.nsplit * per_split;
+    return HSIDM_OK;
+}
+
+template <typename T, int TH, int TW, int NT, int MODE>
+static int launch_wgrad(const WgradParams& p, const WgPlan& pl, hipStream_t s) {
+    using C = WgCfg<T, TH, TW, NT, MODE>;
+    static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &conv_wgrad_kernel<T, TH, TW, NT, MODE>, C::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<T, TH, TW, NT, MODE>), dim3(pl.cin_tiles * pl.cout_tiles, pl.nsplit), dim3(256),
+                       C::LDS_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int dispatch_wgrad(const WgradParams& p, const WgPlan& pl, hipStream_t s) {
+    const bool w16 = pl.TW == 16;
+    if (pl.NT == 1) return w16 ? launch_wgrad<T, 8, 16, 1, 0>(p, pl, s) : launch_wgrad<T, 8, 8, 1, 0>(p, pl, s);
+    if (pl.mode == 0) return w16 ? launch_wgrad<T, 8, 16, 9, 0>(p, pl, s) : launch_wgrad<T, 8, 8, 9, 0>(p, pl, s);
+    if (pl.mode == 1) return w16 ? launch_wgrad<T, 8, 16, 9, 1>(p, pl, s) : launch_wgrad<T, 8, 8, 9, 1>(p, pl, s);
+    return w16 ? launch_wgrad<T, 4, 16, 9, 2>(p, pl, s) : launch_wgrad<T, 4, 8, 9, 2>(p, pl, s);
+}
+
+}  // namespace hsidm
+
+using namespace hsidm;
+
+extern "C" int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize,
+                                                    int stride, int ups) {
+    WgPlan pl;
+    const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
+    return rc != HSIDM_OK ? (int64_t)rc : (int64_t)pl.ws_bytes;
+}
+
+extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
+                                int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    WgPlan pl;
+    const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
+    if (rc != HSIDM_OK) return rc;
+    if (!a0 || (C1 > 0 && !a1) || !dy || !dw || !workspace || Cout_w <= 0 || Cout_w > Cout || Cin_w <= 0 || Cin_w > C0 + C1) return HSIDM_E_BADARG;
+    if ((size_t)workspace_bytes < pl.ws_bytes) return HSIDM_E_BADARG;
+    WgradParams p;
+    p.a0 = a0; p.a1 = C1 > 0 ? a1 : nullptr; p.dy = dy; p.ws = (float*)workspace;
+    p.C0 = C0; p.C1 = C1; p.Cin = C0 + C1; p.Cout = Cout;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+    p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ksteps = pl.ksteps; p.nsplit = pl.nsplit;
+    p.cin_tiles = pl.cin_tiles; p.Cin_pad = pl.Cin_pad; p.Cout_pad = pl.Cout_pad;
+    hipStream_t s = (hipStream_t)stream;
+    int e;
+    if (prec == HSIDM_BF16) e = dispatch_wgrad<bf16>(p, pl, s);
+    else if (prec == HSIDM_F32X3) e = dispatch_wgrad<float>(p, pl, s);
+    else return HSIDM_E_BADARG;
+    if (e) return e;
+    const int64_t n = (int64_t)Cout_w * Cin_w;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
+                       pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw);
+    return (int)hipGetLastError();
+}

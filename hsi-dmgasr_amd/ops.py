@@ -24,6 +24,69 @@ def pick_bn(cout, out_nchw=False):
     return 128
 
 
+def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=False, fold_dn=False):
+    """The packed layouts of one convolution as tensors of `weight`'s dtype (values are only moved, or - for the folded
+    upsample kernels - summed): {"w": [step][Cout_pad][BK], "w_v2": ..., "w_up4": ..., "w_dn4": ...} plus the meta data
+    PackedConv carries.  Called with the real fp32 weights (PackedConv) and with float64 index-valued tensors
+    (training.PackMap: the layouts become gather maps into the flat parameter buffer)."""
+    prec = _lib.prec_id(precision)
+    bk = 64 if prec == _lib.BF16 else 32
+    cout, cin, kh, kw = weight.shape
+    assert kh == kw and kh in (1, 3)
+    if cin % 8:     # NHWC tensors carry channels in 16-B vectors: pad the K axis with zero weights
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 8 - cin % 8))
+        cin = weight.shape[1]
+    bn = pick_bn(cout, out_nchw)
+    cpad = (cout + bn - 1) // bn * bn
+    parts = [PackedConv._steps(weight, cpad, bk)]
+    proj_cin = 0
+    if proj_weight is not None:
+        assert proj_weight.shape[2] == 1 and proj_weight.shape[0] == cout
+        if proj_weight.shape[1] % 8:
+            proj_weight = torch.nn.functional.pad(proj_weight, (0, 0, 0, 0, 0, 8 - proj_weight.shape[1] % 8))
+        proj_cin = proj_weight.shape[1]
+        parts.append(PackedConv._steps(proj_weight, cpad, bk))
+    lay = dict(w=torch.cat(parts, dim=0).contiguous(), w_v2=None, w_up4=None, w_dn4=None)
+    meta = dict(ksize=kh, cin=cin, cout=cout, bn=bn, cpad=cpad, proj_cin=proj_cin, prec=prec, tap_major=False)
+    # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
+    # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
+    if prec == _lib.BF16 and proj_weight is None and (not out_nchw or (kh == 3 and bn == 32)):
+        wv = lay["w"]
+        meta["tap_major"] = kh == 3 and cin == 8
+        if meta["tap_major"]:                    # stem-like convs: tap-major GEMM (conv1x1_g IM mode), k = 8*tap + c -> 128
+            w2 = weight.reshape(cout, 8, 9).permute(0, 2, 1).reshape(cout, 72, 1, 1)
+            wv = PackedConv._steps(w2, cpad, bk).contiguous()
+        if kh == 1 and wv.shape[0] % 2:          # 1x1 GEMM kernel (conv1x1_g.hip): K padded to a multiple of 128
+            wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
+        lay["w_v2"] = PackedConv._lanes(wv, cpad)
+    # nearest-x2 + conv3x3 as four 2x2 convs on the input grid (include/hsidm.h, HSIDM_UPS_FOLDED): taps that read
+    # the same input pixel are summed, then rounded to bf16 once
+    if fold_ups and lay["w_v2"] is not None and kh == 3 and bn == 128:
+        rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # parity -> 3x3 taps behind each of the two 2x2 taps
+        pars = []
+        for py in (0, 1):
+            for px in (0, 1):
+                f = torch.stack([torch.stack([sum(weight[:, :, dy, dx] for dy in rows[py][ty] for dx in rows[px][tx])
+                                              for tx in (0, 1)], dim=-1) for ty in (0, 1)], dim=-2)
+                pars.append(PackedConv._steps(f, cpad, bk))
+        lay["w_up4"] = PackedConv._lanes(torch.cat(pars, dim=0).contiguous(), cpad)
+    # stride-2 conv over the four input-parity planes (include/hsidm.h, hsidm_conv_desc.stride)
+    if fold_dn and lay["w_v2"] is not None and kh == 3 and bn in (64, 128):
+        tapmap = {0: (None, 1), 1: (0, 2)}                      # plane parity -> 3x3 tap behind each of the two window taps
+        planes = []
+        for ry in (0, 1):
+            for rx in (0, 1):
+                f = torch.zeros(cout, cin, 2, 2, dtype=weight.dtype, device=weight.device)
+                for ty in (0, 1):
+                    for tx in (0, 1):
+                        dy, dx = tapmap[ry][ty], tapmap[rx][tx]
+                        if dy is not None and dx is not None:
+                            f[:, :, ty, tx] = weight[:, :, dy, dx]
+                planes.append(PackedConv._steps(f, cpad, bk))
+        lay["w_dn4"] = PackedConv._lanes(torch.cat(planes, dim=0).contiguous(), cpad)
+    return lay, meta
+
+
 class PackedConv:
     """Weights of one hsidm_conv2d launch in the kernel's streaming order.
 
@@ -32,76 +95,33 @@ class PackedConv:
     """
 
     def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False, fold_ups=False, fold_dn=False):
-        prec = _lib.prec_id(precision)
-        bk = 64 if prec == _lib.BF16 else 32
         dev = weight.device
-        cout, cin, kh, kw = weight.shape
-        assert kh == kw and kh in (1, 3)
-        if cin % 8:     # NHWC tensors carry channels in 16-B vectors: pad the K axis with zero weights
-            weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 8 - cin % 8))
-            cin = weight.shape[1]
-        self.ksize, self.cin, self.cout, self.precision, self.prec = kh, cin, cout, precision, prec
-        self.out_nchw = out_nchw
-        self.bn = pick_bn(cout, out_nchw)
-        cpad = (cout + self.bn - 1) // self.bn * self.bn
-        parts = [self._steps(weight.detach().float(), cpad, bk)]
-        self.proj_cin = 0
+        lay, meta = pack_layouts(weight.detach().float(), precision, None if proj_weight is None else proj_weight.detach().float(),
+                                 out_nchw, fold_ups, fold_dn)
+        self._set_meta(meta, precision, out_nchw)
         b = None if bias is None else bias.detach().float().clone()
-        if proj_weight is not None:
-            assert proj_weight.shape[2] == 1 and proj_weight.shape[0] == cout
-            if proj_weight.shape[1] % 8:
-                proj_weight = torch.nn.functional.pad(proj_weight.detach(), (0, 0, 0, 0, 0, 8 - proj_weight.shape[1] % 8))
-            self.proj_cin = proj_weight.shape[1]
-            parts.append(self._steps(proj_weight.detach().float(), cpad, bk))
-            if proj_bias is not None:
-                b = proj_bias.detach().float().clone() if b is None else b + proj_bias.detach().float()
-        w = torch.cat(parts, dim=0).contiguous()
+        if proj_weight is not None and proj_bias is not None:
+            b = proj_bias.detach().float().clone() if b is None else b + proj_bias.detach().float()
+        w = lay["w"]
         self.w_hi = w.to(torch.bfloat16).contiguous()
-        self.w_lo = (w - self.w_hi.float()).to(torch.bfloat16).contiguous() if prec == _lib.F32X3 else None
+        self.w_lo = (w - self.w_hi.float()).to(torch.bfloat16).contiguous() if self.prec == _lib.F32X3 else None
         self.bias = None if b is None else b.to(dev).contiguous()
-        # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
-        # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
-        self.w_v2 = None
-        self.tap_major = False
-        if prec == _lib.BF16 and proj_weight is None and (not out_nchw or (kh == 3 and self.bn == 32)):
-            wv = self.w_hi
-            self.tap_major = kh == 3 and cin == 8
-            if self.tap_major:                       # stem-like convs: tap-major GEMM (conv1x1_g IM mode), k = 8*tap + c -> 128
-                w2 = weight.detach().float().reshape(cout, 8, 9).permute(0, 2, 1).reshape(cout, 72, 1, 1)
-                wv = self._steps(w2, cpad, bk).to(torch.bfloat16).contiguous()
-            if kh == 1 and wv.shape[0] % 2:          # 1x1 GEMM kernel (conv1x1_g.hip): K padded to a multiple of 128
-                wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
-            self.w_v2 = self._lanes(wv, cpad)
-        # nearest-x2 + conv3x3 as four 2x2 convs on the input grid (include/hsidm.h, HSIDM_UPS_FOLDED): taps that read
-        # the same input pixel are summed in fp32, then rounded to bf16 once
-        self.w_up4 = None
-        if fold_ups and self.w_v2 is not None and kh == 3 and self.bn == 128:
-            w = weight.detach().float()
-            rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # parity -> 3x3 taps behind each of the two 2x2 taps
-            pars = []
-            for py in (0, 1):
-                for px in (0, 1):
-                    f = torch.stack([torch.stack([sum(w[:, :, dy, dx] for dy in rows[py][ty] for dx in rows[px][tx])
-                                                  for tx in (0, 1)], dim=-1) for ty in (0, 1)], dim=-2)
-                    pars.append(self._steps(f, cpad, bk))
-            self.w_up4 = self._lanes(torch.cat(pars, dim=0).to(torch.bfloat16).contiguous(), cpad)
+        self.w_v2 = None if lay["w_v2"] is None else lay["w_v2"].to(torch.bfloat16).contiguous()
+        self.w_up4 = None if lay["w_up4"] is None else lay["w_up4"].to(torch.bfloat16).contiguous()
+        self.w_dn4 = None if lay["w_dn4"] is None else lay["w_dn4"].to(torch.bfloat16).contiguous()
 
-        # stride-2 conv over the four input-parity planes (include/hsidm.h, hsidm_conv_desc.stride)
-        self.w_dn4 = None
-        if fold_dn and self.w_v2 is not None and kh == 3 and self.bn in (64, 128):
-            w = weight.detach().float()
-            tapmap = {0: (None, 1), 1: (0, 2)}                      # plane parity -> 3x3 tap behind each of the two window taps
-            planes = []
-            for ry in (0, 1):
-                for rx in (0, 1):
-                    f = torch.zeros(cout, cin, 2, 2, dtype=torch.float32, device=w.device)
-                    for ty in (0, 1):
-                        for tx in (0, 1):
-                            dy, dx = tapmap[ry][ty], tapmap[rx][tx]
-                            if dy is not None and dx is not None:
-                                f[:, :, ty, tx] = w[:, :, dy, dx]
-                    planes.append(self._steps(f, cpad, bk))
-            self.w_dn4 = self._lanes(torch.cat(planes, dim=0).to(torch.bfloat16).contiguous(), cpad)
+    def _set_meta(self, meta, precision, out_nchw):
+        self.ksize, self.cin, self.cout, self.bn = meta["ksize"], meta["cin"], meta["cout"], meta["bn"]
+        self.proj_cin, self.prec, self.tap_major = meta["proj_cin"], meta["prec"], meta["tap_major"]
+        self.precision, self.out_nchw = precision, out_nchw
+
+    @classmethod
+    def from_buffers(cls, meta, precision, out_nchw, w_hi, w_lo, w_v2, w_dn4, bias):
+        """A PackedConv over caller-owned packed buffers (the training step refreshes them in place every iteration)."""
+        self = cls.__new__(cls)
+        self._set_meta(meta, precision, out_nchw)
+        self.w_hi, self.w_lo, self.w_v2, self.w_up4, self.w_dn4, self.bias = w_hi, w_lo, w_v2, None, w_dn4, bias
+        return self
 
     @staticmethod
     def _lanes(w_steps, cpad):
@@ -114,7 +134,7 @@ class PackedConv:
         cout, cin, kh, kw = w.shape
         taps = kh * kw
         nch = (cin + bk - 1) // bk
-        wp = torch.zeros(cpad, nch * bk, taps, dtype=torch.float32, device=w.device)
+        wp = torch.zeros(cpad, nch * bk, taps, dtype=w.dtype, device=w.device)
         wp[:cout, :cin] = w.reshape(cout, cin, taps)
         # [cpad][chunk][k][tap] -> [chunk][tap][cpad][k]
         return wp.reshape(cpad, nch, bk, taps).permute(1, 3, 0, 2).reshape(nch * taps, cpad, bk)
@@ -237,7 +257,8 @@ def gn_scale_shift(x0, x1, gamma, beta, groups, precision, eps=1e-5):
     C1 = 0 if x1 is None else x1.shape[3]
     p0, n0 = _partials(x0, precision)
     p1, n1 = _partials(x1, precision) if x1 is not None else (None, 0)
-    ab = torch.empty(B * (C0 + C1) * 4, dtype=torch.float32, device=x0.device)      # fp32 pairs + two fp16x2 parts (hsidm.h)
+    # fp32 pairs + two fp16x2 parts + (mean, rstd) per (image, group) (hsidm.h)
+    ab = torch.empty(B * (C0 + C1) * 4 + B * groups * 2, dtype=torch.float32, device=x0.device)
     _lib.check(_lib.lib().hsidm_gn_finalize(_lib.ptr(p0), n0, C0, _lib.ptr(p1), n1, C1, B, H * W, groups,
                                             _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(ab),
                                             _lib.stream_ptr()), "gn_finalize")

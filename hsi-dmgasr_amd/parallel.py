@@ -55,6 +55,57 @@ def broadcast_module_(module, src=0, bucket_bytes=256 << 20):
     return module
 
 
+def grad_buckets(n_floats, bucket_bytes=64 << 20):
+    """[(start, stop)] element ranges of a flat fp32 gradient buffer, last bucket first (= the order in which the backward
+    pass completes them: the flat buffer follows the module order)."""
+    per = max(1, bucket_bytes // 4)
+    cuts = list(range(0, n_floats, per)) + [n_floats]
+    return [(cuts[i], cuts[i + 1]) for i in reversed(range(len(cuts) - 1))]
+
+
+def allreduce_grads_(flat_grad, bucket_bytes=64 << 20):
+    """Sum the flat gradient buffer over the ranks of the default group in a few large buckets (xGMI links are per peer:
+    few large messages; SURVEY 5: 391 MB fp32 per step for the shipped UNet), all in flight at once.  The caller divides by
+    the world size (hsidm_adam_step's grad_scale).  The reference's counterpart is nn.DataParallel's reduce-add of the
+    replicas' gradients onto GPU 0 (model/networks.py:113-115)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flat_grad
+    works = [dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in grad_buckets(flat_grad.numel(), bucket_bytes)]
+    for w in works:
+        w.wait()
+    return flat_grad
+
+
+class GradReducer:
+    """Overlaps the gradient all-reduce with the backward pass: the flat gradient buffer follows the module order, the backward
+    pass fills it from the end, and every bucket is reduced (async, on RCCL's stream) as soon as everything above its lower
+    edge is final.  `ready(lowest_final_offset)` after each layer's backward; `finish()` before the optimiser step."""
+
+    def __init__(self, flat_grad, bucket_bytes=64 << 20):
+        self.flat = flat_grad
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.buckets = grad_buckets(flat_grad.numel(), bucket_bytes)
+        self.reset()
+
+    def reset(self):
+        self.next, self.works = 0, []
+
+    def ready(self, lowest_final_offset):
+        while self.next < len(self.buckets) and self.buckets[self.next][0] >= lowest_final_offset:
+            a, b = self.buckets[self.next]
+            if self.on:
+                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self.next += 1
+
+    def finish(self):
+        self.ready(0)
+        for w in self.works:
+            w.wait()
+        fired = self.next
+        self.reset()
+        return fired
+
+
 def all_gather_patches(local, n_total):
     """local: [n_local, ...] results of this rank's shard (shard_range order) -> [n_total, ...] on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -1,0 +1,165 @@
+"""Host-side wrappers of the training kernels (include/hsidm.h, "training step"): NHWC tensors of the mode's storage type in,
+kernels enqueued on the current stream, nothing synchronised.  Forward convolutions and their input gradients go through
+ops.conv2d (the input gradient of a convolution is a convolution with the transposed, flipped weights)."""
+import torch
+
+from . import _lib, ops
+
+
+def _check(code, what):
+    _lib.check(code, what)
+
+
+def gn_act_apply(x0, x1, gn_ab, silu, precision, p_drop=0.0, seed=0, layer=0):
+    """a = dropout(act(GroupNorm(cat(x0, x1)))) materialised (NHWC [B, H, W, C0+C1])."""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    out = torch.empty((B, H, W, C0 + C1), dtype=x0.dtype, device=x0.device)
+    _check(_lib.lib().hsidm_gn_act_apply(_lib.prec_id(precision), _lib.ptr(x0), _lib.ptr(x1), C0, C1, _lib.ptr(gn_ab),
+                                         ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE, B, H * W, float(p_drop), int(seed), int(layer),
+                                         _lib.ptr(out), _lib.stream_ptr()), "gn_act_apply")
+    return out
+
+
+def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta, p_drop=0.0, seed=0, layer=0, add=None):
+    """Backward of gn_act_apply + GroupNorm: returns (dx0, dx1) and writes dgamma / dbeta (fp32 views of the gradient buffer)."""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    C = C0 + C1
+    HW = H * W
+    nsplit = max(1, min(32, HW // 512))
+    L = _lib.lib()
+    ws = torch.empty(L.hsidm_gn_act_bwd_workspace_floats(B, C, groups, nsplit), dtype=torch.float32, device=x0.device)
+    dx0 = torch.empty_like(x0)
+    dx1 = None if x1 is None else torch.empty_like(x1)
+    assert da.shape == (B, H, W, C) and (add is None or add.shape == da.shape)
+    _check(L.hsidm_gn_act_bwd(_lib.prec_id(precision), _lib.ptr(da), _lib.ptr(x0), _lib.ptr(x1), C0, C1, _lib.ptr(gn_ab), _lib.ptr(gamma),
+                              groups, ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE, B, HW, float(p_drop), int(seed), int(layer), nsplit,
+                              _lib.ptr(ws), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(add), _lib.ptr(dx0), _lib.ptr(dx1),
+                              _lib.stream_ptr()), "gn_act_bwd")
+    return dx0, dx1
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, dev):
+    """One growing scratch buffer per device for the weight-gradient partial sums (launches are stream-ordered)."""
+    key = str(dev)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False):
+    """dw [Cout_w, Cin_w, k, k] (fp32, contiguous view of the gradient buffer) = weight gradient of the convolution that
+    maps a = cat(a0, a1) to the tensor whose gradient is dy."""
+    B, Hin, Win, C0 = a0.shape
+    C1 = 0 if a1 is None else a1.shape[3]
+    _, Ho, Wo, Ct = dy.shape
+    cout_w, cin_w, k, _ = dw.shape
+    L = _lib.lib()
+    nb = L.hsidm_conv_wgrad_workspace_bytes(C0, C1, B, Hin, Win, Ho, Wo, Ct, k, stride, int(bool(ups)))
+    if nb < 0:
+        _check(int(nb), "conv_wgrad_workspace_bytes")
+    ws = _workspace(nb, a0.device)
+    assert dw.is_contiguous() and dw.dtype == torch.float32
+    _check(L.hsidm_conv_wgrad(_lib.prec_id(precision), _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(dy), B, Hin, Win, Ho, Wo, Ct, k,
+                              stride, int(bool(ups)), cout_w, cin_w, _lib.ptr(dw), _lib.ptr(ws), int(nb), _lib.stream_ptr()), "conv_wgrad")
+
+
+def add(a, b, precision):
+    out = torch.empty_like(a)
+    _check(_lib.lib().hsidm_add(_lib.prec_id(precision), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), _lib.stream_ptr()), "add")
+    return out
+
+
+def zero_insert2(x, Ho, Wo, precision):
+    B, Hi, Wi, C = x.shape
+    out = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    _check(_lib.lib().hsidm_zero_insert2(_lib.prec_id(precision), _lib.ptr(x), _lib.ptr(out), B, Hi, Wi, Ho, Wo, C, _lib.stream_ptr()),
+           "zero_insert2")
+    return out
+
+
+def sum2x2(x, precision):
+    B, H2, W2, C = x.shape
+    out = torch.empty((B, H2 // 2, W2 // 2, C), dtype=x.dtype, device=x.device)
+    _check(_lib.lib().hsidm_sum2x2(_lib.prec_id(precision), _lib.ptr(x), _lib.ptr(out), B, H2 // 2, W2 // 2, C, _lib.stream_ptr()), "sum2x2")
+    return out
+
+
+def channel_sums(x, precision, out_c=None, want_bc=False, cout=None):
+    """Per-channel sums of an NHWC tensor: out_c[c] = sum over (b, h, w) (written into the given fp32 view), and optionally the
+    per-image sums [B, cout]."""
+    B, H, W, C = x.shape
+    cout = C if cout is None else cout
+    part, nsplit = ops.channel_partials(x, precision)
+    bc = torch.empty((B, cout), dtype=torch.float32, device=x.device) if want_bc else None
+    _check(_lib.lib().hsidm_colsum(_lib.ptr(part), nsplit, B, C, cout, _lib.ptr(bc), _lib.ptr(out_c), _lib.stream_ptr()), "colsum")
+    return bc
+
+
+def loss_grad(noise, eps, kind, scale, precision):
+    """d(scale * loss)/d(eps) as an NHWC tensor [B, H, W, 8-padded C]."""
+    B, Ci, H, W = eps.shape
+    cpad = (Ci + 7) // 8 * 8
+    out = torch.empty((B, H, W, cpad), dtype=_lib.act_dtype(precision), device=eps.device)
+    _check(_lib.lib().hsidm_loss_grad(_lib.prec_id(precision), _lib.ptr(noise), _lib.ptr(eps), B, Ci, H * W, cpad, {"l1": 0, "l2": 1}[kind],
+                                      float(scale), _lib.ptr(out), _lib.stream_ptr()), "loss_grad")
+    return out
+
+
+def noise_film_bwd(gamma, t_emb, dfilm, mlp, wf, grads):
+    """grads = (dw1, db1, dw2, db2, dwf, dbf): fp32 views of the gradient buffer."""
+    B, dim = t_emb.shape
+    F = wf.shape[0]
+    L = _lib.lib()
+    ws = torch.empty(L.hsidm_noise_film_bwd_workspace_floats(B, dim, F), dtype=torch.float32, device=t_emb.device)
+    w1, b1, w2, _ = mlp
+    dw1, db1, dw2, db2, dwf, dbf = grads
+    _check(L.hsidm_noise_film_bwd(_lib.ptr(gamma), _lib.ptr(t_emb), _lib.ptr(dfilm), B, dim, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+                                  _lib.ptr(wf), F, _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2), _lib.ptr(dwf), _lib.ptr(dbf),
+                                  _lib.ptr(ws), _lib.stream_ptr()), "noise_film_bwd")
+
+
+def _gemm(a, a_f32, sab, sam, sak, b, b_f32, sbb, sbk, sbn, c, c_f32, scb, scm, M, N, K, batch, alpha):
+    _check(_lib.lib().hsidm_bgemm(a, int(a_f32), sab, sam, sak, b, int(b_f32), sbb, sbk, sbn, c, int(c_f32), scb, scm, M, N, K, batch,
+                                  float(alpha), _lib.stream_ptr()), "bgemm")
+
+
+def attention_bwd(qkv, do, precision):
+    """Gradient of ops.attention: qkv [B, H, W, 3C] (q | k | v thirds), do [B, H, W, C] -> dqkv [B, H, W, 3C]."""
+    B, H, W, C3 = qkv.shape
+    C, N = C3 // 3, H * W
+    f32 = qkv.dtype == torch.float32
+    es = qkv.element_size()
+    dev = qkv.device
+    scale = 1.0 / (C ** 0.5)
+    P = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    dP = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    dqkv = torch.empty_like(qkv)
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + C * es, qkv.data_ptr() + 2 * C * es
+    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + C * es, dqkv.data_ptr() + 2 * C * es
+    assert qkv.is_contiguous() and do.is_contiguous() and qkv.is_cuda
+    L = _lib.lib()
+    _gemm(q, f32, N * C3, C3, 1, k, f32, N * C3, 1, C3, P.data_ptr(), True, N * N, N, N, N, C, B, scale)          # S = scale Q K^T
+    _check(L.hsidm_softmax_rows(_lib.ptr(P), B * N, N, _lib.stream_ptr()), "softmax_rows")
+    _gemm(do.data_ptr(), f32, N * C, C, 1, v, f32, N * C3, 1, C3, dP.data_ptr(), True, N * N, N, N, N, C, B, 1.0)   # dP = dO V^T
+    _check(L.hsidm_softmax_bwd_rows(_lib.ptr(P), _lib.ptr(dP), B * N, N, scale, _lib.stream_ptr()), "softmax_bwd_rows")
+    _gemm(dP.data_ptr(), True, N * N, N, 1, k, f32, N * C3, C3, 1, dq, f32, N * C3, C3, N, C, N, B, 1.0)            # dQ = dS K
+    _gemm(dP.data_ptr(), True, N * N, 1, N, q, f32, N * C3, C3, 1, dk, f32, N * C3, C3, N, C, N, B, 1.0)            # dK = dS^T Q
+    _gemm(P.data_ptr(), True, N * N, 1, N, do.data_ptr(), f32, N * C, C, 1, dv, f32, N * C3, C3, N, C, N, B, 1.0)   # dV = P^T dO
+    return dqkv
+
+
+def gather_pack(src, idx, out_hi, out_lo=None):
+    _check(_lib.lib().hsidm_gather_pack(_lib.ptr(src), _lib.ptr(idx), idx.numel(), _lib.ptr(out_hi), _lib.ptr(out_lo), _lib.stream_ptr()),
+           "gather_pack")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _check(_lib.lib().hsidm_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                      float(eps), int(step), float(grad_scale), _lib.stream_ptr()), "adam_step")

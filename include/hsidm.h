@@ -131,9 +131,10 @@ int hsidm_conv_bk(int prec);
  * `part` is [B][nsplit][C][2] floats; hsidm_conv2d's `stats` output has this layout, so a tensor produced by
  * a convolution needs no statistics pass.  finalize takes the two halves of a channel concat separately
  * (part1 may be NULL): GroupNorm groups may straddle the seam (e.g. 192 = 128 + 64 channels, 6 per group).
- * gn_ab (16 * B * C bytes): [B][C][2] fp32 (scale, shift), then [B][C] fp16x2 copies of the same pairs, then [B][C]
- * fp16x2 copies of log2(e) * (scale, shift) (what the bf16 kernels read: the affine-only ones the first copy, the
- * GroupNorm+SiLU ones the pre-scaled copy, whose factor they remove from their fp32 accumulators).
+ * gn_ab (16 * B * C + 8 * B * groups bytes): [B][C][2] fp32 (scale, shift), then [B][C] fp16x2 copies of the same pairs, then
+ * [B][C] fp16x2 copies of log2(e) * (scale, shift) (what the bf16 kernels read: the affine-only ones the first copy, the
+ * GroupNorm+SiLU ones the pre-scaled copy, whose factor they remove from their fp32 accumulators), then [B][groups][2] fp32
+ * (mean, rstd), which only the backward pass reads (hsidm_gn_act_bwd).
  */
 int hsidm_gn_partial(int prec, const void* src0, const void* src1, int C0, int C1, int B, int HW,
                      int nsplit, float* part, void* stream);
@@ -243,6 +244,83 @@ int hsidm_augment(const float* src, float* dst, int64_t outer, int H, int W, int
 int hsidm_color_correction_workspace_bytes(int P, int C);
 int hsidm_color_correction(const float* guide, int guide_HW, const float* x, float* out, int P, int C, int HW,
                            int num_channels, void* workspace, void* stream);
+
+/* ---- training step: forward with materialised operands, backward, optimiser --------------------------------
+ * The reference trains through autograd (model/model.py:49-59: l_pix = netG(data); l_pix.backward(); optG.step()) over
+ * GaussianDiffusion.p_losses (diffusion.py:222-250).  The entry points below are the hand-written adjoints of the forward
+ * kernels above; the host side (hsi-dmgasr_amd/training.py) chains them in reverse order of the forward pass.
+ *
+ * Training-mode operand of a Block's convolution (unet.py:83-88 with Dropout active, :100-101), materialised once and used by
+ * the forward convolution (transform NONE) and by the weight gradient:
+ *   out = dropout_p(act(scale[b,c] * x + shift[b,c])), x = cat(src0, src1), act = SiLU (HSIDM_XF_AFFINE_SILU) or identity
+ *   (HSIDM_XF_AFFINE, the attention's GroupNorm, unet.py:127); (scale, shift) = the fp32 pairs of hsidm_gn_finalize.
+ * Dropout mask: element e (flat NHWC index of out) keeps its value, scaled by 1/(1-p), iff word (e & 3) of
+ * Philox4x32-10(key = seed, counter = (e >> 2, 0, layer, 0)) >= p * 2^32; p_drop = 0 disables it. */
+int hsidm_gn_act_apply(int prec, const void* src0, const void* src1, int C0, int C1, const float* gn_ab, int transform,
+                       int B, int HW, float p_drop, uint64_t seed, uint32_t layer, void* out, void* stream);
+/* Backward of hsidm_gn_act_apply including the GroupNorm statistics (nn.GroupNorm backward):
+ *   dy = da * dropout' * act'(u);  dgamma[c] = sum dy * xhat;  dbeta[c] = sum dy;
+ *   dx = rstd * (gamma * dy - mean_g(gamma * dy) - xhat * mean_g(gamma * dy * xhat))  (+ add [B][HW][C0+C1]: gradients that reach x
+ *   along other paths, e.g. the residual projection), written to the two halves of the concat (dx1 NULL when C1 == 0).
+ * gn_ab: the full table of hsidm_gn_finalize (its (mean, rstd) part is read); gamma [C0+C1]; da NHWC [B][HW][C0+C1].
+ * Four launches: per-(image, split, channel) sums, group means, parameter gradients, dx.  Deterministic.
+ * workspace: hsidm_gn_act_bwd_workspace_floats(B, C0+C1, groups, nsplit) floats. */
+int hsidm_gn_act_bwd_workspace_floats(int B, int C, int groups, int nsplit);
+int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, const void* src1, int C0, int C1, const float* gn_ab,
+                     const float* gamma, int groups, int transform, int B, int HW, float p_drop, uint64_t seed, uint32_t layer,
+                     int nsplit, float* workspace, float* dgamma, float* dbeta, const void* add, void* dx0, void* dx1,
+                     void* stream);
+/* Weight gradient of hsidm_conv2d's convolution: dw[co][ci][ky][kx] (fp32, PyTorch layout [Cout_w][Cin_w][k][k]) =
+ *   sum_{b,y,x} dy[b][y][x][co] * a[b][s*y+ky-1][s*x+kx-1][ci], a = cat(a0, a1) NHWC [B][Hin][Win][C0+C1] (the materialised operand),
+ *   dy NHWC [B][Hout][Wout][Cout]; ksize 3 (pad 1) or 1; stride 1 | 2; ups: a is read through the nearest x2 upsample
+ *   (unet.py:64-65).  Cout_w <= Cout and Cin_w <= C0 + C1 drop the zero-padding channels of the NHWC tensors.
+ * Implicit GEMM over the pixel axis on MFMA (csrc/wgrad.hip), split K with a fixed summation order (deterministic).
+ * workspace: hsidm_conv_wgrad_workspace_bytes(...) bytes (<= 64 MiB). */
+int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize,
+                                         int stride, int ups);
+int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
+                     int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+/* Adjoints of the resampling steps (the input gradient of a convolution itself is hsidm_conv2d with the transposed, flipped
+ * weights): zero_insert2: out[2y][2x] = in[y][x], zero elsewhere (stride-2 conv, unet.py:73-74; Hi = (Ho+1)/2);
+ * sum2x2: out[y][x] = sum of in's 2x2 block (nearest x2, unet.py:64).  NHWC tensors of the mode's storage type. */
+/* out = a + b over n elements (n % 8 == 0) of the mode's storage type: gradients meeting at a fan-out (skip connections). */
+int hsidm_add(int prec, const void* a, const void* b, void* out, int64_t n, void* stream);
+int hsidm_zero_insert2(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+int hsidm_sum2x2(int prec, const void* in, void* out, int B, int H, int W, int C, void* stream);
+/* Column sums of a statistics slab [B][nsplit][C][2] (hsidm_gn_partial / hsidm_conv2d): out_bc[b][c] = sum_s part[b][s][c].sum for
+ * c < Cout (FiLM gradients, unet.py:49), out_c[c] = sum_b out_bc[b][c] (bias gradients); either may be NULL. */
+int hsidm_colsum(const float* part, int nsplit, int B, int C, int Cout, float* out_bc, float* out_c, void* stream);
+/* d/d(eps) of scale * loss_func(noise, eps) (diffusion.py:248 with set_loss's sum reduction; model/model.py:53-54 supplies
+ * scale = 1/(b*c*h*w)): -scale * sign(noise - eps) (L1) or -2 * scale * (noise - eps) (L2).  noise, eps NCHW fp32 [B][Cimg][HW];
+ * out NHWC [B][HW][Cpad] in the storage type, channels >= Cimg zero. */
+int hsidm_loss_grad(int prec, const float* noise, const float* eps, int B, int Cimg, int HW, int Cpad, int kind, float scale,
+                    void* out, void* stream);
+/* Backward of hsidm_noise_film: dfilm [B][F] (per-image channel sums of the gradient at every block1 output) ->
+ * dwf [F][dim], dbf [F], and through t = noise_level_mlp(gamma) (recomputed) dw1 [4dim][dim], db1, dw2 [dim][4dim], db2.
+ * t_emb [B][dim]: the embedding the forward returned.  workspace: hsidm_noise_film_bwd_workspace_floats(B, dim, F) floats. */
+int hsidm_noise_film_bwd_workspace_floats(int B, int dim, int F);
+int hsidm_noise_film_bwd(const float* gamma, const float* t_emb, const float* dfilm, int B, int dim, const float* w1,
+                         const float* b1, const float* w2, const float* wf, int F, float* dw1, float* db1, float* dw2,
+                         float* db2, float* dwf, float* dbf, float* workspace, void* stream);
+/* Strided batched GEMM on the exact fp32 matrix instruction (attention backward, csrc/bgemm.hip):
+ * C[i](m, n) = alpha * sum_k A[i](m, k) * B[i](k, n); A(m,k) = a[i*sab + m*sam + k*sak], B(k,n) = b[i*sbb + k*sbk + n*sbn],
+ * C(m,n) = c[i*scb + m*scm + n]; *_f32: the array holds fp32 (1) or bf16 (0). */
+int hsidm_bgemm(const void* a, int a_f32, int64_t sab, int64_t sam, int64_t sak, const void* b, int b_f32, int64_t sbb,
+                int64_t sbk, int64_t sbn, void* c, int c_f32, int64_t scb, int64_t scm, int M, int N, int K, int batch,
+                float alpha, void* stream);
+/* s <- softmax over each row of s [rows][N] (N <= 1024);  dp <- p o (dp - rowsum(dp o p)) * scale (its backward). */
+int hsidm_softmax_rows(float* s, int64_t rows, int N, void* stream);
+int hsidm_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int N, float scale, void* stream);
+/* Packed (kernel-order) weights straight from the flat fp32 master copy: out_hi[i] = bf16(src[idx[i]]) and, when out_lo != NULL
+ * (HSIDM_F32X3), out_lo[i] = bf16(src[idx[i]] - out_hi[i]); idx[i] < 0 gives a zero (padding).  idx is the packed layout's
+ * gather map, built once on the host; one launch re-packs every convolution of the network after an optimiser step. */
+int hsidm_gather_pack(const float* src, const int32_t* idx, int64_t n, void* out_hi, void* out_lo, void* stream);
+/* One Adam step over a flat fp32 buffer (torch.optim.Adam as built in model/model.py:37-41: betas (0.9, 0.999), eps 1e-8, no
+ * weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), g scaled by
+ * grad_scale first (1/world size after a sum all-reduce). */
+int hsidm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,7 +105,8 @@ def test_benchmark_dispatch_forward_matches_the_oracle_at_batch_40(dev):
     finally:
         ops.set_conv_probe(None)
     labels = sorted({r["kernel"] for r in recs})
-    for need in ("conv_v2 bn256 8x16", "conv_v2 bn256 8x8x2", "conv_v3 bn64", "up4", "dn4", "conv1x1_g"):
+    # (the 8x8 level's two-image 256-cout items need >= 128 work items = batch 128: next test)
+    for need in ("conv_v2 bn256 8x16", "conv_v3 bn64", "up4", "dn4", "conv1x1_g"):
         assert any(need in l for l in labels), (need, labels)
     assert any(l.startswith("conv1x1_g") and l.endswith(" gn") for l in labels), labels           # attention qkv with the GN prologue
     assert not any(l.startswith("conv_igemm") for l in labels), labels                             # nothing on the generic kernel
@@ -115,6 +116,32 @@ def test_benchmark_dispatch_forward_matches_the_oracle_at_batch_40(dev):
     per = [rel_err(y[i].cpu().numpy(), want[i].numpy()) for i in range(B)]
     log_err("unet_full_b40_worst_sample", "bf16", max(per))
     assert max(per) < 3e-2, max(per)
+
+
+def test_8x8_level_two_image_256_cout_items_match_the_oracle(dev):
+    """The 8x8 level's benchmark form (two-image 8x8 tiles, 256-cout items on 8 waves) engages from 128 work items: a
+    512 -> 512 ResnetBlock on 8x8 maps at B = 132 against the oracle block."""
+    from hsi_dmgasr_amd import ops
+    from hsi_dmgasr_amd.sr3_modules import unet
+    from oracle import sr3_unet
+    m = unet.ResnetBlock(512, 512, noise_level_emb_dim=64, norm_groups=32).to(dev).eval()
+    m.precision = "bf16"
+    sd = fill_synth(m, "res8x8.")
+    B = 132
+    x = synth_tensor("res8x8.x", (B, 512, 8, 8))
+    t = synth_tensor("res8x8.t", (B, 1, 64))
+    recs = []
+    ops.set_conv_probe(recs)
+    try:
+        y = m(G(x, dev), G(t, dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_probe(None)
+    labels = sorted({r["kernel"] for r in recs})
+    assert any("conv_v2 bn256 8x8x2" in l for l in labels), labels
+    with torch.no_grad():
+        want = sr3_unet.resnet_block(sd, "", torch.from_numpy(x), torch.from_numpy(t), 32)
+    check("resblock_8x8_b132_bn256", "bf16", y, want, tol=1e-2)
 
 
 def test_graph_replayed_philox_chain_at_batch_40_with_wrap(dev):

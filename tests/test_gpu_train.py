@@ -1,0 +1,354 @@
+"""GPU parity of the training step (SURVEY 8f N2 / a15 / BASELINE configs[4]): every backward kernel through the C ABI against
+torch fp32 formulas (tests/cpu_double.py doubles as the per-op reference), and whole gradients / optimiser steps against the
+oracle's autograd (oracle/train.py, pinned to gradients of the imported reference by tests/golden/grads.npz)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cpu_double as ref
+from gpu_util import check, fill_synth, log_err
+from helpers import jload, load_npz, rel_err, synth_tensor
+
+pytestmark = pytest.mark.gpu
+PRECS = ["fp32", "bf16"]
+TOL = {"fp32": 1e-3, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def act(t, prec, dev):
+    return t.to(dev, torch.bfloat16 if prec == "bf16" else torch.float32).contiguous()
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ------------------------------------------------------------------------------------------------------- GroupNorm + SiLU + dropout
+GN_CASES = [  # B, H, W, C0, C1, groups, silu, p_drop
+    (2, 8, 8, 64, 0, 32, True, 0.0),
+    (3, 16, 8, 64, 32, 32, True, 0.2),       # concat whose seam splits a group (3 channels per group), dropout
+    (2, 8, 8, 128, 64, 32, True, 0.0),       # 6 channels per group: vectors of 8 straddle groups
+    (2, 4, 4, 64, 0, 32, False, 0.0),        # the attention's GroupNorm (affine only)
+    (1, 32, 32, 32, 0, 8, True, 0.35),
+]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("case", GN_CASES)
+def test_gn_act_apply_and_backward(dev, prec, case):
+    from hsi_dmgasr_amd import ops, train_ops as T
+    B, H, W, C0, C1, groups, silu, p = case
+    C = C0 + C1
+    x0 = rnd((B, H, W, C0), 1) * 1.5 + 0.3
+    x1 = rnd((B, H, W, C1), 2) if C1 else None
+    gamma, beta = 1 + 0.2 * rnd((C,), 3), 0.1 * rnd((C,), 4)
+    da = rnd((B, H, W, C), 5)
+    addt = rnd((B, H, W, C), 6)
+    # the kernels see the storage-type values: the reference starts from those
+    x0d, x1d, dad, addd = act(x0, prec, dev), (act(x1, prec, dev) if C1 else None), act(da, prec, dev), act(addt, prec, dev)
+    x0r, x1r, dar, addr = x0d.float().cpu(), (x1d.float().cpu() if C1 else None), dad.float().cpu(), addd.float().cpu()
+    ab = ops.gn_scale_shift(x0d, x1d, gamma.to(dev), beta.to(dev), groups, prec)
+    abr = ref.gn_scale_shift(x0r, x1r, gamma, beta, groups, prec)
+    a = T.gn_act_apply(x0d, x1d, ab, silu, prec, p, 77, 5)
+    ar = ref.gn_act_apply(x0r, x1r, abr, silu, prec, p, 77, 5)
+    check("gn_act_apply%s" % (case,), prec, a, ar, tol=TOL[prec] / 4)
+    if p > 0:      # the mask itself is bit-exact (Philox): same zeros
+        assert torch.equal(a.float().cpu() == 0, ar == 0)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dx0, dx1 = T.gn_act_bwd(dad, x0d, x1d, ab, gamma.to(dev), groups, silu, prec, dg, db, p, 77, 5, add=addd)
+    dgr, dbr = torch.empty(C), torch.empty(C)
+    rx0, rx1 = ref.gn_act_bwd(dar, x0r, x1r, abr, gamma, groups, silu, prec, dgr, dbr, p, 77, 5, add=addr)
+    check("gn_act_bwd_dx0%s" % (case,), prec, dx0, rx0, tol=TOL[prec])
+    if C1:
+        check("gn_act_bwd_dx1%s" % (case,), prec, dx1, rx1, tol=TOL[prec])
+    check("gn_act_bwd_dgamma%s" % (case,), prec, dg, dgr, tol=TOL[prec])
+    check("gn_act_bwd_dbeta%s" % (case,), prec, db, dbr, tol=TOL[prec])
+
+
+# ------------------------------------------------------------------------------------------------------- weight gradient
+WG_CASES = [  # B, Hin, Win, C0, C1, Cout, ksize, stride, ups, cout_w, cin_w
+    (2, 16, 16, 64, 0, 64, 3, 1, False, 64, 64),      # 8x16 tiles
+    (3, 8, 8, 64, 32, 128, 3, 1, False, 128, 96),      # 8x8 tiles, concat input, two cout tiles, ragged cin tile
+    (2, 24, 40, 72, 0, 40, 3, 1, False, 40, 72),       # partial tiles on both axes, channel counts off the 64 grid
+    (2, 16, 32, 8, 0, 64, 3, 1, False, 64, 6),         # the stem: 6 real input channels in an 8-channel tensor
+    (2, 16, 16, 64, 0, 8, 3, 1, False, 3, 64),         # the final conv: 3 real output channels in an 8-channel gradient
+    (2, 16, 16, 64, 0, 64, 3, 2, False, 64, 64),       # stride 2, 8x8 output
+    (3, 32, 32, 32, 0, 48, 3, 2, False, 48, 32),       # stride 2, 16-wide output tiles
+    (2, 9, 13, 32, 0, 32, 3, 2, False, 32, 32),        # stride 2, odd input size
+    (2, 8, 8, 64, 0, 64, 3, 1, True, 64, 64),          # nearest x2 read, 16x16 output
+    (2, 4, 4, 32, 0, 96, 3, 1, True, 96, 32),          # nearest x2, 8x8 output
+    (2, 16, 16, 128, 64, 64, 1, 1, False, 64, 192),    # 1x1 projection over a concat
+    (5, 8, 8, 64, 0, 192, 1, 1, False, 192, 64),       # 1x1, 8x8 tiles (attention qkv)
+    (40, 16, 16, 64, 0, 64, 3, 1, False, 64, 64),      # many pixel tiles: several K splits
+]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_weight_gradient(dev, prec, case):
+    from hsi_dmgasr_amd import train_ops as T
+    B, Hin, Win, C0, C1, Ct, k, stride, ups, cout_w, cin_w = case
+    Ho, Wo = (2 * Hin, 2 * Win) if ups else (((Hin + 1) // 2, (Win + 1) // 2) if stride == 2 else (Hin, Win))
+    a0 = act(rnd((B, Hin, Win, C0), 11), prec, dev)
+    a1 = act(rnd((B, Hin, Win, C1), 12), prec, dev) if C1 else None
+    dy = act(rnd((B, Ho, Wo, Ct), 13, 0.5), prec, dev)
+    dw = torch.full((cout_w, cin_w, k, k), float("nan"), device=dev)
+    T.conv_wgrad(a0, a1, dy, dw, prec, stride=stride, ups=ups)
+    want = torch.empty(cout_w, cin_w, k, k)
+    ref.conv_wgrad(a0.float().cpu(), None if a1 is None else a1.float().cpu(), dy.float().cpu(), want, prec, stride=stride, ups=ups)
+    # same inputs (already rounded to the storage type) on both sides: what remains is the accumulation order (fp32 mode)
+    # or nothing at all beyond it (bf16 products are exact in fp32)
+    check("conv_wgrad%s" % (case,), prec, dw, want, tol=1e-4 if prec == "fp32" else 2e-4)
+    dw2 = torch.empty_like(dw)
+    T.conv_wgrad(a0, a1, dy, dw2, prec, stride=stride, ups=ups)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)                                     # fixed summation order
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 96, 3), (3, 8, 8, 128, 64, 3), (2, 16, 16, 64, 192, 1), (2, 16, 16, 8, 64, 3)])
+def test_conv_input_gradient_is_a_convolution_with_transposed_flipped_weights(dev, prec, case):
+    """dgrad through hsidm_conv2d: weights [Cout, Cin, k, k] -> transpose(0, 1).flip(2, 3), against torch's conv2d input gradient."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Cout_t, Cin, k = case
+    cout_w = 3 if Cout_t == 8 else Cout_t                            # the final conv: 3 real channels in an 8-channel gradient tensor
+    w = rnd((cout_w, Cin, k, k), 21) / math.sqrt(Cin * k * k)
+    dy = torch.zeros(B, H, W, Cout_t)
+    dy[..., :cout_w] = rnd((B, H, W, cout_w), 22)
+    dyd = act(dy, prec, dev)
+    pk = ops.PackedConv(w.transpose(0, 1).flip(2, 3).contiguous().to(dev), None, prec)
+    dx = ops.conv2d(dyd, pk)
+    want = torch.nn.grad.conv2d_input((B, Cin, H, W), w, ref.nchw(dyd.float().cpu()[..., :cout_w]), padding=k // 2)
+    check("conv_dgrad%s" % (case,), prec, dx, ref.nhwc(want), tol=TOL[prec] / 2)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_resampling_adjoints_and_small_kernels(dev, prec):
+    from hsi_dmgasr_amd import train_ops as T
+    x = act(rnd((2, 5, 7, 16), 31), prec, dev)
+    z = T.zero_insert2(x, 9, 13, prec)
+    check("zero_insert2", prec, z, ref.zero_insert2(x.float().cpu(), 9, 13, prec), tol=1e-6)
+    z2 = T.zero_insert2(x, 10, 14, prec)
+    check("zero_insert2_even", prec, z2, ref.zero_insert2(x.float().cpu(), 10, 14, prec), tol=1e-6)
+    u = act(rnd((2, 8, 12, 24), 32), prec, dev)
+    check("sum2x2", prec, T.sum2x2(u, prec), ref.sum2x2(u.float().cpu(), prec), tol=TOL[prec] / 4)
+    a, b = act(rnd((3, 4, 4, 8), 33), prec, dev), act(rnd((3, 4, 4, 8), 34), prec, dev)
+    check("add", prec, T.add(a, b, prec), a.float().cpu() + b.float().cpu(), tol=TOL[prec] / 4)
+    y = act(rnd((3, 16, 16, 40), 35), prec, dev)
+    oc = torch.empty(33, device=dev)
+    bc = T.channel_sums(y, prec, out_c=oc, want_bc=True, cout=33)
+    check("channel_sums_bc", prec, bc, y.float().cpu().sum(dim=(1, 2))[:, :33], tol=1e-5)
+    check("channel_sums_c", prec, oc, y.float().cpu().sum(dim=(0, 1, 2))[:33], tol=1e-5)
+    noise, eps = rnd((2, 3, 8, 8), 36).to(dev), rnd((2, 3, 8, 8), 37).to(dev)
+    eps[0, 0, 0, 0] = noise[0, 0, 0, 0]                                   # sign(0) = 0 like torch's L1 gradient
+    for kind in ("l1", "l2"):
+        g = T.loss_grad(noise, eps, kind, 0.125, prec)
+        assert g.shape == (2, 8, 8, 8)
+        check("loss_grad_" + kind, prec, g, ref.loss_grad(noise.cpu(), eps.cpu(), kind, 0.125, prec), tol=TOL[prec] / 4)
+
+
+def test_film_and_noise_mlp_backward(dev):
+    from hsi_dmgasr_amd import ops, train_ops as T
+    B, dim, Fn = 5, 32, 600
+    w1, b1, w2, b2 = rnd((4 * dim, dim), 41) / 6, 0.1 * rnd((4 * dim,), 42), rnd((dim, 4 * dim), 43) / 11, 0.1 * rnd((dim,), 44)
+    wf, bf = rnd((Fn, dim), 45) / 6, 0.1 * rnd((Fn,), 46)
+    gamma = torch.tensor([0.99, 0.7, 0.4, 0.1, 0.003])
+    dfilm = rnd((B, Fn), 47)
+    mlp_d = tuple(t.to(dev) for t in (w1, b1, w2, b2))
+    film, t_emb = ops.noise_film(B, dim, mlp_d, wf.to(dev), bf.to(dev), gamma=gamma.to(dev), want_t=True)
+    fr, tr = ref.noise_film(B, dim, (w1, b1, w2, b2), wf, bf, gamma=gamma, want_t=True)
+    check("noise_film_fwd", "fp32", film, fr, tol=1e-5)
+    shapes = [(4 * dim, dim), (4 * dim,), (dim, 4 * dim), (dim,), (Fn, dim), (Fn,)]
+    got = tuple(torch.full(s, float("nan"), device=dev) for s in shapes)
+    T.noise_film_bwd(gamma.to(dev), t_emb, dfilm.to(dev), mlp_d, wf.to(dev), got)
+    want = tuple(torch.empty(s) for s in shapes)
+    ref.noise_film_bwd(gamma, tr, dfilm, (w1, b1, w2, b2), wf, want)
+    for name, g, w in zip(("dw1", "db1", "dw2", "db2", "dwf", "dbf"), got, want):
+        check("noise_film_bwd_" + name, "fp32", g, w, tol=2e-5)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (3, 16, 16, 128), (1, 4, 6, 96)])
+def test_attention_backward(dev, prec, shape):
+    from hsi_dmgasr_amd import train_ops as T
+    B, H, W, C = shape
+    qkv = act(rnd((B, H, W, 3 * C), 51), prec, dev)
+    do = act(rnd((B, H, W, C), 52), prec, dev)
+    g = T.attention_bwd(qkv, do, prec)
+    want = ref.attention_bwd(qkv.float().cpu(), do.float().cpu(), prec)
+    check("attention_bwd%s" % (shape,), prec, g, want, tol=1e-4 if prec == "fp32" else 6e-3)      # bf16: the output rounding
+
+
+def test_gather_pack_and_adam(dev):
+    from hsi_dmgasr_amd import train_ops as T
+    src = rnd((1000,), 61)
+    idx = torch.randint(-1, 1000, (4096,), generator=torch.Generator().manual_seed(62), dtype=torch.int32)
+    hi, lo = torch.empty(4096, dtype=torch.bfloat16, device=dev), torch.empty(4096, dtype=torch.bfloat16, device=dev)
+    T.gather_pack(src.to(dev), idx.to(dev), hi, lo)
+    rh, rl = torch.empty(4096, dtype=torch.bfloat16), torch.empty(4096, dtype=torch.bfloat16)
+    ref.gather_pack(src, idx, rh, rl)
+    assert torch.equal(hi.cpu(), rh) and torch.equal(lo.cpu(), rl)
+    n = 10007
+    p0, g = rnd((n,), 63), rnd((n,), 64, 0.01)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=1e-3)                                   # the optimiser the reference builds (model/model.py:37-41)
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gs = g * step
+        pr.grad = gs.clone()
+        opt.step()
+        T.adam_step(p, (2 * gs).to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.5)
+    check("adam_3_steps", "fp32", p, pr.detach(), tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------- whole gradients
+TINY = dict(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1, image_size=16)
+MID = dict(in_channel=6, out_channel=3, inner_channel=32, norm_groups=16, channel_mults=[1, 2, 2], attn_res=[4], res_blocks=2, image_size=16)
+WIDE = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4], attn_res=[8], res_blocks=1, image_size=32)
+
+
+def build(cfg, tag, kind, prec, dev, train_mode, lr=1e-5, seed=9):
+    from hsi_dmgasr_amd import training
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    u = unet.UNet(dropout=0.2, precision=prec, **cfg).to(dev)
+    sd = fill_synth(u, "unet_%s." % tag)
+    u.train(train_mode)
+    gd = diffusion.GaussianDiffusion(u, image_size=cfg["image_size"], channels=3, loss_type=kind, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), dev)
+    return sd, gd, training.Trainer(gd, lr=lr, dropout_seed=seed)
+
+
+def grad_errors(tr, grads):
+    """Per-parameter relative error with a floor for the gradients that are mathematically zero (see tests/test_train_orchestration.py),
+    and the error of the whole gradient vector."""
+    scale = max(float(g.norm()) for g in grads.values())
+    worst, wname, num, den = 0.0, None, 0.0, 0.0
+    for name, p in tr.net.named_parameters():
+        got, want = tr.G(p).float().cpu(), grads[name]
+        assert torch.isfinite(got).all(), name
+        e = float((got - want).norm())
+        num += e * e
+        den += float(want.norm()) ** 2
+        r = e / (float(want.norm()) + 1e-4 * scale)
+        if r > worst:
+            worst, wname = r, name
+    return worst, wname, math.sqrt(num / den)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kind", ["l1", "l2"])
+def test_gradients_against_the_reference_fixture(dev, prec, kind):
+    """l_pix and the gradient of every parameter of the tiny UNet (eval mode = dropout off, as the fixture) against numbers
+    taken from the imported reference's autograd (grads.npz: norm + two random projections per parameter, some tensors whole)."""
+    g = load_npz("grads.npz")
+    k = "grad_%s." % kind
+    sd, gd, tr = build(jload(g["cfg_json"]), "tiny", kind, prec, dev, False)
+    hr, sr, noise = (torch.from_numpy(synth_tensor("grad_%s.%s" % (kind, n), (3, 3, 16, 16))).to(dev) for n in ("hr", "sr", "noise"))
+    np.random.seed(int(g[k + "np_seed"]))                            # t and gamma drawn as the reference draws them
+    loss = tr.loss_and_grads({"HR": hr, "SR": sr}, noise=noise)
+    tol = TOL[prec]
+    assert abs(float(loss) - float(g[k + "l_pix"])) < tol * abs(float(g[k + "l_pix"]))
+    names = jload(g[k + "names_json"])
+    floor = 1e-4 * float(g[k + "stats"][:, 0].max())
+    params = dict(tr.net.named_parameters())
+    worst = 0.0
+    for name, (nrm, p0, p1) in zip(names, g[k + "stats"]):
+        gg = tr.G(params[name]).double().cpu().numpy()
+        r0 = synth_tensor("gradproj0." + name, gg.shape).astype(np.float64)
+        r1 = synth_tensor("gradproj1." + name, gg.shape).astype(np.float64)
+        e = max(abs(np.linalg.norm(gg) - nrm) / (nrm + floor), abs((gg * r0).sum() - p0) / ((nrm + floor) * np.linalg.norm(r0)),
+                abs((gg * r1).sum() - p1) / ((nrm + floor) * np.linalg.norm(r1)))
+        worst = max(worst, e)
+        assert e < 3 * tol, (name, e)
+    for key in g.files:
+        if key.startswith(k + "full."):
+            name = key[len(k + "full."):]
+            e = float(np.linalg.norm(tr.G(params[name]).cpu().numpy() - g[key]) / (np.linalg.norm(g[key]) + floor))
+            assert e < 3 * tol, (name, e)
+    log_err("grads_vs_reference_fixture_%s" % kind, prec, worst)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg_name,kind,train_mode,B", [("tiny", "l1", True, 2), ("mid", "l2", True, 3), ("wide", "l1", True, 2)])
+def test_gradients_with_dropout_against_oracle_autograd(dev, prec, cfg_name, kind, train_mode, B):
+    """Training mode (Dropout 0.2 in every block2, masks from the Philox generator the oracle restates) on three network shapes:
+    every parameter's gradient against torch.autograd over the oracle."""
+    from oracle import train as otrain
+    cfg = {"tiny": TINY, "mid": MID, "wide": WIDE}[cfg_name]
+    s = cfg["image_size"]
+    sd, gd, tr = build(cfg, cfg_name, kind, prec, dev, train_mode)
+    hr, sr, noise = (torch.from_numpy(synth_tensor("gtrain.%s.%s" % (cfg_name, n), (B, 3, s, s))) for n in ("hr", "sr", "noise"))
+    gamma = torch.linspace(0.9, 0.15, B)
+    loss = tr.loss_and_grads({"HR": hr.to(dev), "SR": sr.to(dev)}, noise=noise.to(dev), gamma=gamma)
+    want_loss, grads = otrain.loss_and_grads(sd, cfg, hr, sr, noise, gamma, kind, 0.2, otrain.drop_key(9, 0))
+    worst, wname, total = grad_errors(tr, grads)
+    log_err("grads_%s_%s_dropout" % (cfg_name, kind), prec, total, {"worst_param": wname, "worst_param_err": worst,
+                                                                      "loss_rel_err": abs(float(loss) - want_loss) / abs(want_loss)})
+    assert abs(float(loss) - want_loss) < TOL[prec] * abs(want_loss)
+    assert total < TOL[prec] and worst < 5 * TOL[prec], (total, worst, wname)
+
+
+def test_optimizer_steps_against_torch_adam(dev):
+    """Three optimize_parameters() calls (fp32 mode, dropout on, lr 1e-3) against torch.optim.Adam driven by the oracle's gradients:
+    the parameters after three steps, for every parameter with a non-degenerate gradient."""
+    from oracle import train as otrain
+    sd, gd, tr = build(TINY, "tiny", "l1", "fp32", dev, True, lr=1e-3)
+    hr, sr, noise = (torch.from_numpy(synth_tensor("gadam.%s" % n, (2, 3, 16, 16))) for n in ("hr", "sr", "noise"))
+    gamma = torch.tensor([0.6, 0.2])
+    data = {"HR": hr.to(dev), "SR": sr.to(dev)}
+    losses = [float(tr.optimize_parameters(data, noise=noise.to(dev), gamma=gamma)) for _ in range(3)]
+    want = otrain.adam_steps(sd, lambda s, ps: otrain.loss_and_grads(ps, TINY, hr, sr, noise, gamma, "l1", 0.2, otrain.drop_key(9, s))[1],
+                             3, lr=1e-3)
+    g0 = otrain.loss_and_grads(sd, TINY, hr, sr, noise, gamma, "l1", 0.2, otrain.drop_key(9, 0))[1]
+    scale = max(float(g.norm()) for g in g0.values())
+    checked, worst = 0, 0.0
+    for name, p in tr.net.named_parameters():
+        if float(g0[name].norm()) < 1e-4 * scale:
+            continue
+        moved = float((want[name] - sd[name]).norm())
+        e = float((p.detach().cpu() - want[name]).norm()) / moved
+        worst = max(worst, e)
+        checked += 1
+    log_err("adam_three_steps_params", "fp32", worst, {"losses": losses})
+    assert checked > 100 and worst < 5e-2, worst
+    assert all(math.isfinite(l) for l in losses)
+    # the inference path sees the updated weights (re-packed kernel weights follow the master copy)
+    x = torch.from_numpy(synth_tensor("gadam.x", (2, 6, 16, 16))).to(dev)
+    gam = torch.tensor([[0.5], [0.3]], device=dev)
+    tr.net.eval()
+    y = tr.net(x, gam)
+    from oracle import sr3_unet
+    ysd = {k: v.detach().cpu() for k, v in tr.net.state_dict().items()}
+    check("inference_after_training", "fp32", y, sr3_unet.unet_forward(ysd, TINY, x.cpu(), gam.cpu()), tol=1e-3)
+
+
+def test_full_size_training_step_gradients(dev):
+    """The shipped 97.8 M-parameter UNet, one training step's gradients in fp32 mode at B = 1, 128 x 128 (BASELINE configs[4]'s
+    network) against the oracle's autograd on the host; and the bf16 mode's deviation from it, logged and bounded."""
+    from oracle import train as otrain
+    cfg = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8], attn_res=[16],
+               res_blocks=2, image_size=128)
+    hr, sr, noise = (torch.from_numpy(synth_tensor("gfull.%s" % n, (1, 3, 128, 128))) for n in ("hr", "sr", "noise"))
+    gamma = torch.tensor([0.45])
+    grads = None
+    for prec in PRECS:
+        sd, gd, tr = build(cfg, "full", "l1", prec, dev, True)
+        loss = tr.loss_and_grads({"HR": hr.to(dev), "SR": sr.to(dev)}, noise=noise.to(dev), gamma=gamma)
+        if grads is None:
+            want_loss, grads = otrain.loss_and_grads(sd, cfg, hr, sr, noise, gamma, "l1", 0.2, otrain.drop_key(9, 0))
+        worst, wname, total = grad_errors(tr, grads)
+        log_err("grads_full_unet_b1", prec, total, {"worst_param": wname, "worst_param_err": worst,
+                                                    "loss_rel_err": abs(float(loss) - want_loss) / abs(want_loss)})
+        assert abs(float(loss) - want_loss) < TOL[prec] * abs(want_loss)
+        assert total < (1e-3 if prec == "fp32" else 5e-2), (prec, total, worst, wname)
+        del tr, gd
+        torch.cuda.empty_cache()
