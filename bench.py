@@ -189,6 +189,54 @@ def gae_bench(dev, patches, reps=5):
     return out
 
 
+def train_bench(dev, batch=4, steps=10, warm=3, precisions=("bf16", "fp32"), reduce_grads=False):
+    """BASELINE configs[4]: one joint-train step of the UNet (p_losses forward in training mode with Dropout 0.2, hand-written
+    backward, fused Adam, re-pack) on `batch` GAE latents of 3 x 128 x 128 per GPU; model/model.py:49-59.  Returns per precision
+    mode the time per step (HIP events around whole steps) and its split into forward+loss / backward / optimiser."""
+    from hsi_dmgasr_amd.init import init_weights_orthogonal
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    out = {"batch_per_gpu": batch, "steps": steps}
+    g = torch.Generator().manual_seed(5)
+    data = {"HR": torch.randn((batch, 3, 128, 128), generator=g).clamp(-2.5, 2.5).to(dev),
+            "SR": torch.randn((batch, 3, 128, 128), generator=g).clamp(-2.5, 2.5).to(dev)}
+    for prec in precisions:
+        u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8],
+                      attn_res=[16], res_blocks=2, dropout=0.2, image_size=128, precision=prec)
+        init_weights_orthogonal(u, seed=0)
+        gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, loss_type="l1", conditional=True).to(dev).train()
+        gd.set_loss(dev)
+        gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), dev)   # config/sr_sr3_16_128.json:96-101
+        tr = gd.trainer(lr=1e-5)                                                                                        # :120-123
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t_f = t_b = t_o = 0.0
+        losses = []
+        for i in range(warm + steps):
+            if i == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ev[0].record()
+            loss, state = tr.forward_loss(data)
+            ev[1].record()
+            tr.backward_loss(state, 1.0 / float(state[2]))
+            ev[2].record()
+            tr.optimizer_step()
+            ev[3].record()
+            if i >= warm:
+                torch.cuda.synchronize()
+                t_f += ev[0].elapsed_time(ev[1]); t_b += ev[1].elapsed_time(ev[2]); t_o += ev[2].elapsed_time(ev[3])
+                losses.append(float(loss) / float(state[2]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert all(l == l and abs(l) < 1e6 for l in losses), "training diverged"
+        out[prec] = dict(ms_per_step=dt / steps * 1e3, value=steps * batch / dt, unit="train-steps*batch/s",
+                         forward_ms=t_f / steps, backward_ms=t_b / steps, optimizer_ms=t_o / steps,
+                         l_pix_first=losses[0], l_pix_last=losses[-1],
+                         tflops=3 * 92.35e9 * batch / (dt / steps) / 1e12)      # fwd + dgrad + wgrad ~ 3x the forward's 92.35 GFLOP per sample
+        del tr, gd, u
+        torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a plain shell: re-run under torch.distributed.run as a CHILD process (never exec:
     nothing here has touched the GPU yet, and nothing will in this parent)."""
@@ -198,6 +246,62 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def main_train(args, dev, rank, world, use_dist):
+    """--workload train: BASELINE configs[4] as its own benchmark line (one rank per GPU, gradients averaged over RCCL inside the
+    backward pass).  K timed steps after W warm-up steps, barrier + synchronize on both sides, MAX over ranks."""
+    import torch.distributed as dist
+    from hsi_dmgasr_amd import parallel
+    from hsi_dmgasr_amd.init import init_weights_orthogonal
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    prec, B = args.precision, args.train_batch
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8],
+                  attn_res=[16], res_blocks=2, dropout=0.2, image_size=128, precision=prec)
+    init_weights_orthogonal(u, seed=0)
+    gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, loss_type="l1", conditional=True).to(dev).train()
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), dev)
+    parallel.broadcast_module_(gd, src=0)
+    tr = gd.trainer(lr=1e-5)
+    g = torch.Generator().manual_seed(5 + rank)
+    data = {"HR": torch.randn((B, 3, 128, 128), generator=g).clamp(-2.5, 2.5).to(dev),
+            "SR": torch.randn((B, 3, 128, 128), generator=g).clamp(-2.5, 2.5).to(dev)}
+    steps = min(args.steps, 200)
+    for _ in range(max(args.warmup, 2)):
+        tr.optimize_parameters(data)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.optimize_parameters(data)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    el = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    dt = float(el.item())
+    assert torch.isfinite(loss), "training diverged"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "UNet joint-train steps/sec x batch (forward + backward + Adam), GAE latents 3x128x128, BASELINE configs[4]",
+            "value": steps * B * world / dt, "unit": "train-steps*batch/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": prec if prec == "bf16" else "fp32 (bf16x3 split forward/dgrad, exact fp32 MFMA wgrad)",
+            "data": "synthetic (orthogonal-init weights seed 0, N(0,1) latents clipped to +-2.5)",
+            "config": {"workload": "sr_gae.py joint-train step: SR3 UNet 97.8M fwd+bwd (Dropout 0.2, L1) + Adam lr 1e-5, GAE frozen",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "grad_allreduce": "bucketed RCCL all-reduce of the flat fp32 gradient buffer (%d MB), launched from inside the backward pass"
+                                         % (tr.grad.numel() * 4 >> 20)},
+            "rccl_ranks": dist.get_world_size() if use_dist else 1, "l_pix": float(loss),
+            "tflops": 3 * 92.35e9 * B * world / (dt / steps) / 1e12}))
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def main():
@@ -215,6 +319,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode object")
     ap.add_argument("--no-gae", action="store_true", help="skip the group-autoencoder object")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step object (BASELINE configs[4])")
+    ap.add_argument("--workload", default="sample", choices=["sample", "train"],
+                    help="sample: the headline metric (reverse-diffusion steps); train: BASELINE configs[4], one joint-train step "
+                         "(UNet forward + backward + Adam, gradients all-reduced over the ranks) on --train-batch latents per GPU")
+    ap.add_argument("--train-batch", type=int, default=4, help="latents per GPU and training step (sr_gae.py:182 uses 4)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -236,6 +345,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from hsi_dmgasr_amd import parallel
+    if args.workload == "train":
+        return main_train(args, dev, rank, world, use_dist)
     log('building model')
     gd = build_model(dev, args.precision)
     log('model on device')
@@ -321,6 +432,10 @@ def main():
         with torch.no_grad():
             gae_rec = gae_bench(dev, patches)
         log('gae done')
+    train_rec = None
+    if rank == 0 and world == 1 and not args.no_train:
+        train_rec = train_bench(dev)
+        log('train step done')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -342,7 +457,7 @@ def main():
                        "patches_per_gpu": patches, "total_patches": total_patches, "groups_per_patch": GROUPS,
                        "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": allgather_ms,
-            "roofline": roof, "fp32_mode": fp32, "gae": gae_rec, "cpu_baseline": cpu,
+            "roofline": roof, "fp32_mode": fp32, "gae": gae_rec, "train_step": train_rec, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if use_dist:

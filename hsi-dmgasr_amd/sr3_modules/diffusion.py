@@ -121,6 +121,25 @@ class ReverseRun:
         return self.x
 
 
+class _TrainingLoss(torch.autograd.Function):
+    """autograd node around the hand-written training step: forward = Trainer.forward_loss, backward = Trainer.backward_loss
+    scaled by the incoming gradient.  The parameters are inputs only so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, gd, x_in, noise, *params):
+        tr = gd.trainer()
+        loss, state = tr.forward_loss(x_in, noise)
+        ctx.tr, ctx.state, ctx.n = tr, state, len(params)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        tr = ctx.tr
+        tr.backward_loss(ctx.state, float(g))
+        # copies: autograd accumulates into p.grad, which may itself be a view of the flat gradient buffer
+        return (None, None, None) + tuple(tr.G(p).clone() for p in tr.net.parameters())
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, denoise_fn, image_size, channels=31, loss_type="l1", conditional=True, schedule_opt=None):
         super().__init__()
@@ -268,27 +287,44 @@ class GaussianDiffusion(nn.Module):
         gamma = continuous_sqrt_alpha_cumprod.to(torch.float32).reshape(b).contiguous()
         return ops.q_sample(x_start.contiguous(), noise.contiguous(), gamma)
 
-    @torch.no_grad()
+    def trainer(self, **kw):
+        """The training engine of this model (hsi_dmgasr_amd.training.Trainer), created on first use: it moves the UNet's
+        parameters into one flat buffer (the nn.Parameters stay valid, as views)."""
+        if getattr(self, "_trainer", None) is None:
+            from ..training import Trainer
+            object.__setattr__(self, "_trainer", Trainer(self, **kw))
+        return self._trainer
+
     def p_losses(self, x_in, noise=None):
-        """Value of the training objective (reference diffusion.py:222-250): sum-reduced L1/L2 between the drawn noise
-        and UNet(cat(SR, q_sample(HR)), gamma).  t and the per-sample gamma come from numpy's global generator exactly
-        as in the reference, so `np.random.seed` reproduces its draws.  Forward value only: the result carries no
-        autograd graph (backward kernels are SURVEY 8f N2)."""
-        x_start = x_in["HR"].contiguous()
-        b = x_start.shape[0]
-        t = np.random.randint(1, self.num_timesteps + 1)
-        gamma = torch.FloatTensor(np.random.uniform(self.sqrt_alphas_cumprod_prev[t - 1],
-                                                    self.sqrt_alphas_cumprod_prev[t], size=b)).to(x_start.device)
-        noise = torch.randn_like(x_start) if noise is None else noise.contiguous()
-        x_noisy = self.q_sample(x_start, gamma, noise)
+        """Training objective (reference diffusion.py:222-250): sum-reduced L1/L2 between the drawn noise and
+        UNet(cat(SR, q_sample(HR)), gamma); t and the per-sample gamma come from numpy's global generator exactly as in the
+        reference, so `np.random.seed` reproduces its draws.
+
+        With autograd enabled the result is differentiable the way the reference's is - ``l = netG(data); l.sum().div(n).backward();
+        optG.step()`` (model/model.py:49-59) works unchanged with any torch optimiser - although no autograd graph exists: one
+        autograd node wraps the hand-written backward pass (training.Trainer.backward).  The fused optimiser path is
+        ``gd.trainer().optimize_parameters(data)``."""
         fn = self.denoise_fn
-        cond = x_in["SR"].contiguous() if self.conditional else None
         if not isinstance(fn, UNet):
             raise TypeError("hsidm: denoise_fn must be hsi_dmgasr_amd.sr3_modules.unet.UNet")
-        x_recon = fn.forward_pair(cond, x_noisy, gamma=gamma)
         if self.loss_type not in ("l1", "l2"):
             raise NotImplementedError()
-        return ops.loss_sum(noise, x_recon.contiguous(), self.loss_type)
+        params = list(fn.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _TrainingLoss.apply(self, x_in, noise, *params)
+        if fn.training and any(u.res_block.block2._dropout for u in fn._res_units()):
+            return self.trainer().forward_loss(x_in, noise)[0]            # value only, Dropout active like the reference's train()
+        with torch.no_grad():
+            x_start = x_in["HR"].contiguous()
+            b = x_start.shape[0]
+            t = np.random.randint(1, self.num_timesteps + 1)
+            gamma = torch.FloatTensor(np.random.uniform(self.sqrt_alphas_cumprod_prev[t - 1],
+                                                        self.sqrt_alphas_cumprod_prev[t], size=b)).to(x_start.device)
+            noise = torch.randn_like(x_start) if noise is None else noise.contiguous()
+            x_noisy = self.q_sample(x_start, gamma, noise)
+            cond = x_in["SR"].contiguous() if self.conditional else None
+            x_recon = fn.forward_pair(cond, x_noisy, gamma=gamma)
+            return ops.loss_sum(noise, x_recon.contiguous(), self.loss_type)
 
     def forward(self, x, *args, **kwargs):
         return self.p_losses(x, *args, **kwargs)

@@ -34,8 +34,9 @@ def default(val, d):
 
 def _need_eval(mod, dropout_p):
     if mod.training and dropout_p:
-        raise NotImplementedError(
-            "hsidm: the HIP path implements inference (eval mode); dropout in training mode is not built yet")
+        raise RuntimeError(
+            "hsidm: this module-level forward runs the fused inference kernels, which have no Dropout; in training mode go through "
+            "GaussianDiffusion.forward / .p_losses (differentiable) or GaussianDiffusion.trainer(), or call .eval() first")
 
 
 class _PackCache:

@@ -42,7 +42,9 @@ class Trainer:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.dropout_seed = int(dropout_seed)
         self.bucket_bytes = int(bucket_bytes)
-        self.step_count = 0
+        self.step_count = 0            # optimiser steps taken (Adam's bias correction)
+        self._iter = 0                 # training forward passes started (dropout mask key)
+        self.reducer, self._reduced, self._low_cache = None, False, {}
         self.dev = next(net.parameters()).device
         self._check_device()
         self._flatten()
@@ -87,7 +89,6 @@ class Trainer:
                 p.data = self.flat[o:o + n].view(p.shape)
                 self._off[id(p)] = o
                 self._gview[id(p)] = self.grad[o:o + n].view(p.shape)
-                p.grad = self._gview[id(p)]
         F = sum(l.weight.shape[0] for l in lins)
         dim = lins[0].weight.shape[1]
         o_w, o_b = offs[id(lins[0].weight)], offs[id(lins[0].bias)]
@@ -176,6 +177,7 @@ class Trainer:
     def repack(self):
         """Kernel-order bf16 (hi [+ lo]) weights of every convolution, forward and transposed, from the fp32 master copy."""
         T.gather_pack(self.flat, self._pack_idx, self._pack_hi, self._pack_lo)
+        self._packed_at = self._versions()
 
     def pk(self, conv):
         return self._pk[(id(conv), "fwd")]
@@ -185,7 +187,8 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------------ forward (training mode)
     def _drop_key(self):
-        return (self.dropout_seed + 0x9E3779B97F4A7C15 * (self.step_count + 1)) & 0xFFFFFFFFFFFFFFFF
+        """Philox key of the current forward pass's dropout masks (a new one per forward_loss call; backward re-derives it)."""
+        return (self.dropout_seed + 0x9E3779B97F4A7C15 * self._iter) & 0xFFFFFFFFFFFFFFFF
 
     def _block_fwd(self, blk, x0, x1, lid, film=None, res=None, out_nchw=False, p_drop=0.0):
         gn, p = blk.block[0], self.precision
@@ -317,8 +320,11 @@ class Trainer:
         net, p = self.net, self.precision
         tp = self._tape
         fconv = net.final_conv.block[3]
+        red = self._reducer()
         T.channel_sums(d_eps, p, out_c=self.G(fconv.bias), cout=fconv.bias.shape[0])
         d, _ = self._block_bwd(net.final_conv, tp["final"], d_eps)
+        if red is not None:
+            red.ready(self._low(net.final_conv))
         dfilms = [None] * tp["n_units"]
         skip_grads = []                   # gradients of the encoder outputs, in the order the decoder consumed them
         tape = tp["tape"]
@@ -349,24 +355,49 @@ class Trainer:
             else:                          # stem: parameters only
                 T.channel_sums(d, p, out_c=self.G(layer.bias))
                 T.conv_wgrad(ctx, None, d, self.G(layer.weight), p)
-            self._after_layer(i)
+            # the flat gradient buffer follows the module order and the backward pass fills it from the end: every bucket
+            # above this layer's lowest offset is final and can go on the wire while the earlier layers are still computing
+            # (FiLM projections - first in the buffer - and the noise MLP are written after the loop)
+            if red is not None and kind != "stem":
+                red.ready(self._low(layer))
         assert not skip_grads
         mlp = net._mlp()
         l1, l2 = net.noise_level_mlp[1], net.noise_level_mlp[3]
         T.noise_film_bwd(tp["gamma"], tp["t_emb"], torch.cat(dfilms, dim=1).contiguous(), mlp, self._wf,
                          (self.G(l1.weight), self.G(l1.bias), self.G(l2.weight), self.G(l2.bias), self._dwf, self._dbf))
         self._tape = None
+        if red is not None:
+            red.finish()
+            self._reduced = True
 
-    def _after_layer(self, i):
-        pass                               # hook for the overlapped gradient all-reduce (parallel.GradReducer)
+    def _low(self, module):
+        """Lowest flat offset of a module's parameters: after its backward everything from there up is final."""
+        key = id(module)
+        v = self._low_cache.get(key)
+        if v is None:
+            # (the FiLM projections of a ResnetBlock live in the head of the buffer and are written last: not part of the layer's range)
+            v = min(self._off[id(p)] for p in module.parameters() if self._off[id(p)] >= self._head_floats)
+            self._low_cache[key] = v
+        return v
+
+    def _reducer(self):
+        if self.reducer is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import parallel
+            self.reducer = parallel.GradReducer(self.grad, self.bucket_bytes)
+        return self.reducer
 
     # ------------------------------------------------------------------------------------------------ the step
+    def _versions(self):
+        return sum(p._version for p in self._params)
+
     @torch.no_grad()
-    def loss_and_grads(self, x_in, noise=None, t=None, gamma=None):
-        """p_losses (diffusion.py:222-250) and its gradient.  Returns l_pix = sum-loss / (b*c*h*w) (model/model.py:53-54) as a
-        0-dim device tensor; gradients of l_pix are left in the flat gradient buffer (``Trainer.grad`` / ``p.grad``).
-        t / gamma are drawn from numpy's global generator exactly as the reference does unless given."""
-        gd, p = self.gd, self.precision
+    def forward_loss(self, x_in, noise=None, t=None, gamma=None):
+        """p_losses (diffusion.py:222-250) in training mode: the SUM-reduced loss as a 0-dim device tensor and the state
+        backward_loss needs.  t / gamma are drawn from numpy's global generator exactly as the reference does unless given."""
+        gd = self.gd
+        self._iter += 1
+        if self._versions() != self._packed_at:        # someone else (a torch optimiser, load_state_dict) changed the weights
+            self.repack()
         x_start = x_in["HR"].contiguous()
         b, c, h, w = x_start.shape
         if gamma is None:
@@ -378,19 +409,35 @@ class Trainer:
         x_noisy = gd.q_sample(x_start, gamma, noise)
         cond = x_in["SR"].contiguous() if gd.conditional else None
         eps = self.forward(cond, x_noisy, gamma)
-        scale = 1.0 / float(b * c * h * w)
-        loss = ops.loss_sum(noise, eps, gd.loss_type) * scale
-        self.backward(T.loss_grad(noise, eps, gd.loss_type, scale, p))
-        return loss
+        return ops.loss_sum(noise, eps, gd.loss_type), (noise, eps, b * c * h * w)
+
+    @torch.no_grad()
+    def backward_loss(self, state, scale):
+        """Gradient of scale * (sum-reduced loss) into the flat gradient buffer."""
+        noise, eps, _ = state
+        self.backward(T.loss_grad(noise, eps, self.gd.loss_type, scale, self.precision))
+
+    @torch.no_grad()
+    def loss_and_grads(self, x_in, noise=None, t=None, gamma=None):
+        """l_pix = sum-loss / (b*c*h*w) (model/model.py:53-54) as a 0-dim device tensor; its gradient is left in the flat gradient
+        buffer (``Trainer.grad`` / ``p.grad``)."""
+        loss, state = self.forward_loss(x_in, noise, t, gamma)
+        scale = 1.0 / float(state[2])
+        self.backward_loss(state, scale)
+        for p in self._params:              # (not before: autograd would ACCUMULATE into a pre-set .grad on the differentiable path)
+            if p.grad is not self._gview[id(p)]:
+                p.grad = self._gview[id(p)]
+        return loss * scale
 
     @torch.no_grad()
     def optimizer_step(self):
         """Adam over the flat buffers (after averaging the gradients over the ranks of the default process group), then
         one gather launch re-packs the kernel weights."""
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1:
+        if world > 1 and not self._reduced:
             from . import parallel
             parallel.allreduce_grads_(self.grad, self.bucket_bytes)
+        self._reduced = False
         self.step_count += 1
         T.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world)
         # the kernel wrote through raw pointers: tell torch (and the inference path's packed-weight caches, which key on it)

@@ -20,7 +20,7 @@ from . import philox, sr3_unet
 
 
 def drop_key(dropout_seed, step_count):
-    """Philox key of the dropout masks of optimiser step `step_count` (0-based), as training.Trainer._drop_key."""
+    """Philox key of the dropout masks of the `step_count`-th (0-based) training forward pass, as training.Trainer._drop_key."""
     return (int(dropout_seed) + 0x9E3779B97F4A7C15 * (int(step_count) + 1)) & 0xFFFFFFFFFFFFFFFF
 
 

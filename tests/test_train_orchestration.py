@@ -120,3 +120,124 @@ def test_pack_maps_reproduce_the_inference_packing():
                 refd = ops.PackedConv(wt, None, prec)
                 gd_ = tr.dpk(conv)
                 assert torch.equal(gd_.w_hi, refd.w_hi) and (refd.w_v2 is None or torch.equal(gd_.w_v2, refd.w_v2))
+
+
+def test_reference_training_loop_runs_unchanged_with_a_torch_optimiser(monkeypatch):
+    """model/model.py:49-59 verbatim - optG.zero_grad(); l_pix = netG(data); l_pix = l_pix.sum() / n; l_pix.backward(); optG.step() -
+    with torch.optim.Adam over the module's parameters: one autograd node wraps the hand-written backward pass.  Two steps, dropout
+    on, t / gamma drawn from numpy as the reference draws them; against torch.optim.Adam driven by the oracle's gradients."""
+    from hsi_dmgasr_amd import training
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import train as otrain
+    cpu_double.install(monkeypatch)
+    monkeypatch.setattr(training.Trainer, "_check_device", lambda self: None)
+    cfg = CFGS["tiny"]
+    u = unet.UNet(dropout=0.2, precision="fp32", **cfg)
+    sd = fill_synth(u, "unet_tiny.")
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, loss_type="l1", conditional=True)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), "cpu")
+    gd.train()
+    optG = torch.optim.Adam(list(gd.parameters()), lr=1e-3)                    # model/model.py:37-41
+    hr, sr, noise = (torch.from_numpy(synth_tensor("orch.%s" % n, (2, 3, 16, 16))) for n in ("hr", "sr", "noise"))
+    data = {"HR": hr, "SR": sr}
+    gammas = []
+    for step in range(2):
+        np.random.seed(100 + step)
+        t = np.random.randint(1, gd.num_timesteps + 1)
+        gammas.append(torch.FloatTensor(np.random.uniform(gd.sqrt_alphas_cumprod_prev[t - 1], gd.sqrt_alphas_cumprod_prev[t], size=2)))
+        np.random.seed(100 + step)
+        optG.zero_grad()
+        l_pix = gd(data, noise=noise)
+        b, c, h, w = hr.shape
+        l_pix = l_pix.sum() / int(b * c * h * w)
+        l_pix.backward()
+        optG.step()
+        if step == 0:
+            want_loss = otrain.l_pix(sd, cfg, hr, sr, noise, gammas[0], "l1", 0.2, otrain.drop_key(0, 0))
+            assert abs(float(l_pix.detach()) - float(want_loss)) < 1e-4 * abs(float(want_loss))
+    want = otrain.adam_steps(sd, lambda s, ps: otrain.loss_and_grads(ps, cfg, hr, sr, noise, gammas[s], "l1", 0.2, otrain.drop_key(0, s))[1],
+                             2, lr=1e-3)
+    g0 = otrain.loss_and_grads(sd, cfg, hr, sr, noise, gammas[0], "l1", 0.2, otrain.drop_key(0, 0))[1]
+    scale = max(float(g.norm()) for g in g0.values())
+    checked = 0
+    for name, p in u.named_parameters():
+        if float(g0[name].norm()) < 1e-4 * scale:
+            continue
+        moved = float((want[name] - sd[name]).norm())
+        assert float((p.detach() - want[name]).norm()) < 2e-2 * moved + 1e-7, name
+        checked += 1
+    assert checked > 100
+    # evaluation in train() mode under no_grad: a value with Dropout active; eval(): the fused inference kernels' value
+    with torch.no_grad():
+        assert gd(data, noise=noise).ndim == 0
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import pytest as _pytest
+    import cpu_double as cd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    mp_ = _pytest.MonkeyPatch()
+    cd.install(mp_)
+    cfg, sd, gd, tr = build("tiny", "l1", True)
+    tr.bucket_bytes = 256 << 10                     # several buckets: exercises the overlap bookkeeping
+    hr, sr, noise = (torch.from_numpy(synth_tensor("ddp.r%d.%s" % (rank, n), (2, 3, 16, 16))) for n in ("hr", "sr", "noise"))
+    gamma = torch.tensor([0.7, 0.25]) - 0.1 * rank
+    loss = tr.optimize_parameters({"HR": hr, "SR": sr}, noise=noise, gamma=gamma)
+    fired = len(tr.reducer.buckets)
+    torch.save({"flat": tr.flat.clone(), "loss": float(loss), "buckets": fired}, os.path.join(out_dir, "r%d.pt" % rank))
+    mp_.undo()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_training_step_on_gloo(tmp_path):
+    """BASELINE configs[4] on two CPU ranks (gloo, kernel doubles): every rank computes gradients on its own data, the bucketed
+    all-reduce (parallel.GradReducer, launched from inside the backward pass) sums them, Adam applies their mean: both ranks end
+    with identical parameters, equal to torch.optim.Adam on the oracle's averaged gradients."""
+    import os
+    import torch.multiprocessing as mp
+    from oracle import train as otrain
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["flat"], r1["flat"]) and r0["buckets"] > 3
+    cfg = CFGS["tiny"]
+    from helpers import synth_sd
+    from oracle import sr3_unet
+    sd = synth_sd(sr3_unet.unet_param_shapes(cfg), "unet_tiny.")
+    gs = []
+    for rank in range(2):
+        hr, sr, noise = (torch.from_numpy(synth_tensor("ddp.r%d.%s" % (rank, n), (2, 3, 16, 16))) for n in ("hr", "sr", "noise"))
+        gs.append(otrain.loss_and_grads(sd, cfg, hr, sr, noise, torch.tensor([0.7, 0.25]) - 0.1 * rank, "l1", 0.2, otrain.drop_key(9, 0)))
+    assert abs(r0["loss"] - gs[0][0]) < 1e-4 * abs(gs[0][0]) and abs(r1["loss"] - gs[1][0]) < 1e-4 * abs(gs[1][0])
+    mean = {k: 0.5 * (gs[0][1][k] + gs[1][1][k]) for k in sd}
+    want = otrain.adam_steps(sd, lambda s, ps: mean, 1, lr=1e-3)
+    # rebuild the name -> flat offset map the workers used
+    cfg2, sd2, gd2, tr2 = None, None, None, None
+    import cpu_double as cd
+    mp_ = pytest.MonkeyPatch()
+    cd.install(mp_)
+    try:
+        _, _, _, tr = build("tiny", "l1", True)
+    finally:
+        mp_.undo()
+    scale = max(float(g.norm()) for g in mean.values())
+    checked = 0
+    for name, p in tr.net.named_parameters():
+        if float(mean[name].norm()) < 1e-4 * scale:
+            continue
+        o = tr._off[id(p)]
+        got = r0["flat"][o:o + p.numel()].view(p.shape)
+        moved = float((want[name] - sd[name]).norm())
+        assert float((got - want[name]).norm()) < 2e-2 * moved + 1e-7, name
+        checked += 1
+    assert checked > 100
