@@ -232,6 +232,19 @@ def train_bench(dev, batch=4, steps=10, warm=3, precisions=("bf16", "fp32"), red
                          forward_ms=t_f / steps, backward_ms=t_b / steps, optimizer_ms=t_o / steps,
                          l_pix_first=losses[0], l_pix_last=losses[-1],
                          tflops=3 * 92.35e9 * batch / (dt / steps) / 1e12)      # fwd + dgrad + wgrad ~ 3x the forward's 92.35 GFLOP per sample
+        # the same step as ONE hipGraph replay (Trainer.optimize_parameters from its third call on)
+        for _ in range(3):
+            tr.optimize_parameters(data)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.optimize_parameters(data)
+        torch.cuda.synchronize()
+        dg = time.perf_counter() - t0
+        assert bool(torch.isfinite(loss))
+        out[prec]["graph_ms_per_step"] = dg / steps * 1e3
+        out[prec]["graph_value"] = steps * batch / dg
+        out[prec]["graph_tflops"] = 3 * 92.35e9 * batch / (dg / steps) / 1e12
         del tr, gd, u
         torch.cuda.empty_cache()
     return out

@@ -64,9 +64,9 @@ SIGNATURES = {
     "hsidm_color_correction_workspace_bytes": [_i32, _i32],
     "hsidm_color_correction": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     # training step
-    "hsidm_gn_act_apply": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _u64, _u32, _vp, _vp],
+    "hsidm_gn_act_apply": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _u64, _vp, _u32, _vp, _vp],
     "hsidm_gn_act_bwd_workspace_floats": [_i32, _i32, _i32, _i32],
-    "hsidm_gn_act_bwd": [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp, _vp, _vp,
+    "hsidm_gn_act_bwd": [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u64, _vp, _u32, _i32, _vp, _vp, _vp,
                          _vp, _vp, _vp, _vp],
     "hsidm_conv_wgrad_workspace_bytes": [_i32] * 11,
     "hsidm_conv_wgrad": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
@@ -82,7 +82,7 @@ SIGNATURES = {
     "hsidm_softmax_rows": [_vp, _i64, _i32, _vp],
     "hsidm_softmax_bwd_rows": [_vp, _vp, _i64, _i32, _f32, _vp],
     "hsidm_gather_pack": [_vp, _vp, _i64, _vp, _vp, _vp],
-    "hsidm_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+    "hsidm_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp],
 }
 RESTYPE_I64 = {"hsidm_conv_wgrad_workspace_bytes"}
 

@@ -34,7 +34,9 @@ __device__ __forceinline__ void dropout8(uint64_t e0, uint32_t layer, uint64_t s
     f[6] = r1.z >= thresh ? inv_keep : 0.f; f[7] = r1.w >= thresh ? inv_keep : 0.f;
 }
 
-struct DropArgs { uint64_t seed; uint32_t layer; uint32_t thresh; float inv_keep; };
+// seed_ptr != NULL: the key is read from device memory (a captured training step is replayed with a new key per iteration)
+struct DropArgs { uint64_t seed; const uint64_t* seed_ptr; uint32_t layer; uint32_t thresh; float inv_keep; };
+__device__ __forceinline__ uint64_t drop_key(const DropArgs& d) { return d.seed_ptr ? *d.seed_ptr : d.seed; }
 
 // ---- forward: a = dropout(act(scale*x + shift)) ---------------------------------------------------------------------
 template <typename T>
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void gn_act_apply_kernel(const T* __restrict__
         }
         if (dr.thresh) {
             float f[8];
-            dropout8((uint64_t)bp * C + c, dr.layer, dr.seed, dr.thresh, dr.inv_keep, f);
+            dropout8((uint64_t)bp * C + c, dr.layer, drop_key(dr), dr.thresh, dr.inv_keep, f);
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] *= f[k];
         }
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_reduce_kernel(const T* __restr
             Vec8<T>::load(da + bp * C + c, g);
 #pragma unroll
             for (int k = 0; k < 8; ++k) u[k] = fmaf(x[k], sc[k], sh[k]);
-            if (dr.thresh) dropout8((uint64_t)bp * C + c, dr.layer, dr.seed, dr.thresh, dr.inv_keep, f);
+            if (dr.thresh) dropout8((uint64_t)bp * C + c, dr.layer, drop_key(dr), dr.thresh, dr.inv_keep, f);
             dy8(g, u, silu_on, dr.thresh != 0, f, dy);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_apply_kernel(const T* __restri
             sc[k] = p.x;
             u[k] = fmaf(x[k], p.x, p.y);
         }
-        if (dr.thresh) dropout8((uint64_t)bp * C + c, dr.layer, dr.seed, dr.thresh, dr.inv_keep, f);
+        if (dr.thresh) dropout8((uint64_t)bp * C + c, dr.layer, drop_key(dr), dr.thresh, dr.inv_keep, f);
         dy8(g, u, silu_on, dr.thresh != 0, f, dy);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -405,7 +407,8 @@ __global__ __launch_bounds__(256) void noise_mlp_bwd_kernel(const float* __restr
 // ---- Adam (torch.optim.Adam, no weight decay / amsgrad; model/model.py:37-41) -------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float beta1, float beta2, float step_size,
-                                                   float inv_sqrt_bc2, float eps, float grad_scale) {
+                                                   float inv_sqrt_bc2, float eps, float grad_scale, const float* __restrict__ coef) {
+    if (coef) { step_size = coef[0]; inv_sqrt_bc2 = coef[1]; }      // a captured step: the bias corrections come from device memory
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
@@ -431,14 +434,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 // ---- packed weights from the flat fp32 master copy: out_hi[i] = bf16(src[idx[i]]), out_lo[i] = bf16(src[idx[i]] - hi) ----------------
-__global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t n,
+// n % 8 == 0: a thread packs 8 consecutive outputs (32 bytes of indices in, 16 bytes of bf16 out)
+__global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t n8,
                                                           bf16* __restrict__ hi, bf16* __restrict__ lo) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int32_t k = idx[i];
-        const float w = k >= 0 ? src[k] : 0.f;
-        const bf16 h = (bf16)w;
-        hi[i] = h;
-        if (lo) lo[i] = (bf16)(w - (float)h);
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const i32x4 k0 = reinterpret_cast<const i32x4*>(idx)[2 * i], k1 = reinterpret_cast<const i32x4*>(idx)[2 * i + 1];
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = k0[j] >= 0 ? src[k0[j]] : 0.f; w[4 + j] = k1[j] >= 0 ? src[k1[j]] : 0.f; }
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[j] = (bf16)w[j]; l[j] = (bf16)(w[j] - (float)h[j]); }
+        reinterpret_cast<bf16x8*>(hi)[i] = h;
+        if (lo) reinterpret_cast<bf16x8*>(lo)[i] = l;
     }
 }
 
@@ -447,9 +456,9 @@ static inline int grid_for(int64_t n_items) {
     const int64_t cap = (int64_t)device_cus() * 16;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
-static inline DropArgs drop_args(float p_drop, uint64_t seed, uint32_t layer) {
+static inline DropArgs drop_args(float p_drop, uint64_t seed, const void* seed_dev, uint32_t layer) {
     DropArgs d;
-    d.seed = seed; d.layer = layer;
+    d.seed = seed; d.seed_ptr = reinterpret_cast<const uint64_t*>(seed_dev); d.layer = layer;
     // keep iff word >= thresh: P(keep) = 1 - thresh / 2^32
     const double th = (double)p_drop * 4294967296.0;
     d.thresh = p_drop > 0.f ? (uint32_t)(th > 4294967295.0 ? 4294967295.0 : th) : 0u;
@@ -471,12 +480,12 @@ static bool cat_ok(const void* s0, const void* s1, int C0, int C1) {
 }
 
 extern "C" int hsidm_gn_act_apply(int prec, const void* src0, const void* src1, int C0, int C1, const float* gn_ab, int transform,
-                                  int B, int HW, float p_drop, uint64_t seed, uint32_t layer, void* out, void* stream) {
+                                  int B, int HW, float p_drop, uint64_t seed, const void* seed_dev, uint32_t layer, void* out, void* stream) {
     if (!cat_ok(src0, src1, C0, C1) || !gn_ab || !out || B <= 0 || HW <= 0 || p_drop < 0.f || p_drop >= 1.f) return HSIDM_E_BADARG;
     if (transform != HSIDM_XF_AFFINE && transform != HSIDM_XF_AFFINE_SILU) return HSIDM_E_BADARG;
     const int C = C0 + C1;
     const int64_t nvec = (int64_t)B * HW * (C >> 3);
-    const DropArgs dr = drop_args(p_drop, seed, layer);
+    const DropArgs dr = drop_args(p_drop, seed, seed_dev, layer);
     hipStream_t s = (hipStream_t)stream;
 #define ARGS(T) dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)src0, (const T*)src1, C0, C1, (const float2*)gn_ab, \
                 (int)(transform == HSIDM_XF_AFFINE_SILU), HW, nvec, dr, (T*)out
@@ -494,7 +503,7 @@ extern "C" int hsidm_gn_act_bwd_workspace_floats(int B, int C, int groups, int n
 
 extern "C" int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, const void* src1, int C0, int C1, const float* gn_ab,
                                 const float* gamma, int groups, int transform, int B, int HW, float p_drop, uint64_t seed,
-                                uint32_t layer, int nsplit, float* workspace, float* dgamma, float* dbeta, const void* add,
+                                const void* seed_dev, uint32_t layer, int nsplit, float* workspace, float* dgamma, float* dbeta, const void* add,
                                 void* dx0, void* dx1, void* stream) {
     if (!cat_ok(src0, src1, C0, C1) || !da || !gn_ab || !gamma || !workspace || !dgamma || !dbeta || !dx0 || B <= 0 || HW <= 0 ||
         groups <= 0 || nsplit <= 0 || p_drop < 0.f || p_drop >= 1.f) return HSIDM_E_BADARG;
@@ -502,7 +511,7 @@ extern "C" int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, cons
     const int C = C0 + C1;
     if (C % groups || (C1 > 0 && !dx1)) return HSIDM_E_BADARG;
     const int silu_on = transform == HSIDM_XF_AFFINE_SILU;
-    const DropArgs dr = drop_args(p_drop, seed, layer);
+    const DropArgs dr = drop_args(p_drop, seed, seed_dev, layer);
     const float2* ab = (const float2*)gn_ab;
     const float2* mr = (const float2*)(gn_ab + (size_t)4 * B * C);          // (mean, rstd) part of the table (hsidm_gn_finalize)
     float2* part = (float2*)workspace;
@@ -597,16 +606,17 @@ extern "C" int hsidm_noise_film_bwd(const float* gamma, const float* t_emb, cons
 }
 
 extern "C" int hsidm_gather_pack(const float* src, const int32_t* idx, int64_t n, void* out_hi, void* out_lo, void* stream) {
-    if (!src || !idx || !out_hi || n <= 0) return HSIDM_E_BADARG;
-    hipLaunchKernelGGL(gather_pack_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, idx, n, (bf16*)out_hi, (bf16*)out_lo);
+    if (!src || !idx || !out_hi || n <= 0 || (n & 7)) return HSIDM_E_BADARG;
+    hipLaunchKernelGGL(gather_pack_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, src, idx, n >> 3, (bf16*)out_hi, (bf16*)out_lo);
     return (int)hipGetLastError();
 }
 
 extern "C" int hsidm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                               int step, float grad_scale, void* stream) {
-    if (!p || !g || !m || !v || n <= 0 || step <= 0) return HSIDM_E_BADARG;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+                               int step, float grad_scale, const float* coef_dev, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || (step <= 0 && !coef_dev)) return HSIDM_E_BADARG;
+    const int st = step > 0 ? step : 1;
+    const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale, coef_dev);
     return (int)hipGetLastError();
 }

@@ -180,16 +180,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
-// dw[co][ci][tap] = sum over splits (in order) of ws[split][tap][co][ci]
+// dw[co][ci][tap] = sum over splits (in a fixed order) of ws[split][tap][co][ci].
+// A workgroup owns 64 consecutive (co, ci) pairs: thread (pair, q) sums the splits s = q, q + 4, ... of every tap (consecutive
+// threads = consecutive ci: coalesced reads), the four partial sums meet in LDS in the order q = 0..3, and the 64 x NT results
+// leave as one contiguous run of the PyTorch layout (coalesced writes).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
                                                            int Cout_w, int Cin_w, float* __restrict__ dw) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)Cout_w * Cin_w) return;
-    const int co = (int)(i / Cin_w), ci = (int)(i % Cin_w);
-    for (int t = 0; t < NT; ++t) {
-        float a = 0.f;
-        for (int s = 0; s < nsplit; ++s) a += ws[((size_t)(s * NT + t) * Cout_pad + co) * Cin_pad + ci];
-        dw[i * NT + t] = a;
+    __shared__ float sm[4][64][10];
+    const int pair = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t npairs = (int64_t)Cout_w * Cin_w;
+    const int64_t i = (int64_t)blockIdx.x * 64 + pair;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (i < npairs) {
+        const int co = (int)(i / Cin_w), ci = (int)(i % Cin_w);
+        const size_t plane = (size_t)Cout_pad * Cin_pad;
+        const float* src = ws + (size_t)co * Cin_pad + ci;
+        for (int s = q; s < nsplit; s += 4) {
+            const float* ps = src + (size_t)s * NT * plane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (t < NT) acc[t] += ps[(size_t)t * plane];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sm[q][pair][t] = acc[t];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * 64 * NT, total = npairs * NT;
+    for (int e = threadIdx.x; e < 64 * NT; e += 256) {
+        if (base + e < total) {
+            const int pr = e / NT, t = e - pr * NT;
+            dw[base + e] = ((sm[0][pr][t] + sm[1][pr][t]) + sm[2][pr][t]) + sm[3][pr][t];
+        }
     }
 }
 
@@ -220,8 +243,8 @@ static int wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wou
     const size_t per_split = (size_t)pl.NT * pl.Cout_pad * pl.Cin_pad * sizeof(float);
     const size_t cap = (size_t)64 << 20;                              // partial sums are written and read once each
     if ((size_t)ns * per_split > cap) ns = (int)(cap / per_split);
-    if (ns > pl.ksteps) ns = pl.ksteps;
-    if (ns < 1) ns = 1;
+    if (ns > pl.ksteps / 4) ns = pl.ksteps / 4;                      // at least four pixel tiles per workgroup: the partial tile it
+    if (ns < 1) ns = 1;                                               // writes (147 KB with 9 taps) must not outweigh what it computes
     const int per = (pl.ksteps + ns - 1) / ns;
     pl.nsplit = (pl.ksteps + per - 1) / per;                          // no empty split
     pl.ws_bytes = (size_t)pl.nsplit * per_split;
@@ -280,7 +303,7 @@ extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0
     else return HSIDM_E_BADARG;
     if (e) return e;
     const int64_t n = (int64_t)Cout_w * Cin_w;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
                        pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw);
     return (int)hipGetLastError();
 }

@@ -275,11 +275,12 @@ def gn_table(scale_shift):
     return torch.cat([ss.reshape(-1), packed.view(torch.float32), scaled.view(torch.float32)]).contiguous()
 
 
-def channel_partials(x, precision):
+def channel_partials(x, precision, nsplit=None):
     """Per-(image, split, channel) (sum, sumsq) of an NHWC tensor: [B, nsplit, C, 2]."""
     B, H, W, Cc = x.shape
     HW = H * W
-    nsplit = max(1, min(32, HW // 512))
+    if nsplit is None:
+        nsplit = max(1, min(32, HW // 512))
     part = torch.empty((B, nsplit, Cc, 2), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().hsidm_gn_partial(_lib.prec_id(precision), _lib.ptr(x), None, Cc, 0, B, HW, nsplit,
                                            _lib.ptr(part), _lib.stream_ptr()), "gn_partial")

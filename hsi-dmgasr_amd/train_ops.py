@@ -10,13 +10,21 @@ def _check(code, what):
     _lib.check(code, what)
 
 
+def _seed_args(seed):
+    """seed: a Python int (kernel argument) or a device int64 tensor holding the key (captured steps)."""
+    if torch.is_tensor(seed):
+        return 0, _lib.ptr(seed)
+    return int(seed), None
+
+
 def gn_act_apply(x0, x1, gn_ab, silu, precision, p_drop=0.0, seed=0, layer=0):
     """a = dropout(act(GroupNorm(cat(x0, x1)))) materialised (NHWC [B, H, W, C0+C1])."""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     out = torch.empty((B, H, W, C0 + C1), dtype=x0.dtype, device=x0.device)
+    sv, sp = _seed_args(seed)
     _check(_lib.lib().hsidm_gn_act_apply(_lib.prec_id(precision), _lib.ptr(x0), _lib.ptr(x1), C0, C1, _lib.ptr(gn_ab),
-                                         ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE, B, H * W, float(p_drop), int(seed), int(layer),
+                                         ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE, B, H * W, float(p_drop), sv, sp, int(layer),
                                          _lib.ptr(out), _lib.stream_ptr()), "gn_act_apply")
     return out
 
@@ -27,17 +35,24 @@ def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta,
     C1 = 0 if x1 is None else x1.shape[3]
     C = C0 + C1
     HW = H * W
-    nsplit = max(1, min(32, HW // 512))
+    nsplit = _nsplit(B, HW)
     L = _lib.lib()
     ws = torch.empty(L.hsidm_gn_act_bwd_workspace_floats(B, C, groups, nsplit), dtype=torch.float32, device=x0.device)
     dx0 = torch.empty_like(x0)
     dx1 = None if x1 is None else torch.empty_like(x1)
     assert da.shape == (B, H, W, C) and (add is None or add.shape == da.shape)
+    sv, sp = _seed_args(seed)
     _check(L.hsidm_gn_act_bwd(_lib.prec_id(precision), _lib.ptr(da), _lib.ptr(x0), _lib.ptr(x1), C0, C1, _lib.ptr(gn_ab), _lib.ptr(gamma),
-                              groups, ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE, B, HW, float(p_drop), int(seed), int(layer), nsplit,
+                              groups, ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE, B, HW, float(p_drop), sv, sp, int(layer), nsplit,
                               _lib.ptr(ws), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(add), _lib.ptr(dx0), _lib.ptr(dx1),
                               _lib.stream_ptr()), "gn_act_bwd")
     return dx0, dx1
+
+
+def _nsplit(B, HW):
+    """Pixel ranges per image for the streaming reductions: about four workgroups per CU over the batch (training batches are
+    small: 4 latents per GPU in the reference, sr_gae.py:182), at least 64 pixels each."""
+    return max(1, min(HW // 64, (1024 + B - 1) // B))
 
 
 _ws_cache = {}
@@ -96,7 +111,7 @@ def channel_sums(x, precision, out_c=None, want_bc=False, cout=None):
     per-image sums [B, cout]."""
     B, H, W, C = x.shape
     cout = C if cout is None else cout
-    part, nsplit = ops.channel_partials(x, precision)
+    part, nsplit = ops.channel_partials(x, precision, nsplit=_nsplit(B, H * W))
     bc = torch.empty((B, cout), dtype=torch.float32, device=x.device) if want_bc else None
     _check(_lib.lib().hsidm_colsum(_lib.ptr(part), nsplit, B, C, cout, _lib.ptr(bc), _lib.ptr(out_c), _lib.stream_ptr()), "colsum")
     return bc
@@ -160,6 +175,12 @@ def gather_pack(src, idx, out_hi, out_lo=None):
            "gather_pack")
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def adam_coefs(lr, beta1, beta2, step):
+    """(lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)): what hsidm_adam_step derives from `step`, for the device-resident form."""
+    return float(lr / (1.0 - beta1 ** step)), float(1.0 / (1.0 - beta2 ** step) ** 0.5)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, coef=None):
+    """coef: optional device tensor of two floats (adam_coefs) read by the kernel instead of deriving them from `step`."""
     _check(_lib.lib().hsidm_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
-                                      float(eps), int(step), float(grad_scale), _lib.stream_ptr()), "adam_step")
+                                      float(eps), int(step), float(grad_scale), _lib.ptr(coef), _lib.stream_ptr()), "adam_step")

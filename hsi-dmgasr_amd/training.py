@@ -45,6 +45,7 @@ class Trainer:
         self.step_count = 0            # optimiser steps taken (Adam's bias correction)
         self._iter = 0                 # training forward passes started (dropout mask key)
         self.reducer, self._reduced, self._low_cache = None, False, {}
+        self._g, self._g_active, self._g_calls = None, False, 0      # captured step (optimize_parameters): state, capturing/replaying, calls
         self.dev = next(net.parameters()).device
         self._check_device()
         self._flatten()
@@ -186,9 +187,13 @@ class Trainer:
         return self._pk[(id(conv), "dgrad")]
 
     # ------------------------------------------------------------------------------------------------ forward (training mode)
-    def _drop_key(self):
-        """Philox key of the current forward pass's dropout masks (a new one per forward_loss call; backward re-derives it)."""
+    def _drop_key_value(self):
         return (self.dropout_seed + 0x9E3779B97F4A7C15 * self._iter) & 0xFFFFFFFFFFFFFFFF
+
+    def _drop_key(self):
+        """Philox key of the current forward pass's dropout masks (a new one per forward_loss call; backward re-derives it):
+        a Python int, or - inside a captured step - the device word the host refreshes before every replay."""
+        return self._g["key"] if self._g_active else self._drop_key_value()
 
     def _block_fwd(self, blk, x0, x1, lid, film=None, res=None, out_nchw=False, p_drop=0.0):
         gn, p = blk.block[0], self.precision
@@ -444,8 +449,94 @@ class Trainer:
         torch.autograd.graph.increment_version(self._params)
         self.repack()
 
-    def optimize_parameters(self, data, **kw):
-        """model/model.py:49-59.  -> l_pix (0-dim device tensor; the reference logs .item())."""
-        loss = self.loss_and_grads(data, **kw)
-        self.optimizer_step()
+    def optimize_parameters(self, data, use_graph=True, **kw):
+        """model/model.py:49-59.  -> l_pix (0-dim device tensor; the reference logs .item()).
+
+        use_graph (and no injected noise / t / gamma, one rank): from the third call on the whole step - forward, backward,
+        Adam, re-pack: ~1 500 launches - is ONE hipGraph replay.  What changes per iteration lives in device memory the host
+        refreshes before the replay: the batch, the drawn noise levels, the dropout key and Adam's bias corrections; the noise
+        comes from torch's graph-safe generator."""
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if kw or not use_graph or world > 1 or self.dev.type != "cuda":
+            loss = self.loss_and_grads(data, **kw)
+            self.optimizer_step()
+            return loss
+        return self._graphed_step(data)
+
+    def _host_draws(self, b):
+        """(t, gamma) exactly as diffusion.py:226-234 draws them."""
+        gd = self.gd
+        t = np.random.randint(1, gd.num_timesteps + 1)
+        return np.random.uniform(gd.sqrt_alphas_cumprod_prev[t - 1], gd.sqrt_alphas_cumprod_prev[t], size=b).astype(np.float32)
+
+    @torch.no_grad()
+    def _graphed_step(self, data):
+        hr, sr = data["HR"], data.get("SR")
+        b = hr.shape[0]
+        shape_key = (tuple(hr.shape), None if sr is None else tuple(sr.shape))
+        if self._g is not None and self._g["shape"] != shape_key:
+            self._g, self._g_calls = None, 0                    # another batch shape: capture again
+        self._g_calls += 1
+        if self._g_calls == 1:                                  # eager: sizes every cache (workspaces, LDS caps, offsets)
+            loss = self.loss_and_grads(data)
+            self.optimizer_step()
+            return loss
+        if self._g is None:
+            g = dict(shape=shape_key, hr=hr.clone(), sr=None if sr is None else sr.clone(),
+                     gamma=torch.zeros(b, dtype=torch.float32, device=self.dev), key=torch.zeros(1, dtype=torch.int64, device=self.dev),
+                     coef=torch.zeros(2, dtype=torch.float32, device=self.dev),
+                     h_gamma=torch.zeros(b, dtype=torch.float32).pin_memory(), h_key=torch.zeros(1, dtype=torch.int64).pin_memory(),
+                     h_coef=torch.zeros(2, dtype=torch.float32).pin_memory(), graph=None, loss=None)
+            self._g = g
+        g = self._g
+        # ---- host side of the iteration: draws, counters, staging copies (stream-ordered ahead of the replay)
+        if g.get("ev") is not None:
+            g["ev"].synchronize()              # the previous call's staging copies have left the pinned buffers
+        self._iter += 1
+        self.step_count += 1
+        g["h_gamma"].copy_(torch.from_numpy(self._host_draws(b)))
+        key = self._drop_key_value()
+        g["h_key"][0] = key - (1 << 64) if key >= (1 << 63) else key
+        c0, c1 = T.adam_coefs(self.lr, self.betas[0], self.betas[1], self.step_count)
+        g["h_coef"][0], g["h_coef"][1] = c0, c1
+        g["gamma"].copy_(g["h_gamma"], non_blocking=True)
+        g["key"].copy_(g["h_key"], non_blocking=True)
+        g["coef"].copy_(g["h_coef"], non_blocking=True)
+        g["ev"] = torch.cuda.Event()
+        g["ev"].record()
+        if g["hr"].data_ptr() != hr.data_ptr():
+            g["hr"].copy_(hr)
+        if sr is not None and g["sr"].data_ptr() != sr.data_ptr():
+            g["sr"].copy_(sr)
+        if g["graph"] is None:
+            if self._versions() != self._packed_at:
+                self.repack()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            self._g_active = True
+            try:
+                with torch.cuda.graph(graph):
+                    g["loss"] = self._captured_body(g)
+            finally:
+                self._g_active = False
+            g["graph"] = graph
+        g["graph"].replay()
+        torch.autograd.graph.increment_version(self._params)    # the replay rewrote the parameters through raw pointers
+        self._packed_at = self._versions()
+        return g["loss"]
+
+    def _captured_body(self, g):
+        """One training step with every per-iteration quantity read from device memory (recorded once, replayed)."""
+        gd = self.gd
+        x_start = g["hr"]
+        b, c, h, w = x_start.shape
+        noise = torch.randn_like(x_start)
+        g["noise"] = noise                                       # (kept for inspection: tests re-derive the step from it)
+        x_noisy = gd.q_sample(x_start, g["gamma"], noise)
+        eps = self.forward(g["sr"] if gd.conditional else None, x_noisy, g["gamma"])
+        scale = 1.0 / float(b * c * h * w)
+        loss = ops.loss_sum(noise, eps, gd.loss_type) * scale
+        self.backward(T.loss_grad(noise, eps, gd.loss_type, scale, self.precision))
+        T.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, 0, 1.0, coef=g["coef"])
+        T.gather_pack(self.flat, self._pack_idx, self._pack_hi, self._pack_lo)
         return loss

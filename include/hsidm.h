@@ -255,9 +255,11 @@ int hsidm_color_correction(const float* guide, int guide_HW, const float* x, flo
  *   out = dropout_p(act(scale[b,c] * x + shift[b,c])), x = cat(src0, src1), act = SiLU (HSIDM_XF_AFFINE_SILU) or identity
  *   (HSIDM_XF_AFFINE, the attention's GroupNorm, unet.py:127); (scale, shift) = the fp32 pairs of hsidm_gn_finalize.
  * Dropout mask: element e (flat NHWC index of out) keeps its value, scaled by 1/(1-p), iff word (e & 3) of
- * Philox4x32-10(key = seed, counter = (e >> 2, 0, layer, 0)) >= p * 2^32; p_drop = 0 disables it. */
+ * Philox4x32-10(key = seed, counter = (e >> 2, 0, layer, 0)) >= p * 2^32; p_drop = 0 disables it.  seed_dev != NULL: the key is
+ * the uint64 at that device address instead of `seed` (a training step captured into a hipGraph is replayed with a new key per
+ * iteration). */
 int hsidm_gn_act_apply(int prec, const void* src0, const void* src1, int C0, int C1, const float* gn_ab, int transform,
-                       int B, int HW, float p_drop, uint64_t seed, uint32_t layer, void* out, void* stream);
+                       int B, int HW, float p_drop, uint64_t seed, const void* seed_dev, uint32_t layer, void* out, void* stream);
 /* Backward of hsidm_gn_act_apply including the GroupNorm statistics (nn.GroupNorm backward):
  *   dy = da * dropout' * act'(u);  dgamma[c] = sum dy * xhat;  dbeta[c] = sum dy;
  *   dx = rstd * (gamma * dy - mean_g(gamma * dy) - xhat * mean_g(gamma * dy * xhat))  (+ add [B][HW][C0+C1]: gradients that reach x
@@ -267,8 +269,8 @@ int hsidm_gn_act_apply(int prec, const void* src0, const void* src1, int C0, int
  * workspace: hsidm_gn_act_bwd_workspace_floats(B, C0+C1, groups, nsplit) floats. */
 int hsidm_gn_act_bwd_workspace_floats(int B, int C, int groups, int nsplit);
 int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, const void* src1, int C0, int C1, const float* gn_ab,
-                     const float* gamma, int groups, int transform, int B, int HW, float p_drop, uint64_t seed, uint32_t layer,
-                     int nsplit, float* workspace, float* dgamma, float* dbeta, const void* add, void* dx0, void* dx1,
+                     const float* gamma, int groups, int transform, int B, int HW, float p_drop, uint64_t seed, const void* seed_dev,
+                     uint32_t layer, int nsplit, float* workspace, float* dgamma, float* dbeta, const void* add, void* dx0, void* dx1,
                      void* stream);
 /* Weight gradient of hsidm_conv2d's convolution: dw[co][ci][ky][kx] (fp32, PyTorch layout [Cout_w][Cin_w][k][k]) =
  *   sum_{b,y,x} dy[b][y][x][co] * a[b][s*y+ky-1][s*x+kx-1][ci], a = cat(a0, a1) NHWC [B][Hin][Win][C0+C1] (the materialised operand),
@@ -313,14 +315,15 @@ int hsidm_bgemm(const void* a, int a_f32, int64_t sab, int64_t sam, int64_t sak,
 int hsidm_softmax_rows(float* s, int64_t rows, int N, void* stream);
 int hsidm_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int N, float scale, void* stream);
 /* Packed (kernel-order) weights straight from the flat fp32 master copy: out_hi[i] = bf16(src[idx[i]]) and, when out_lo != NULL
- * (HSIDM_F32X3), out_lo[i] = bf16(src[idx[i]] - out_hi[i]); idx[i] < 0 gives a zero (padding).  idx is the packed layout's
+ * (HSIDM_F32X3), out_lo[i] = bf16(src[idx[i]] - out_hi[i]); idx[i] < 0 gives a zero (padding); n % 8 == 0.  idx is the packed layout's
  * gather map, built once on the host; one launch re-packs every convolution of the network after an optimiser step. */
 int hsidm_gather_pack(const float* src, const int32_t* idx, int64_t n, void* out_hi, void* out_lo, void* stream);
 /* One Adam step over a flat fp32 buffer (torch.optim.Adam as built in model/model.py:37-41: betas (0.9, 0.999), eps 1e-8, no
  * weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), g scaled by
- * grad_scale first (1/world size after a sum all-reduce). */
+ * grad_scale first (1/world size after a sum all-reduce).  coef_dev != NULL: (lr/(1-b1^t), 1/sqrt(1-b2^t)) are read from that
+ * device address (two floats) instead of being derived from `step` (captured steps). */
 int hsidm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                    int step, float grad_scale, void* stream);
+                    int step, float grad_scale, const float* coef_dev, void* stream);
 
 #ifdef __cplusplus
 }

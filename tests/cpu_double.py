@@ -116,9 +116,13 @@ def q_sample(x0, noise, gamma):
 
 
 # ----------------------------------------------------------------------------------------------------------- train_ops.*
+def _key(seed):
+    return int(seed.item()) & 0xFFFFFFFFFFFFFFFF if torch.is_tensor(seed) else int(seed)
+
+
 def _factor(shape_nhwc, p_drop, seed, layer):
     B, H, W, C = shape_nhwc
-    return nhwc(otrain.dropout_factor(int(seed), int(layer), (B, C, H, W), p_drop))
+    return nhwc(otrain.dropout_factor(_key(seed), int(layer), (B, C, H, W), p_drop))
 
 
 def gn_act_apply(x0, x1, gn_ab, silu, precision, p_drop=0.0, seed=0, layer=0):
@@ -143,7 +147,7 @@ def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta,
         y = F.group_norm(nchw(x), groups, gam, beta, eps=1e-5)
         a = y * torch.sigmoid(y) if silu else y
         if p_drop > 0:
-            a = a * otrain.dropout_factor(int(seed), int(layer), tuple(a.shape), p_drop)
+            a = a * otrain.dropout_factor(_key(seed), int(layer), tuple(a.shape), p_drop)
         gx, gg, gb = torch.autograd.grad(nhwc(a), [x, gam, beta], grad_outputs=da)
     dgamma.copy_(gg)
     dbeta.copy_(gb)
@@ -219,12 +223,12 @@ def gather_pack(src, idx, out_hi, out_lo=None):
         out_lo.copy_((w - hi.float()).to(torch.bfloat16))
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, coef=None):
     gg = g * grad_scale
     m.mul_(beta1).add_(gg, alpha=1 - beta1)
     v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
-    denom = v.sqrt() / math.sqrt(1 - beta2 ** step) + eps
-    p.sub_((lr / (1 - beta1 ** step)) * (m / denom))
+    step_size, inv = (float(coef[0]), float(coef[1])) if coef is not None else (lr / (1 - beta1 ** step), 1 / math.sqrt(1 - beta2 ** step))
+    p.sub_(step_size * (m / (v.sqrt() * inv + eps)))
 
 
 OPS = dict(conv2d=conv2d, gn_scale_shift=gn_scale_shift, noise_film=noise_film, to_nhwc=to_nhwc, attention=attention,

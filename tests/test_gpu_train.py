@@ -339,6 +339,49 @@ def test_optimizer_steps_against_torch_adam(dev):
     check("inference_after_training", "fp32", y, sr3_unet.unet_forward(ysd, TINY, x.cpu(), gam.cpu()), tol=1e-3)
 
 
+def test_captured_training_step_replays_correctly(dev):
+    """optimize_parameters() as one hipGraph replay (third call on): per-iteration inputs - batch, noise levels, dropout key,
+    Adam's bias corrections - come from device memory the host refreshes.  For two replayed steps: the gradients left in the
+    flat buffer against the oracle's autograd on the pre-step parameters with the noise / gamma / key that step used, and the
+    parameter update against torch.optim.Adam's."""
+    from oracle import train as otrain
+    sd, gd, tr = build(TINY, "tiny", "l1", "fp32", dev, True, lr=1e-3)
+    hr, sr = (torch.from_numpy(synth_tensor("ggraph.%s" % n, (2, 3, 16, 16))).to(dev) for n in ("hr", "sr"))
+    data = {"HR": hr, "SR": sr}
+    np.random.seed(3)
+    torch.manual_seed(3)
+    tr.optimize_parameters(data)                       # eager
+    tr.optimize_parameters(data)                       # capture + first replay
+    keys, losses = [], []
+    for it in range(2):
+        before = {k: v.detach().cpu().clone() for k, v in tr.net.state_dict().items()}
+        m0, v0 = tr.m.clone(), tr.v.clone()
+        loss = tr.optimize_parameters(data)
+        torch.cuda.synchronize()
+        assert tr._g["graph"] is not None
+        g = tr._g
+        noise, gamma = g["noise"].cpu(), g["gamma"].cpu()
+        key = int(g["key"].item()) & 0xFFFFFFFFFFFFFFFF
+        keys.append(key)
+        want_loss, grads = otrain.loss_and_grads(before, TINY, hr.cpu(), sr.cpu(), noise, gamma, "l1", 0.2, key)
+        worst, wname, total = grad_errors(tr, grads, "fp32")
+        assert abs(float(loss) - want_loss) < 1e-4 * abs(want_loss)
+        assert total < 1e-3 and worst < 5e-3, (total, worst, wname)
+        losses.append(float(loss))
+        # the update: Adam on the gradients this step left in the buffer, from the moments before it
+        step = tr.step_count
+        gg = tr.grad
+        m1 = 0.9 * m0 + 0.1 * gg
+        v1 = 0.999 * v0 + 0.001 * gg * gg
+        c0, c1 = (1e-3 / (1 - 0.9 ** step)), 1 / math.sqrt(1 - 0.999 ** step)
+        for name, p in tr.net.named_parameters():
+            o = tr._off[id(p)]
+            want = before[name].to(dev).reshape(-1) - c0 * (m1[o:o + p.numel()] / (v1[o:o + p.numel()].sqrt() * c1 + 1e-8))
+            assert float((p.detach().reshape(-1) - want).abs().max()) < 1e-6, name
+    assert keys[0] != keys[1] and tr.step_count == 4 and tr._iter == 4
+    log_err("captured_train_step_losses", "fp32", losses[-1], {"losses": losses})
+
+
 def test_full_size_training_step_gradients(dev):
     """The shipped 97.8 M-parameter UNet, one training step's gradients in fp32 mode at B = 1, 128 x 128 (BASELINE configs[4]'s
     network) against the oracle's autograd on the host; and the bf16 mode's deviation from it, logged and bounded."""
