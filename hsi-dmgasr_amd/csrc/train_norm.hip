@@ -136,17 +136,31 @@ __global__ __launch_bounds__(256) void gn_act_bwd_reduce_kernel(const T* __restr
 // ---- backward pass 2a: grid (B): S[b][c] = sum over splits; group means gm[b][g] = (sum_c gamma_c S1, sum_c gamma_c S2) / n ----
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __restrict__ part, int nsplit, int C, int HW, int groups,
                                                               const float* __restrict__ gamma, float2* __restrict__ S, float2* __restrict__ gm) {
-    extern __shared__ float sm[];          // [C][2] gamma-weighted sums
+    extern __shared__ float sm[];          // [C][2] gamma-weighted sums, then [256][2] scratch
+    float* scr = sm + 2 * C;
     const int b = blockIdx.x, t = threadIdx.x, cpg = C / groups;
-    for (int c = t; c < C; c += 256) {
-        double a = 0.0, d = 0.0;
-        for (int s = 0; s < nsplit; ++s) {
-            const float2 v = part[((size_t)b * nsplit + s) * C + c];
-            a += v.x; d += v.y;
+    // channel windows of up to 256 channels; within a window thread = (channel, split group): the splits of a channel are
+    // summed by 256 / window threads and combined through LDS in a fixed order
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = min(256, C - c0), ng = 256 / cw;
+        const int cl = t % cw, sg = t / cw;
+        float a = 0.f, d = 0.f;
+        if (sg < ng)
+            for (int s = sg; s < nsplit; s += ng) {
+                const float2 v = part[((size_t)b * nsplit + s) * C + c0 + cl];
+                a += v.x; d += v.y;
+            }
+        __syncthreads();
+        scr[2 * t] = a; scr[2 * t + 1] = d;
+        __syncthreads();
+        if (t < cw) {
+            float sa = 0.f, sd = 0.f;
+            for (int g = 0; g < ng; ++g) { sa += scr[2 * (g * cw + t)]; sd += scr[2 * (g * cw + t) + 1]; }
+            const int c = c0 + t;
+            S[(size_t)b * C + c] = make_float2(sa, sd);
+            sm[2 * c] = sa * gamma[c];
+            sm[2 * c + 1] = sd * gamma[c];
         }
-        S[(size_t)b * C + c] = make_float2((float)a, (float)d);
-        sm[2 * c] = (float)(a * gamma[c]);
-        sm[2 * c + 1] = (float)(d * gamma[c]);
     }
     __syncthreads();
     for (int g = t; g < groups; g += 256) {
@@ -274,16 +288,25 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 // ---- column sums of a statistics slab: out_bc[b][c] = sum_s part[b][s][c].x, out_c[c] = sum_b out_bc -------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float2* __restrict__ part, int nsplit, int B, int C, int Cout,
                                                      float* __restrict__ out_bc, float* __restrict__ out_c) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= Cout) return;
-    double tot = 0.0;
+    // workgroup = 64 channels x 4 split groups; the groups meet in LDS in a fixed order
+    __shared__ float scr[4][64];
+    const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float tot = 0.f;
     for (int b = 0; b < B; ++b) {
-        double a = 0.0;
-        for (int s = 0; s < nsplit; ++s) a += part[((size_t)b * nsplit + s) * C + c].x;
-        if (out_bc) out_bc[(size_t)b * Cout + c] = (float)a;
-        tot += a;
+        float a = 0.f;
+        if (c < Cout)
+            for (int s = sg; s < nsplit; s += 4) a += part[((size_t)b * nsplit + s) * C + c].x;
+        __syncthreads();
+        scr[sg][cl] = a;
+        __syncthreads();
+        if (sg == 0 && c < Cout) {
+            const float v = ((scr[0][cl] + scr[1][cl]) + scr[2][cl]) + scr[3][cl];
+            if (out_bc) out_bc[(size_t)b * Cout + c] = v;
+            tot += v;
+        }
     }
-    if (out_c) out_c[c] = (float)tot;
+    if (sg == 0 && c < Cout && out_c) out_c[c] = tot;
 }
 
 // ---- d(loss)/d(eps): loss = scale * sum |noise - eps| (L1) or scale * sum (noise - eps)^2 (L2); NCHW fp32 in, NHWC (Cpad) out ----
@@ -525,7 +548,7 @@ extern "C" int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, cons
     if (prec == HSIDM_BF16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_reduce_kernel<bf16>), RARGS(bf16));
     else if (prec == HSIDM_F32X3) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_reduce_kernel<float>), RARGS(float));
     else return HSIDM_E_BADARG;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), (size_t)2 * C * sizeof(float), s, (const float2*)part, nsplit, C, HW,
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), (size_t)(2 * C + 512) * sizeof(float), s, (const float2*)part, nsplit, C, HW,
                        groups, gamma, S, gm);
     hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2*)S, B, C, dgamma, dbeta);
     if (prec == HSIDM_BF16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_apply_kernel<bf16>), AARGS(bf16));
@@ -566,7 +589,7 @@ extern "C" int hsidm_add(int prec, const void* a, const void* b, void* out, int6
 
 extern "C" int hsidm_colsum(const float* part, int nsplit, int B, int C, int Cout, float* out_bc, float* out_c, void* stream) {
     if (!part || nsplit <= 0 || B <= 0 || C <= 0 || Cout <= 0 || Cout > C || (!out_bc && !out_c)) return HSIDM_E_BADARG;
-    hipLaunchKernelGGL(colsum_kernel, dim3((Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float2*)part, nsplit, B, C, Cout, out_bc, out_c);
+    hipLaunchKernelGGL(colsum_kernel, dim3((Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float2*)part, nsplit, B, C, Cout, out_bc, out_c);
     return (int)hipGetLastError();
 }
 
