@@ -43,6 +43,7 @@ SIGNATURES = {
     "hsidm_gn_partial": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "hsidm_gn_finalize": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "hsidm_noise_film": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "hsidm_film_affine": [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "hsidm_attention": [_i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "hsidm_nchw_to_nhwc": [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     "hsidm_nhwc_to_nchw": [_i32, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -57,6 +58,8 @@ SIGNATURES = {
     "hsidm_overlap_average": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "hsidm_hsi_metrics_workspace_bytes": [_i32, _i32, _i32],
     "hsidm_hsi_metrics": [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
+    "hsidm_hsi_mssim_workspace_bytes": [_i32, _i32, _i32, _i32],
+    "hsidm_hsi_mssim": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "hsidm_resample_axis": [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp],
     "hsidm_minmax_workspace_bytes": [_i32],
     "hsidm_minmax_normalize": [_vp, _vp, _i32, _i64, _vp, _vp],

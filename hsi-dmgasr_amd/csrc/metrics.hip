@@ -105,7 +105,61 @@ __global__ __launch_bounds__(256) void metrics_finalize_kernel(const double* __r
     }
 }
 
+// ---- MSSIM (eval_hsi.py:124-135: mean over bands of skimage.metrics.structural_similarity with its defaults: 7x7 uniform
+// window, sample covariance (n/(n-1)), K1 = 0.01, K2 = 0.03, the 3-pixel border cropped before the mean) ----------------------
+// grid (ceil((W-6)/16), ceil((H-6)/16), P*C), block 16x16: one interior pixel per thread, the 49 taps straight from L1/L2 (the whole
+// cube is a few MB); fp64 block sums -> part[(p*C + c) * nblk + block]
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ truth, const float* __restrict__ pred, int H, int W,
+                                                           float c1, float c2, double* __restrict__ part) {
+    __shared__ double red[256];
+    const int pc = blockIdx.z;
+    const float* t = truth + (size_t)pc * H * W;
+    const float* q = pred + (size_t)pc * H * W;
+    const int x = 3 + blockIdx.x * 16 + (threadIdx.x & 15), y = 3 + blockIdx.y * 16 + (threadIdx.x >> 4);
+    double sv = 0.0;
+    if (x < W - 3 && y < H - 3) {
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int dy = -3; dy <= 3; ++dy)
+#pragma unroll
+            for (int dx = -3; dx <= 3; ++dx) {
+                const float a = t[(size_t)(y + dy) * W + x + dx], b = q[(size_t)(y + dy) * W + x + dx];
+                sx += a; sy += b; sxx = fmaf(a, a, sxx); syy = fmaf(b, b, syy); sxy = fmaf(a, b, sxy);
+            }
+        const float inv = 1.0f / 49.0f, cov = 49.0f / 48.0f;
+        const float ux = sx * inv, uy = sy * inv;
+        const float vx = cov * (sxx * inv - ux * ux), vy = cov * (syy * inv - uy * uy), vxy = cov * (sxy * inv - ux * uy);
+        sv = (double)(((2.f * ux * uy + c1) * (2.f * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)));
+    }
+    const double tot = block_sum_f64(sv, red);
+    if (threadIdx.x == 0) part[((size_t)pc * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void ssim_finalize_kernel(const double* __restrict__ part, int C, int nblk, int H, int W, float* __restrict__ out) {
+    __shared__ double red[256];
+    const int p = blockIdx.x;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < C * nblk; i += 256) a += part[(size_t)p * C * nblk + i];
+    a = block_sum_f64(a, red);
+    if (threadIdx.x == 0) out[p] = (float)(a / ((double)C * (H - 6) * (W - 6)));
+}
+
 }  // namespace hsidm
+
+extern "C" int hsidm_hsi_mssim_workspace_bytes(int P, int C, int H, int W) {
+    if (P <= 0 || C <= 0 || H < 7 || W < 7) return HSIDM_E_BADARG;
+    const long long n = (long long)P * C * ((H - 6 + 15) / 16) * ((W - 6 + 15) / 16) * 8;
+    return n > 0x7fffffffLL ? HSIDM_E_UNSUPPORTED : (int)n;
+}
+
+extern "C" int hsidm_hsi_mssim(const float* truth, const float* pred, int P, int C, int H, int W, float data_range, void* workspace,
+                               float* out, void* stream) {
+    if (!truth || !pred || !workspace || !out || P <= 0 || C <= 0 || H < 7 || W < 7 || !(data_range > 0.f) || (long long)P * C > 65535) return HSIDM_E_BADARG;
+    const int gx = (W - 6 + 15) / 16, gy = (H - 6 + 15) / 16;
+    const float c1 = (0.01f * data_range) * (0.01f * data_range), c2 = (0.03f * data_range) * (0.03f * data_range);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(hsidm::ssim_partial_kernel, dim3(gx, gy, P * C), dim3(256), 0, s, truth, pred, H, W, c1, c2, (double*)workspace);
+    hipLaunchKernelGGL(hsidm::ssim_finalize_kernel, dim3(P), dim3(256), 0, s, (const double*)workspace, C, gx * gy, H, W, out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int hsidm_hsi_metrics_workspace_bytes(int P, int C, int HW) {
     if (P <= 0 || C <= 0 || HW <= 0) return HSIDM_E_BADARG;

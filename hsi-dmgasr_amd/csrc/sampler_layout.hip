@@ -174,6 +174,23 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(const ActT* __restrict__ 
     }
 }
 
+// out = (1 + gb[b][c]) * x + gb[b][C + c]: FeatureWiseAffine with use_affine_level (reference unet.py:44-47), NHWC, 8 channels per thread
+template <typename ActT>
+__global__ __launch_bounds__(256) void film_affine_kernel(const ActT* __restrict__ x, const float* __restrict__ gb, ActT* __restrict__ out,
+                                                          int HW, int C, int64_t nvec) {
+    const int nv = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % nv);
+        const int b = (int)(i / nv / HW);
+        float a[8];
+        Vec8<ActT>::load(x + i * 8, a);
+        const float* g = gb + (size_t)b * 2 * C + cv * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fmaf(1.0f + g[k], a[k], g[C + k]);
+        Vec8<ActT>::store(out + i * 8, a);
+    }
+}
+
 // y[b][c][p] = mean over the groups g covering band c of dec[b*G+g][c-start[g]][p]   (AE.py:286-295)
 __global__ __launch_bounds__(256) void overlap_average_kernel(const float* __restrict__ dec, const int32_t* __restrict__ start,
                                                               int G, int n_subs, int C, int HW, float* __restrict__ y) {
@@ -283,6 +300,19 @@ extern "C" int hsidm_ca_apply(int prec, const void* r, const float* ca, const vo
     else if (prec == HSIDM_F32X3)
         hipLaunchKernelGGL(ca_apply_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)r, ca, (const float*)skip,
                            (const float*)skip2, res_scale, (float*)out, HW, C, nvec);
+    else
+        return HSIDM_E_BADARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int hsidm_film_affine(int prec, const void* x, const float* gamma_beta, void* out, int B, int HW, int C, void* stream) {
+    if (!x || !gamma_beta || !out || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return HSIDM_E_BADARG;
+    const int64_t nvec = (int64_t)B * HW * (C >> 3);
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == HSIDM_BF16)
+        hipLaunchKernelGGL(film_affine_kernel<bf16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)x, gamma_beta, (bf16*)out, HW, C, nvec);
+    else if (prec == HSIDM_F32X3)
+        hipLaunchKernelGGL(film_affine_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)x, gamma_beta, (float*)out, HW, C, nvec);
     else
         return HSIDM_E_BADARG;
     return (int)hipGetLastError();

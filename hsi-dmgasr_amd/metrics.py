@@ -1,18 +1,20 @@
 """Quality indices of super-resolved cubes on the device (reference eval_hsi.py:27-121, used in sr_gae.py:468-474).
 
 ``quality_indices(truth, pred)`` takes the NCHW fp32 cubes the pipeline already holds on the GPU and returns one row per
-cube: MPSNR, SAM (degrees), ERGAS, CC, RMSE - the numbers the reference computes on the host with numpy (SAM as a Python
-double loop over pixels).  Kernels: csrc/metrics.hip through hsidm_hsi_metrics.
+cube: MPSNR, SAM (degrees), ERGAS, CC, RMSE, MSSIM - the indices of the reference's quality_assessment (eval_hsi.py:217-238),
+which computes them on the host with numpy / skimage (SAM as a Python double loop over pixels).  Kernels: csrc/metrics.hip
+through hsidm_hsi_metrics and hsidm_hsi_mssim.
 """
 import torch
 
 from . import _lib
 
-NAMES = ("mpsnr", "sam", "ergas", "cc", "rmse")
+NAMES = ("mpsnr", "sam", "ergas", "cc", "rmse", "mssim")
 
 
 def quality_indices(truth, pred, ratio=4, data_range=1.0):
-    """truth, pred: [P, C, H, W] fp32 device tensors (same shape).  Returns a [P, 5] fp32 device tensor, columns NAMES."""
+    """truth, pred: [P, C, H, W] fp32 device tensors (same shape).  Returns a [P, 6] fp32 device tensor, columns NAMES
+    (MSSIM is NaN for cubes smaller than its 7x7 window)."""
     if truth.shape != pred.shape or truth.dim() != 4:
         raise ValueError("expected two [P, C, H, W] tensors of equal shape, got %s and %s" % (tuple(truth.shape), tuple(pred.shape)))
     truth = truth.to(torch.float32).contiguous()
@@ -26,11 +28,19 @@ def quality_indices(truth, pred, ratio=4, data_range=1.0):
     out = torch.empty((P, 5), dtype=torch.float32, device=truth.device)
     _lib.check(L.hsidm_hsi_metrics(_lib.ptr(truth), _lib.ptr(pred), P, C, H * W, float(ratio), float(data_range),
                                    _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()), "hsi_metrics")
-    return out
+    ss = torch.full((P, 1), float("nan"), dtype=torch.float32, device=truth.device)
+    if H >= 7 and W >= 7:
+        nb = L.hsidm_hsi_mssim_workspace_bytes(P, C, H, W)
+        if nb <= 0:
+            _lib.check(nb, "hsi_mssim_workspace_bytes")
+        ws2 = torch.empty(nb // 8, dtype=torch.float64, device=truth.device)
+        _lib.check(L.hsidm_hsi_mssim(_lib.ptr(truth), _lib.ptr(pred), P, C, H, W, float(data_range), _lib.ptr(ws2), _lib.ptr(ss),
+                                     _lib.stream_ptr()), "hsi_mssim")
+    return torch.cat([out, ss], dim=1)
 
 
 def as_dicts(table):
-    """[P, 5] tensor -> list of {name: float} (one host synchronisation)."""
+    """[P, 6] tensor -> list of {name: float} (one host synchronisation)."""
     rows = table.detach().cpu().tolist()
     return [dict(zip(NAMES, r)) for r in rows]
 

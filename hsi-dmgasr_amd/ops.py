@@ -301,12 +301,46 @@ def noise_film(B, dim, mlp, wf, bf, *, gamma=None, level_table=None, t_ptr=None,
     return (film, t_out) if want_t else film
 
 
+def film_affine(x, gamma_beta, precision):
+    """(1 + gamma[b, c]) * x + beta[b, c] (FeatureWiseAffine with use_affine_level, reference unet.py:44-47); gamma_beta [B, 2C]."""
+    B, H, W, Cc = x.shape
+    assert gamma_beta.shape == (B, 2 * Cc) and gamma_beta.is_contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().hsidm_film_affine(_lib.prec_id(precision), _lib.ptr(x), _lib.ptr(gamma_beta), _lib.ptr(out), B, H * W, Cc,
+                                            _lib.stream_ptr()), "film_affine")
+    return out
+
+
 def attention(qkv, precision):
     B, H, W, C3 = qkv.shape
     Cc = C3 // 3
     out = torch.empty((B, H, W, Cc), dtype=qkv.dtype, device=qkv.device)
     _lib.check(_lib.lib().hsidm_attention(_lib.prec_id(precision), _lib.ptr(qkv), _lib.ptr(out), B, H * W, Cc,
                                           _lib.stream_ptr()), "attention")
+    return out
+
+
+def attention_multihead(qkv, n_head, precision):
+    """SelfAttention's core for n_head > 1 (reference unet.py:131-141; its UNet only ever builds n_head = 1, the fused kernel
+    above): the qkv channels are n_head blocks of (q | k | v) of head_dim each, the scale stays 1/sqrt(C).  Three launches per
+    head on the strided batched GEMM + row softmax kernels (hsidm_bgemm, hsidm_softmax_rows)."""
+    B, H, W, C3 = qkv.shape
+    Cc, N = C3 // 3, H * W
+    hd = Cc // n_head
+    f32 = qkv.dtype == torch.float32
+    es = qkv.element_size()
+    out = torch.empty((B, H, W, Cc), dtype=qkv.dtype, device=qkv.device)
+    P = torch.empty((B, N, N), dtype=torch.float32, device=qkv.device)
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    for h in range(n_head):
+        q = qkv.data_ptr() + (h * 3 * hd) * es
+        k, v = q + hd * es, q + 2 * hd * es
+        o = out.data_ptr() + h * hd * es
+        _lib.check(L.hsidm_bgemm(q, int(f32), N * C3, C3, 1, k, int(f32), N * C3, 1, C3, P.data_ptr(), 1, N * N, N, N, N, hd, B,
+                                 1.0 / Cc ** 0.5, st), "bgemm")
+        _lib.check(L.hsidm_softmax_rows(_lib.ptr(P), B * N, N, st), "softmax_rows")
+        _lib.check(L.hsidm_bgemm(P.data_ptr(), 1, N * N, N, 1, v, int(f32), N * C3, C3, 1, o, int(f32), N * Cc, Cc, N, hd, N, B, 1.0, st), "bgemm")
     return out
 
 

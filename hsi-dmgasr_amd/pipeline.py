@@ -36,7 +36,7 @@ def evaluate(gae, gd, raw_cubes, n_scale=4, normalize=True, precision=None):
     """The whole validation iteration of sr_gae.py:436-494 on the device, for a batch of ground-truth cubes
     raw_cubes [P, C, H, W]: min-max normalise (HStest.py:37) -> bicubic x1/n, xn (HStest.py:43-45) -> encode, denoise every
     group latent with the sampler set on `gd` (set_sampler), decode -> quality indices against the ground truth
-    (eval_hsi.py).  Returns (SR cubes, indices [P, 5] with columns metrics.NAMES, bicubic baseline indices [P, 5])."""
+    (eval_hsi.py).  Returns (SR cubes, indices [P, 6] with columns metrics.NAMES, bicubic baseline indices [P, 6])."""
     gt = degrade.minmax_normalize(raw_cubes) if normalize else raw_cubes.to(torch.float32).contiguous()
     _, lms = degrade.lr_pair(gt, n_scale)
     sr, _ = super_resolve(gae, gd, lms, precision=precision)

@@ -84,10 +84,8 @@ class FeatureWiseAffine(nn.Module):
 
     def __init__(self, in_channels, out_channels, use_affine_level=False):
         super().__init__()
-        if use_affine_level:
-            raise NotImplementedError("hsidm: use_affine_level=True is not used by the HSI configs and not built")
         self.use_affine_level = use_affine_level
-        self.noise_func = nn.Sequential(nn.Linear(in_channels, out_channels))
+        self.noise_func = nn.Sequential(nn.Linear(in_channels, out_channels * (1 + self.use_affine_level)))
 
     def forward(self, x, noise_embed):
         _kernel_only("FeatureWiseAffine")
@@ -191,8 +189,13 @@ class ResnetBlock(_HipModule):
         self._cache = _PackCache()
 
     def _run(self, x0, x1, film, precision):
-        """x = cat(x0, x1) on channels (x1 may be None); film: [B, dim_out] slice of the FiLM table."""
-        h = self.block1._run(x0, precision, x1=x1, film=film)
+        """x = cat(x0, x1) on channels (x1 may be None); film: [B, dim_out] slice of the FiLM table ([B, 2*dim_out] = (gamma | beta)
+        with use_affine_level: h = (1 + gamma) * block1(x) + beta, reference unet.py:44-47, as its own pass - the reference's UNet
+        never enables it, so it is not fused into the convolution's epilogue)."""
+        if self.noise_func.use_affine_level:
+            h = ops.film_affine(self.block1._run(x0, precision, x1=x1), film.contiguous(), precision)
+        else:
+            h = self.block1._run(x0, precision, x1=x1, film=film)
         if isinstance(self.res_conv, nn.Conv2d):
             if precision == "bf16" and ops.use_v2():
                 # throughput mode: the persistent 3x3 kernel is single-phase; the 1x1 projection is its own
@@ -217,8 +220,8 @@ class ResnetBlock(_HipModule):
 class SelfAttention(_HipModule):
     def __init__(self, in_channel, n_head=1, norm_groups=32):
         super().__init__()
-        if n_head != 1:
-            raise NotImplementedError("hsidm: the reference only ever builds single-head attention (unet.py:152)")
+        if in_channel % n_head:
+            raise ValueError("in_channel must be a multiple of n_head")
         self.n_head = n_head
         self.norm = nn.GroupNorm(norm_groups, in_channel)
         self.qkv = nn.Conv2d(in_channel, in_channel * 3, 1, bias=False)
@@ -231,7 +234,9 @@ class SelfAttention(_HipModule):
                              lambda: ops.PackedConv(self.out.weight, self.out.bias, precision))
         ab = ops.gn_scale_shift(x, None, self.norm.weight, self.norm.bias, self.norm.num_groups, precision, self.norm.eps)
         qkv = ops.conv2d(x, pq, gn_ab=ab, transform=ops.XF_AFFINE)
-        o = ops.attention(qkv, precision)
+        # (the reference's UNet only ever builds n_head = 1, unet.py:152: the fused MFMA kernel; more heads go through the
+        # strided GEMM + softmax kernels)
+        o = ops.attention(qkv, precision) if self.n_head == 1 else ops.attention_multihead(qkv, self.n_head, precision)
         return ops.conv2d(o, po, res=x, stats=True)
 
     def forward(self, input):
@@ -266,7 +271,10 @@ class UNet(_HipModule):
                  attn_res=(8), res_blocks=3, dropout=0, with_noise_level_emb=True, image_size=128, precision=None):
         super().__init__()
         if not with_noise_level_emb:
-            raise NotImplementedError("hsidm: with_noise_level_emb=False is never used by the reference configs")
+            # the reference cannot build this variant either: its ResnetBlock constructs nn.Linear(None, dim_out)
+            # (unet.py:97-98 with noise_level_emb_dim=None) and raises the same TypeError
+            raise TypeError("hsidm: with_noise_level_emb=False leaves the FiLM projections without an input width "
+                            "(the reference's constructor fails on nn.Linear(None, ...) in the same way)")
         self.precision = precision
         attn_res = (attn_res,) if isinstance(attn_res, int) else tuple(attn_res)
         emb = inner_channel

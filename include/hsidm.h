@@ -154,6 +154,11 @@ int hsidm_noise_film(const float* gamma, const float* level_table, const int32_t
                      int B, int dim, const float* w1, const float* b1, const float* w2, const float* b2,
                      const float* wf, const float* bf, int F, float* film, float* t_out, void* stream);
 
+/* FeatureWiseAffine with use_affine_level=True (unet.py:44-47; not reachable from the reference's UNet, which never passes it):
+ * out = (1 + gamma[b][c]) * x + beta[b][c] with gamma_beta [B][2C] = (gamma | beta), the projection hsidm_noise_film emits for a
+ * Linear(dim, 2C); NHWC tensors of the mode's storage type. */
+int hsidm_film_affine(int prec, const void* x, const float* gamma_beta, void* out, int B, int HW, int C, void* stream);
+
 /* ---- self-attention core (unet.py:130-140): softmax(q k^T / sqrt(C)) v, single head ---------------
  * qkv: NHWC [B][N][3C] (q | k | v channel thirds, unet.py:129), out: [B][N][C].  N <= 1024.
  */
@@ -223,6 +228,13 @@ int hsidm_overlap_average(const float* dec, const int32_t* start, int G, int n_s
 int hsidm_hsi_metrics_workspace_bytes(int P, int C, int HW);
 int hsidm_hsi_metrics(const float* truth, const float* pred, int P, int C, int HW, float ratio, float data_range,
                       void* workspace, float* out, void* stream);
+
+/* MSSIM (eval_hsi.py:124-135, the remaining index of quality_assessment :217-238): out[p] = mean over bands of the structural
+ * similarity with skimage's defaults (7x7 uniform window, sample covariance, K1 0.01, K2 0.03, 3-pixel border cropped).
+ * truth, pred NCHW fp32 [P][C][H][W], H, W >= 7.  workspace: hsidm_hsi_mssim_workspace_bytes(P, C, H, W) bytes.  Deterministic. */
+int hsidm_hsi_mssim_workspace_bytes(int P, int C, int H, int W);
+int hsidm_hsi_mssim(const float* truth, const float* pred, int P, int C, int H, int W, float data_range, void* workspace,
+                    float* out, void* stream);
 
 /* ---- patch preparation (HStest.py:37-45, HStrain.py:49-63, imsize.py) ------------------------------------
  * One axis of the MATLAB-compatible resize: dst[o][j][i] = sum_p weights[j][p] * src[o][indices[j][p]][i] for

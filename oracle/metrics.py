@@ -59,3 +59,24 @@ def rmse(x_true, x_pred):
     """eval_hsi.py:99-107: Frobenius norm of the difference / sqrt(number of elements)."""
     d = x_true.astype(np.float32) - x_pred.astype(np.float32)
     return float(np.linalg.norm(d) / np.sqrt(d.size))
+
+
+def mssim(x_true, x_pred, data_range=1.0):
+    """eval_hsi.py:124-135: mean over bands of skimage.metrics.structural_similarity(im1, im2, data_range=...) with its
+    defaults, restated from skimage's documented algorithm (skimage is not part of this image: unpinned, like MPSNR):
+    7x7 uniform filter, sample covariance (n / (n - 1)), K1 = 0.01, K2 = 0.03, border of (7 - 1) / 2 pixels cropped."""
+    from scipy.ndimage import uniform_filter
+    t = x_true.astype(np.float64)
+    p = x_pred.astype(np.float64)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    cov = 49.0 / 48.0
+    vals = []
+    for k in range(t.shape[2]):
+        a, b = t[:, :, k], p[:, :, k]
+        ux, uy = uniform_filter(a, 7), uniform_filter(b, 7)
+        vx = cov * (uniform_filter(a * a, 7) - ux * ux)
+        vy = cov * (uniform_filter(b * b, 7) - uy * uy)
+        vxy = cov * (uniform_filter(a * b, 7) - ux * uy)
+        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+        vals.append(s[3:-3, 3:-3].mean())
+    return float(np.mean(vals))

@@ -103,10 +103,21 @@ def test_quality_indices_on_device(dev):
         assert abs(r["ergas"] - float(g[tag + ".ergas"])) < 1e-4 * float(g[tag + ".ergas"])
         assert abs(r["cc"] - float(g[tag + ".cc"])) < 1e-5
         assert abs(r["rmse"] - float(g[tag + ".rmse"])) < 1e-6
+        assert abs(r["mssim"] - om.mssim(t, p)) < 2e-5            # (restated from skimage's documented algorithm, oracle/metrics.py)
     same = metrics.as_dicts(metrics.quality_indices(tt, tt))[0]    # identical cubes: cosine clamped -> a tiny angle, never NaN
     assert 0.0 <= same["sam"] < 0.05 and same["rmse"] == 0.0 and same["mpsnr"] == float("inf")
     with pytest.raises(ValueError):
         metrics.quality_indices(tt, pp[:, :3])
+    assert same["mssim"] == pytest.approx(1.0, abs=1e-6)
+    # a low-contrast cube (mean 0.9, standard deviation 1e-3): the one-pass correlation E[tp] - E[t]E[p] needs the fp64 partial
+    # sums of the band statistics kernel (fp32 partials lose it)
+    rng = np.random.Generator(np.random.PCG64(8))
+    tl = (0.9 + 1e-3 * rng.standard_normal((64, 64, 6))).astype(np.float32)
+    pl = (tl + 3e-4 * rng.standard_normal((64, 64, 6))).astype(np.float32)
+    rl = metrics.as_dicts(metrics.quality_indices(torch.from_numpy(tl.transpose(2, 0, 1)[None].copy()).to(dev),
+                                                  torch.from_numpy(pl.transpose(2, 0, 1)[None].copy()).to(dev)))[0]
+    assert abs(rl["cc"] - om.cross_correlation(tl, pl)) < 2e-4, (rl["cc"], om.cross_correlation(tl, pl))
+    assert abs(rl["mssim"] - om.mssim(tl, pl)) < 1e-3
 
 
 def test_patch_preparation_on_device(dev):

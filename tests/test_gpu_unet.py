@@ -54,6 +54,33 @@ def test_resnet_block(dev, ops_npz, prec, tag, cin, cout):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("tag,cin,cout", [("aff_same", 64, 64), ("aff_proj", 32, 64)])
+def test_resnet_block_with_affine_noise_level(dev, prec, tag, cin, cout):
+    """ResnetBlock(use_affine_level=True): h = (1 + gamma) * block1(x) + beta (reference unet.py:44-47), against the reference's output."""
+    from hsi_dmgasr_amd.sr3_modules import unet
+    g = load_npz("variants.npz")
+    m = unet.ResnetBlock(cin, cout, noise_level_emb_dim=32, use_affine_level=True, norm_groups=32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, tag + ".")
+    y = m(G(synth_tensor(tag + ".x", (2, cin, 8, 8)), dev), G(synth_tensor(tag + ".t", (2, 1, 32)), dev))
+    check(tag, prec, y, g[tag + ".y"])
+    with pytest.raises(TypeError):          # the variant the reference cannot construct either (nn.Linear(None, ...))
+        unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  with_noise_level_emb=False, image_size=16)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_self_attention_with_four_heads(dev, prec):
+    """SelfAttention(n_head=4) (reference unet.py:114-143; unreachable from its UNet) against the reference's output."""
+    from hsi_dmgasr_amd.sr3_modules import unet
+    g = load_npz("variants.npz")
+    m = unet.SelfAttention(64, n_head=4, norm_groups=32).to(dev).eval()
+    m.precision = prec
+    fill_synth(m, "attn4.")
+    check("attn_4_heads", prec, m(G(synth_tensor("attn4.x", (2, 64, 8, 8)), dev)), g["attn4.y"])
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_resnet_block_two_pointer_concat(dev, ops_npz, prec):
     """Skip-concat input read in place from two tensors (GroupNorm group 21 straddles the seam at 64)."""
     from hsi_dmgasr_amd import ops
