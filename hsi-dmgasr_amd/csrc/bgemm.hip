@@ -22,40 +22,43 @@ __device__ __forceinline__ float ld_elem(const void* p, int64_t i, int is_f32) {
     return is_f32 ? reinterpret_cast<const float*>(p)[i] : (float)reinterpret_cast<const bf16*>(p)[i];
 }
 
-// C[b] (M x N, row-major, unit column stride) = alpha * A[b] (M x K) * B[b] (K x N); workgroup = 64 x 64 tile, wave = 32 x 32
+// C[b] (M x N, row-major, unit column stride) = alpha * A[b] (M x K) * B[b] (K x N).
+// Workgroup = one 32 x 32 tile of C, its four waves split every 64-deep K chunk four ways (16 k each = 8 MFMAs) and meet in
+// LDS at the end: the attention backward's products are 256 x 256 ... 512 per image at batch 4, so 64 x 64 tiles would be 64
+// workgroups on 256 CUs; 32 x 32 tiles with the K split inside the workgroup give 256-512 of them at the same staging cost.
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmParams p) {
-    constexpr int KC = 16, PITCH = 65;
+    constexpr int KC = 64, PITCH = 33;
     __shared__ float As[KC * PITCH], Bs[KC * PITCH];
+    __shared__ float red[3][32 * 33];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, bz = blockIdx.z;
     const int64_t abase = (int64_t)bz * p.sab, bbase = (int64_t)bz * p.sbb;
     // consecutive threads walk the unit-stride axis of each operand
     const bool a_kfast = p.sak == 1, b_kfast = p.sbk == 1;
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    float ra[4], rb[4];
+    float ra[8], rb[8];
     auto issue = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int k, m;
-            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 31; k = (tid >> 5) + 8 * i; }
             ra[i] = (m0 + m < p.M && k0 + k < p.K) ? ld_elem(p.a, abase + (int64_t)(m0 + m) * p.sam + (int64_t)(k0 + k) * p.sak, p.a_f32) : 0.f;
             int kb, n;
-            if (b_kfast) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+            if (b_kfast) { kb = tid & 63; n = (tid >> 6) + 4 * i; } else { n = tid & 31; kb = (tid >> 5) + 8 * i; }
             rb[i] = (n0 + n < p.N && k0 + kb < p.K) ? ld_elem(p.b, bbase + (int64_t)(k0 + kb) * p.sbk + (int64_t)(n0 + n) * p.sbn, p.b_f32) : 0.f;
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int k, m;
-            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 31; k = (tid >> 5) + 8 * i; }
             As[k * PITCH + m] = ra[i];
             int kb, n;
-            if (b_kfast) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+            if (b_kfast) { kb = tid & 63; n = (tid >> 6) + 4 * i; } else { n = tid & 31; kb = (tid >> 5) + 8 * i; }
             Bs[kb * PITCH + n] = rb[i];
         }
     };
@@ -67,20 +70,27 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmParams p) {
         if (k0 + KC < p.K) issue(k0 + KC);
         const int h = lane >> 5, r = lane & 31;
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 2) {
-            const float av = As[(kk + h) * PITCH + 32 * wm + r];
-            const float bv = Bs[(kk + h) * PITCH + 32 * wn + r];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int kk = 0; kk < 16; kk += 2) {
+            const int k = 16 * wave + kk + h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * PITCH + r], Bs[k * PITCH + r], acc, 0, 0, 0);
         }
     }
-    const int n = n0 + 32 * wn + (lane & 31);
-    if (n < p.N) {
+    // the four K quarters meet in a fixed order (wave 0 + 1 + 2 + 3): deterministic
+    const int col = lane & 31;
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[wave - 1][((j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)) * 33 + col] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n = n0 + col;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int m = m0 + 32 * wm + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
-            if (m < p.M) {
+            const int row = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+            const int m = m0 + row;
+            const float v = p.alpha * (((acc[j] + red[0][row * 33 + col]) + red[1][row * 33 + col]) + red[2][row * 33 + col]);
+            if (m < p.M && n < p.N) {
                 const int64_t idx = (int64_t)bz * p.scb + (int64_t)m * p.scm + n;
-                const float v = p.alpha * acc[j];
                 if (p.c_f32) reinterpret_cast<float*>(p.c)[idx] = v;
                 else reinterpret_cast<bf16*>(p.c)[idx] = (bf16)v;
             }
@@ -157,7 +167,7 @@ extern "C" int hsidm_bgemm(const void* a, int a_f32, int64_t sab, int64_t sam, i
     p.a = a; p.b = b; p.c = c;
     p.sab = sab; p.sam = sam; p.sak = sak; p.sbb = sbb; p.sbk = sbk; p.sbn = sbn; p.scb = scb; p.scm = scm;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.a_f32 = a_f32; p.b_f32 = b_f32; p.c_f32 = c_f32;
-    hipLaunchKernelGGL(bgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(bgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

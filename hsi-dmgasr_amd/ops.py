@@ -195,6 +195,10 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         slab = torch.empty((B, nsplit, pw.cout, 2), dtype=torch.float32, device=x0.device)
         d.stats = _lib.ptr(slab)
         out._hsidm_stats = (slab, nsplit)
+    trk = getattr(pw, "_track", None)
+    if trk is not None:     # the training step records which packed layout the dispatch reads (training.Trainer._prune_layouts)
+        kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
+        trk.add("w" if (kid & 15) == 0 else ("w_dn4" if planes else "w_v2"))
     if _conv_probe is None:
         _lib.check(_lib.lib().hsidm_conv2d(C.byref(d), _lib.stream_ptr()), "conv2d")
     else:   # measurement hook (bench.py): HIP events on the launch stream around this one kernel

@@ -111,7 +111,8 @@ def channel_sums(x, precision, out_c=None, want_bc=False, cout=None):
     per-image sums [B, cout]."""
     B, H, W, C = x.shape
     cout = C if cout is None else cout
-    part, nsplit = ops.channel_partials(x, precision, nsplit=_nsplit(B, H * W))
+    # (a quarter of the splits of the GroupNorm reductions: the column-sum kernel walks them per image)
+    part, nsplit = ops.channel_partials(x, precision, nsplit=max(1, _nsplit(B, H * W) // 4))
     bc = torch.empty((B, cout), dtype=torch.float32, device=x.device) if want_bc else None
     _check(_lib.lib().hsidm_colsum(_lib.ptr(part), nsplit, B, C, cout, _lib.ptr(bc), _lib.ptr(out_c), _lib.stream_ptr()), "colsum")
     return bc

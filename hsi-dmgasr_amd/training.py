@@ -45,6 +45,7 @@ class Trainer:
         self.step_count = 0            # optimiser steps taken (Adam's bias correction)
         self._iter = 0                 # training forward passes started (dropout mask key)
         self.reducer, self._reduced, self._low_cache = None, False, {}
+        self._shape_seen, self._tracking = None, False
         self._g, self._g_active, self._g_calls = None, False, 0      # captured step (optimize_parameters): state, capturing/replaying, calls
         self.dev = next(net.parameters()).device
         self._check_device()
@@ -131,22 +132,11 @@ class Trainer:
         return out
 
     def _build_pack_maps(self):
+        """Gather maps (packed element -> index into the flat parameter buffer) of every layout of every convolution, built by
+        running the inference packing code on index-valued tensors.  Which of them are materialised is decided by _assemble."""
         prec = self.precision
-        segs, maps, total = [], [], 0
-
-        def add_map(layout):
-            nonlocal total
-            idx = (layout.round().to(torch.int64) - 1).to(torch.int32).reshape(-1)
-            n = idx.numel()
-            pad = (-n) % 8
-            if pad:
-                idx = torch.cat([idx, torch.full((pad,), -1, dtype=torch.int32, device=idx.device)])
-            maps.append(idx)
-            seg = (total, n, tuple(layout.shape))
-            total += n + pad
-            return seg
-
-        self._pk_spec = {}
+        self._seg = {}                       # (conv id, role, layout name) -> (idx int32 [n padded to 8], n, shape)
+        self._pk_meta = {}                   # (conv id, role) -> (meta, out_nchw)
         for conv, out_nchw, fold_dn, need_dg in self._convs():
             w = conv.weight
             base = self._off[id(w)]
@@ -156,24 +146,63 @@ class Trainer:
                 roles.append(("dgrad", iw.transpose(0, 1).flip(2, 3).contiguous(), False, False))
             for role, iwt, nchw, fdn in roles:
                 lay, meta = ops.pack_layouts(iwt, prec, out_nchw=nchw, fold_dn=fdn and prec == "bf16")
-                spec = dict(meta=meta, out_nchw=nchw, w=add_map(lay["w"]),
-                            w_v2=None if lay["w_v2"] is None else add_map(lay["w_v2"]),
-                            w_dn4=None if lay["w_dn4"] is None else add_map(lay["w_dn4"]))
-                self._pk_spec[(id(conv), role)] = spec
-        self._pack_idx = torch.cat(maps)
+                self._pk_meta[(id(conv), role)] = (meta, nchw)
+                for name in ("w", "w_v2", "w_dn4"):
+                    if lay[name] is None:
+                        continue
+                    idx = (lay[name].round().to(torch.int64) - 1).to(torch.int32).reshape(-1)
+                    n = idx.numel()
+                    if n % 8:
+                        idx = torch.cat([idx, torch.full((8 - n % 8,), -1, dtype=torch.int32, device=idx.device)])
+                    self._seg[(id(conv), role, name)] = (idx, n, tuple(lay[name].shape))
+        self._assemble(set(self._seg))
+
+    def _assemble(self, active):
+        """One index map + one packed buffer over the `active` layouts, and PackedConv views over it."""
+        prec = self.precision
+        keys = [k for k in self._seg if k in active]
+        self._active = set(keys)
+        self._pack_idx = torch.cat([self._seg[k][0] for k in keys])
+        total = self._pack_idx.numel()
         self._pack_hi = torch.zeros(total, dtype=torch.bfloat16, device=self.dev)
         self._pack_lo = torch.zeros(total, dtype=torch.bfloat16, device=self.dev) if prec == "fp32" else None
+        views, o = {}, 0
+        for k in keys:
+            idx, n, shape = self._seg[k]
+            views[k] = (self._pack_hi[o:o + n].view(shape), None if self._pack_lo is None else self._pack_lo[o:o + n].view(shape))
+            o += idx.numel()
         self._pk = {}
-
-        def view(buf, seg):
-            return None if (seg is None or buf is None) else buf[seg[0]:seg[0] + seg[1]].view(seg[2])
-
-        for (cid, role), spec in self._pk_spec.items():
-            self._pk[(cid, role)] = ops.PackedConv.from_buffers(
-                spec["meta"], prec, spec["out_nchw"], view(self._pack_hi, spec["w"]), view(self._pack_lo, spec["w"]),
-                view(self._pack_hi, spec["w_v2"]), view(self._pack_hi, spec["w_dn4"]), None)
+        for (cid, role), (meta, nchw) in self._pk_meta.items():
+            w = views.get((cid, role, "w"))
+            v2 = views.get((cid, role, "w_v2"))
+            dn4 = views.get((cid, role, "w_dn4"))
+            any_hi = next(v[0] for v in (w, v2, dn4) if v is not None)
+            # hsidm_conv2d wants a non-null w_hi even when the dispatch reads another layout: a pruned one aliases a live buffer
+            pk = ops.PackedConv.from_buffers(meta, prec, nchw, w[0] if w is not None else any_hi, None if w is None else w[1],
+                                             None if v2 is None else v2[0], None if dn4 is None else dn4[0], None)
+            pk._track = None
+            self._pk[(cid, role)] = pk
         for conv, _, _, _ in self._convs():          # forward convolutions read their bias straight from the master copy
             self._pk[(id(conv), "fwd")].bias = None if conv.bias is None else conv.bias.detach()
+        self._g, self._g_calls = None, 0             # a captured step holds pointers into the old buffers
+
+    def _track_layouts(self, on):
+        for pk in self._pk.values():
+            pk._track = set() if on else None
+
+    def _prune_layouts(self):
+        """After a tracked step: keep only the layouts the kernel dispatch read for this batch shape (in the bf16 mode most
+        convolutions read the register-streaming order only; the LDS-tiled order is packed for the rest)."""
+        keep = set()
+        for (cid, role), pk in self._pk.items():
+            used = pk._track or set()
+            names = [n for n in ("w", "w_v2", "w_dn4") if (cid, role, n) in self._seg]
+            live = [n for n in names if n in used] or names        # never drop everything
+            keep.update((cid, role, n) for n in live)
+        self._track_layouts(False)
+        if keep != self._active:
+            self._assemble(keep)
+            self.repack()
 
     def repack(self):
         """Kernel-order bf16 (hi [+ lo]) weights of every convolution, forward and transposed, from the fp32 master copy."""
@@ -401,9 +430,10 @@ class Trainer:
         backward_loss needs.  t / gamma are drawn from numpy's global generator exactly as the reference does unless given."""
         gd = self.gd
         self._iter += 1
+        x_start = x_in["HR"].contiguous()
+        self._note_shape(tuple(x_start.shape))
         if self._versions() != self._packed_at:        # someone else (a torch optimiser, load_state_dict) changed the weights
             self.repack()
-        x_start = x_in["HR"].contiguous()
         b, c, h, w = x_start.shape
         if gamma is None:
             if t is None:
@@ -416,11 +446,24 @@ class Trainer:
         eps = self.forward(cond, x_noisy, gamma)
         return ops.loss_sum(noise, eps, gd.loss_type), (noise, eps, b * c * h * w)
 
+    def _note_shape(self, shape):
+        """Layout pruning is per batch shape (the dispatch depends on it): a new shape restores every layout and tracks again."""
+        if shape != self._shape_seen:
+            self._shape_seen = shape
+            if self._active != set(self._seg):
+                self._assemble(set(self._seg))
+                self.repack()
+            self._track_layouts(True)
+            self._tracking = True
+
     @torch.no_grad()
     def backward_loss(self, state, scale):
         """Gradient of scale * (sum-reduced loss) into the flat gradient buffer."""
         noise, eps, _ = state
         self.backward(T.loss_grad(noise, eps, self.gd.loss_type, scale, self.precision))
+        if self._tracking and not self._g_active:
+            self._tracking = False
+            self._prune_layouts()
 
     @torch.no_grad()
     def loss_and_grads(self, x_in, noise=None, t=None, gamma=None):
@@ -477,8 +520,8 @@ class Trainer:
         if self._g is not None and self._g["shape"] != shape_key:
             self._g, self._g_calls = None, 0                    # another batch shape: capture again
         self._g_calls += 1
-        if self._g_calls == 1:                                  # eager: sizes every cache (workspaces, LDS caps, offsets)
-            loss = self.loss_and_grads(data)
+        if self._g_calls == 1:                                  # eager: sizes every cache (workspaces, LDS caps, offsets) and
+            loss = self.loss_and_grads(data)                    # prunes the packed layouts for this batch shape
             self.optimizer_step()
             return loss
         if self._g is None:
