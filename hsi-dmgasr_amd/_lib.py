@@ -32,6 +32,11 @@ class ConvDesc(C.Structure):
                 ("out_nchw", _i32), ("prec", _i32), ("bn", _i32)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("ws", _vp), ("dw", _vp), ("nsplit", _i32), ("NT", _i32), ("Cout_pad", _i32), ("Cin_pad", _i32), ("Cout_w", _i32),
+                ("Cin_w", _i32), ("block0", _i32), ("reserved", _i32)]
+
+
 # name -> argtypes, exactly the prototypes of include/hsidm.h
 SIGNATURES = {
     "hsidm_version": [],
@@ -74,6 +79,8 @@ SIGNATURES = {
     "hsidm_conv_wgrad_workspace_bytes": [_i32] * 11,
     "hsidm_conv_wgrad": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
                          _i64, _vp],
+    "hsidm_conv_wgrad_plan": [_i32] * 11 + [_vp],
+    "hsidm_wgrad_reduce_all": [_vp, _i32, _i32, _vp],
     "hsidm_add": [_i32, _vp, _vp, _vp, _i64, _vp],
     "hsidm_zero_insert2": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "hsidm_sum2x2": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -184,12 +184,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // A workgroup owns 64 consecutive (co, ci) pairs: thread (pair, q) sums the splits s = q, q + 4, ... of every tap (consecutive
 // threads = consecutive ci: coalesced reads), the four partial sums meet in LDS in the order q = 0..3, and the 64 x NT results
 // leave as one contiguous run of the PyTorch layout (coalesced writes).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
-                                                           int Cout_w, int Cin_w, float* __restrict__ dw) {
-    __shared__ float sm[4][64][10];
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
+                                                   int Cout_w, int Cin_w, float* __restrict__ dw, int blk, float (*sm)[64][10]) {
     const int pair = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t npairs = (int64_t)Cout_w * Cin_w;
-    const int64_t i = (int64_t)blockIdx.x * 64 + pair;
+    const int64_t i = (int64_t)blk * 64 + pair;
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
@@ -207,13 +206,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < 9; ++t) sm[q][pair][t] = acc[t];
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * 64 * NT, total = npairs * NT;
+    const int64_t base = (int64_t)blk * 64 * NT, total = npairs * NT;
     for (int e = threadIdx.x; e < 64 * NT; e += 256) {
         if (base + e < total) {
             const int pr = e / NT, t = e - pr * NT;
             dw[base + e] = ((sm[0][pr][t] + sm[1][pr][t]) + sm[2][pr][t]) + sm[3][pr][t];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
+                                                           int Cout_w, int Cin_w, float* __restrict__ dw) {
+    __shared__ float sm[4][64][10];
+    wgrad_reduce_block(ws, nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, dw, blockIdx.x, sm);
+}
+
+// every layer's reduction in ONE launch (the training step on one GPU defers them to the end of the backward pass: 94 launches
+// of 10-20 us each are latency, this one runs at bandwidth).  items[] is sorted by block0; a block finds its item by bisection.
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const hsidm_wgrad_item* __restrict__ items, int n_items) {
+    __shared__ float sm[4][64][10];
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const hsidm_wgrad_item it = items[lo];
+    wgrad_reduce_block(it.ws, it.nsplit, it.NT, it.Cout_pad, it.Cin_pad, it.Cout_w, it.Cin_w, it.dw, (int)blockIdx.x - it.block0, sm);
 }
 
 struct WgPlan { int TW, TH, tiles_x, tiles_y, ksteps, nsplit, cin_tiles, cout_tiles, Cin_pad, Cout_pad, NT, mode; size_t ws_bytes; };
@@ -282,13 +300,29 @@ extern "C" int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int H
     return rc != HSIDM_OK ? (int64_t)rc : (int64_t)pl.ws_bytes;
 }
 
+extern "C" int hsidm_conv_wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize, int stride, int ups,
+                                     int32_t* plan4) {
+    WgPlan pl;
+    const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
+    if (rc != HSIDM_OK) return rc;
+    if (!plan4) return HSIDM_E_BADARG;
+    plan4[0] = pl.nsplit; plan4[1] = pl.NT; plan4[2] = pl.Cout_pad; plan4[3] = pl.Cin_pad;
+    return HSIDM_OK;
+}
+
+extern "C" int hsidm_wgrad_reduce_all(const hsidm_wgrad_item* items_dev, int n_items, int total_blocks, void* stream) {
+    if (!items_dev || n_items <= 0 || total_blocks <= 0) return HSIDM_E_BADARG;
+    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+    return (int)hipGetLastError();
+}
+
 extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
                                 int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
     WgPlan pl;
     const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
     if (rc != HSIDM_OK) return rc;
-    if (!a0 || (C1 > 0 && !a1) || !dy || !dw || !workspace || Cout_w <= 0 || Cout_w > Cout || Cin_w <= 0 || Cin_w > C0 + C1) return HSIDM_E_BADARG;
+    if (!a0 || (C1 > 0 && !a1) || !dy || !workspace || Cout_w <= 0 || Cout_w > Cout || Cin_w <= 0 || Cin_w > C0 + C1) return HSIDM_E_BADARG;
     if ((size_t)workspace_bytes < pl.ws_bytes) return HSIDM_E_BADARG;
     WgradParams p;
     p.a0 = a0; p.a1 = C1 > 0 ? a1 : nullptr; p.dy = dy; p.ws = (float*)workspace;
@@ -302,6 +336,7 @@ extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0
     else if (prec == HSIDM_F32X3) e = dispatch_wgrad<float>(p, pl, s);
     else return HSIDM_E_BADARG;
     if (e) return e;
+    if (!dw) return HSIDM_OK;                       // deferred: the caller sums the partial tiles later (hsidm_wgrad_reduce_all)
     const int64_t n = (int64_t)Cout_w * Cin_w;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
                        pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw);

@@ -1,6 +1,8 @@
 """Host-side wrappers of the training kernels (include/hsidm.h, "training step"): NHWC tensors of the mode's storage type in,
 kernels enqueued on the current stream, nothing synchronised.  Forward convolutions and their input gradients go through
 ops.conv2d (the input gradient of a convolution is a convolution with the transposed, flipped weights)."""
+import ctypes as C
+
 import torch
 
 from . import _lib, ops
@@ -68,21 +70,66 @@ def _workspace(nbytes, dev):
     return buf
 
 
-def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False):
+def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None):
     """dw [Cout_w, Cin_w, k, k] (fp32, contiguous view of the gradient buffer) = weight gradient of the convolution that
-    maps a = cat(a0, a1) to the tensor whose gradient is dy."""
+    maps a = cat(a0, a1) to the tensor whose gradient is dy.
+
+    deferred: a DeferredReductions collector - the split-K partial tiles stay in a workspace of this layer's own and ONE launch sums
+    all layers at the end (reduce_deferred)."""
     B, Hin, Win, C0 = a0.shape
     C1 = 0 if a1 is None else a1.shape[3]
     _, Ho, Wo, Ct = dy.shape
     cout_w, cin_w, k, _ = dw.shape
     L = _lib.lib()
-    nb = L.hsidm_conv_wgrad_workspace_bytes(C0, C1, B, Hin, Win, Ho, Wo, Ct, k, stride, int(bool(ups)))
+    geo = (C0, C1, B, Hin, Win, Ho, Wo, Ct, k, stride, int(bool(ups)))
+    nb = L.hsidm_conv_wgrad_workspace_bytes(*geo)
     if nb < 0:
         _check(int(nb), "conv_wgrad_workspace_bytes")
-    ws = _workspace(nb, a0.device)
     assert dw.is_contiguous() and dw.dtype == torch.float32
+    if deferred is None:
+        ws = _workspace(nb, a0.device)
+        dwp = _lib.ptr(dw)
+    else:
+        ws = deferred.workspace(dw, nb, geo)
+        dwp = None
     _check(L.hsidm_conv_wgrad(_lib.prec_id(precision), _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(dy), B, Hin, Win, Ho, Wo, Ct, k,
-                              stride, int(bool(ups)), cout_w, cin_w, _lib.ptr(dw), _lib.ptr(ws), int(nb), _lib.stream_ptr()), "conv_wgrad")
+                              stride, int(bool(ups)), cout_w, cin_w, dwp, _lib.ptr(ws), int(nb), _lib.stream_ptr()), "conv_wgrad")
+
+
+class DeferredReductions:
+    """Per-layer split-K workspaces (persistent: their addresses go into a device table once) and the one-launch reduction."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.ws, self.items, self.table, self.blocks = {}, [], None, 0
+
+    def workspace(self, dw, nbytes, geo):
+        key = dw.data_ptr()
+        hit = self.ws.get(key)
+        if hit is None or hit[0].numel() < nbytes or hit[1] != geo:
+            plan = (C.c_int32 * 4)()
+            _check(_lib.lib().hsidm_conv_wgrad_plan(*geo, plan), "conv_wgrad_plan")
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+            self.ws[key] = (buf, geo, tuple(plan), dw)
+            self.table = None                           # addresses changed: rebuild the table
+        return self.ws[key][0]
+
+    def reduce(self):
+        if not self.ws:
+            return
+        if self.table is None:
+            arr = (_lib.WgradItem * len(self.ws))()
+            blk = 0
+            for i, (buf, geo, plan, dw) in enumerate(self.ws.values()):
+                it = arr[i]
+                it.ws, it.dw = buf.data_ptr(), dw.data_ptr()
+                it.nsplit, it.NT, it.Cout_pad, it.Cin_pad = plan
+                it.Cout_w, it.Cin_w, it.block0 = dw.shape[0], dw.shape[1], blk
+                blk += (dw.shape[0] * dw.shape[1] + 63) // 64
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = host.to(self.dev)
+            self.n, self.blocks = len(self.ws), blk
+        _check(_lib.lib().hsidm_wgrad_reduce_all(_lib.ptr(self.table), self.n, self.blocks, _lib.stream_ptr()), "wgrad_reduce_all")
 
 
 def add(a, b, precision):

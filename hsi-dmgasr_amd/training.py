@@ -46,6 +46,7 @@ class Trainer:
         self._iter = 0                 # training forward passes started (dropout mask key)
         self.reducer, self._reduced, self._low_cache = None, False, {}
         self._shape_seen, self._tracking = None, False
+        self._defer_obj, self._defer = None, None
         self._g, self._g_active, self._g_calls = None, False, 0      # captured step (optimize_parameters): state, capturing/replaying, calls
         self.dev = next(net.parameters()).device
         self._check_device()
@@ -235,7 +236,7 @@ class Trainer:
         """dy: gradient at the block's conv output (bias sums are the caller's).  -> (dx0, dx1)"""
         x0, x1, ab, a, lid, p_drop = ctx
         gn, conv, p = blk.block[0], blk.block[3], self.precision
-        T.conv_wgrad(a, None, dy, self.G(conv.weight), p)
+        T.conv_wgrad(a, None, dy, self.G(conv.weight), p, deferred=self._defer)
         da = ops.conv2d(dy, self.dpk(conv))
         return T.gn_act_bwd(da, x0, x1, ab, gn.weight, gn.num_groups, True, p, self.G(gn.weight), self.G(gn.bias), p_drop,
                             self._drop_key(), lid, add=add)
@@ -261,7 +262,7 @@ class Trainer:
         dh1, _ = self._block_bwd(rb.block2, c2, d_out)
         dfilm = T.channel_sums(dh1, p, out_c=self.G(conv1.bias), want_bc=True)
         if proj:
-            T.conv_wgrad(x0, x1, d_out, self.G(rb.res_conv.weight), p)
+            T.conv_wgrad(x0, x1, d_out, self.G(rb.res_conv.weight), p, deferred=self._defer)
             add = ops.conv2d(d_out, self.dpk(rb.res_conv), res=skip_add)
         else:
             add = d_out if skip_add is None else T.add(d_out, skip_add, p)
@@ -281,10 +282,10 @@ class Trainer:
         x, ab, n, qkv, o = ctx
         p = self.precision
         T.channel_sums(dy, p, out_c=self.G(at.out.bias))
-        T.conv_wgrad(o, None, dy, self.G(at.out.weight), p)
+        T.conv_wgrad(o, None, dy, self.G(at.out.weight), p, deferred=self._defer)
         do = ops.conv2d(dy, self.dpk(at.out))
         dqkv = T.attention_bwd(qkv, do, p)
-        T.conv_wgrad(n, None, dqkv, self.G(at.qkv.weight), p)
+        T.conv_wgrad(n, None, dqkv, self.G(at.qkv.weight), p, deferred=self._defer)
         dn = ops.conv2d(dqkv, self.dpk(at.qkv))
         dx, _ = T.gn_act_bwd(dn, x, None, ab, at.norm.weight, at.norm.num_groups, False, p, self.G(at.norm.weight),
                              self.G(at.norm.bias), add=dy)
@@ -355,6 +356,11 @@ class Trainer:
         tp = self._tape
         fconv = net.final_conv.block[3]
         red = self._reducer()
+        # one GPU: the 94 split-K reductions of the weight gradients are deferred to ONE launch at the end (each is 10-20 us of
+        # latency on its own); several GPUs: every layer reduces at once, so that its bucket can go on the wire
+        if red is None and self._defer_obj is None and self.dev.type == "cuda":
+            self._defer_obj = T.DeferredReductions(self.dev)
+        self._defer = self._defer_obj if red is None else None
         T.channel_sums(d_eps, p, out_c=self.G(fconv.bias), cout=fconv.bias.shape[0])
         d, _ = self._block_bwd(net.final_conv, tp["final"], d_eps)
         if red is not None:
@@ -378,17 +384,17 @@ class Trainer:
             elif kind == "up":
                 conv = layer.conv
                 T.channel_sums(d, p, out_c=self.G(conv.bias))
-                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, ups=True)
+                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, ups=True, deferred=self._defer)
                 d = T.sum2x2(ops.conv2d(d, self.dpk(conv)), p)
             elif kind == "down":
                 conv = layer.conv
                 T.channel_sums(d, p, out_c=self.G(conv.bias))
-                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, stride=2)
+                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, stride=2, deferred=self._defer)
                 z = T.zero_insert2(d, ctx.shape[1], ctx.shape[2], p)
                 d = ops.conv2d(z, self.dpk(conv), res=skip_add)
             else:                          # stem: parameters only
                 T.channel_sums(d, p, out_c=self.G(layer.bias))
-                T.conv_wgrad(ctx, None, d, self.G(layer.weight), p)
+                T.conv_wgrad(ctx, None, d, self.G(layer.weight), p, deferred=self._defer)
             # the flat gradient buffer follows the module order and the backward pass fills it from the end: every bucket
             # above this layer's lowest offset is final and can go on the wire while the earlier layers are still computing
             # (FiLM projections - first in the buffer - and the noise MLP are written after the loop)
@@ -399,6 +405,8 @@ class Trainer:
         l1, l2 = net.noise_level_mlp[1], net.noise_level_mlp[3]
         T.noise_film_bwd(tp["gamma"], tp["t_emb"], torch.cat(dfilms, dim=1).contiguous(), mlp, self._wf,
                          (self.G(l1.weight), self.G(l1.bias), self.G(l2.weight), self.G(l2.bias), self._dwf, self._dbf))
+        if self._defer is not None:
+            self._defer.reduce()
         self._tape = None
         if red is not None:
             red.finish()

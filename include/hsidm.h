@@ -295,6 +295,18 @@ int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int Hin, int Win
 int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
                      int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
                      void* workspace, int64_t workspace_bytes, void* stream);
+/* Deferred form: dw == NULL leaves the partial tiles in `workspace` ([nsplit][taps][Cout_pad][Cin_pad] fp32; the four sizes from
+ * hsidm_conv_wgrad_plan) and ONE hsidm_wgrad_reduce_all launch sums every layer's splits later - a training step on one GPU has 94
+ * of these reductions, each 10-20 us of latency on its own.  items: device array sorted by block0, block0 = prefix sum of
+ * ceil(Cout_w * Cin_w / 64) over the items; total_blocks = that sum. */
+typedef struct hsidm_wgrad_item {
+    const float* ws;
+    float*       dw;
+    int32_t nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, block0, reserved;
+} hsidm_wgrad_item;
+int hsidm_conv_wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize, int stride, int ups,
+                          int32_t* plan4);
+int hsidm_wgrad_reduce_all(const hsidm_wgrad_item* items_dev, int n_items, int total_blocks, void* stream);
 /* Adjoints of the resampling steps (the input gradient of a convolution itself is hsidm_conv2d with the transposed, flipped
  * weights): zero_insert2: out[2y][2x] = in[y][x], zero elsewhere (stride-2 conv, unet.py:73-74; Hi = (Ho+1)/2);
  * sum2x2: out[y][x] = sum of in's 2x2 block (nearest x2, unet.py:64).  NHWC tensors of the mode's storage type. */

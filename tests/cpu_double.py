@@ -157,7 +157,7 @@ def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta,
     return gx[..., :C0].contiguous(), (None if x1 is None else gx[..., C0:].contiguous())
 
 
-def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False):
+def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None):
     x = nchw(cat(a0, a1))
     if ups:
         x = F.interpolate(x, scale_factor=2, mode="nearest")

@@ -403,3 +403,27 @@ def test_full_size_training_step_gradients(dev):
         assert total < (1e-3 if prec == "fp32" else 4e-2), (prec, total, worst, wname)
         del tr, gd
         torch.cuda.empty_cache()
+
+
+def test_deferred_weight_gradient_reductions_match_the_immediate_ones(dev):
+    """hsidm_conv_wgrad's deferred form + ONE hsidm_wgrad_reduce_all launch over several layers against the per-layer reduction:
+    bit-identical (same partial tiles, same summation order)."""
+    from hsi_dmgasr_amd import train_ops as T
+    cases = [(2, 16, 16, 64, 64, 3, 1, False), (3, 8, 8, 96, 128, 3, 1, False), (2, 16, 16, 192, 64, 1, 1, False), (2, 16, 16, 64, 64, 3, 2, False),
+             (2, 8, 8, 32, 96, 3, 1, True), (12, 32, 32, 64, 40, 3, 1, False)]
+    defer = T.DeferredReductions(dev)
+    now, later = [], []
+    for i, (B, H, W, Ci, Co, k, stride, ups) in enumerate(cases):
+        Ho, Wo = (2 * H, 2 * W) if ups else ((H // 2, W // 2) if stride == 2 else (H, W))
+        a = act(rnd((B, H, W, Ci), 70 + i), "bf16", dev)
+        dy = act(rnd((B, Ho, Wo, Co), 80 + i, 0.5), "bf16", dev)
+        d0 = torch.empty(Co, Ci, k, k, device=dev)
+        d1 = torch.full((Co, Ci, k, k), float("nan"), device=dev)
+        T.conv_wgrad(a, None, dy, d0, "bf16", stride=stride, ups=ups)
+        T.conv_wgrad(a, None, dy, d1, "bf16", stride=stride, ups=ups, deferred=defer)
+        now.append(d0)
+        later.append(d1)
+    defer.reduce()
+    torch.cuda.synchronize()
+    for d0, d1 in zip(now, later):
+        assert torch.equal(d0, d1)
