@@ -427,3 +427,34 @@ def test_deferred_weight_gradient_reductions_match_the_immediate_ones(dev):
     torch.cuda.synchronize()
     for d0, d1 in zip(now, later):
         assert torch.equal(d0, d1)
+
+
+def test_gradient_allreduce_over_an_rccl_group_of_one(dev):
+    """The data-parallel training path with the default process group on RCCL ("nccl", one rank): the overlapped bucketed all-reduce
+    (parallel.GradReducer, fired from inside the backward pass) runs on RCCL's stream and the step equals the single-process step."""
+    import os
+    import torch.distributed as dist
+    from hsi_dmgasr_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    hr, sr, noise = (torch.from_numpy(synth_tensor("gddp.%s" % n, (2, 3, 16, 16))).to(dev) for n in ("hr", "sr", "noise"))
+    gamma = torch.tensor([0.55, 0.35])
+    sd, gd, tr0 = build(TINY, "tiny", "l1", "fp32", dev, True, lr=1e-3)
+    tr0.optimize_parameters({"HR": hr, "SR": sr}, noise=noise, gamma=gamma)
+    want = tr0.flat.clone()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sd, gd, tr = build(TINY, "tiny", "l1", "fp32", dev, True, lr=1e-3)
+        tr.bucket_bytes = 256 << 10
+        red = parallel.GradReducer(tr.grad, tr.bucket_bytes)
+        red.on = True                                     # a group of one: still send every bucket through RCCL
+        tr.reducer = red
+        tr.optimize_parameters({"HR": hr, "SR": sr}, noise=noise, gamma=gamma)
+        torch.cuda.synchronize()
+        assert len(red.buckets) > 3 and dist.get_backend() == "nccl"
+        assert torch.equal(tr.flat, want)
+    finally:
+        if created:
+            dist.destroy_process_group()
