@@ -187,8 +187,17 @@ __global__ __launch_bounds__(256) void gn_act_bwd_apply_kernel(const T* __restri
                                                                int C0, int C1, const float2* __restrict__ ab, const float2* __restrict__ mr,
                                                                const float2* __restrict__ gm, const float* __restrict__ gamma, int groups,
                                                                int silu_on, int HW, int64_t nvec, DropArgs dr, const T* __restrict__ add,
-                                                               T* __restrict__ dx0, T* __restrict__ dx1) {
+                                                               T* __restrict__ dx0, T* __restrict__ dx1, const float2* __restrict__ S, int B,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int C = C0 + C1, nv = C >> 3, cpg = C / groups;
+    if (blockIdx.x == 0) {              // parameter gradients: dgamma[c] = sum_b S2[b][c], dbeta[c] = sum_b S1[b][c] (one launch fewer)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double a = 0.0, d = 0.0;
+            for (int b = 0; b < B; ++b) { const float2 v = S[(size_t)b * C + c]; a += v.x; d += v.y; }
+            dbeta[c] = (float)a;
+            dgamma[c] = (float)d;
+        }
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         const int64_t bp = i / nv;
         const int c = (int)(i - bp * nv) * 8;
@@ -544,13 +553,12 @@ extern "C" int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, cons
     const int64_t nvec = (int64_t)B * HW * (C >> 3);
 #define RARGS(T) dim3(nsplit, B), dim3(256), 0, s, (const T*)da, (const T*)src0, (const T*)src1, C0, C1, ab, mr, groups, silu_on, HW, nsplit, dr, part
 #define AARGS(T) dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)da, (const T*)src0, (const T*)src1, C0, C1, ab, mr, (const float2*)gm, gamma, \
-                 groups, silu_on, HW, nvec, dr, (const T*)add, (T*)dx0, (T*)dx1
+                 groups, silu_on, HW, nvec, dr, (const T*)add, (T*)dx0, (T*)dx1, (const float2*)S, B, dgamma, dbeta
     if (prec == HSIDM_BF16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_reduce_kernel<bf16>), RARGS(bf16));
     else if (prec == HSIDM_F32X3) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_reduce_kernel<float>), RARGS(float));
     else return HSIDM_E_BADARG;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), (size_t)(2 * C + 512) * sizeof(float), s, (const float2*)part, nsplit, C, HW,
                        groups, gamma, S, gm);
-    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2*)S, B, C, dgamma, dbeta);
     if (prec == HSIDM_BF16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_apply_kernel<bf16>), AARGS(bf16));
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_bwd_apply_kernel<float>), AARGS(float));
 #undef RARGS

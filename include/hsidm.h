@@ -277,7 +277,7 @@ int hsidm_gn_act_apply(int prec, const void* src0, const void* src1, int C0, int
  *   dx = rstd * (gamma * dy - mean_g(gamma * dy) - xhat * mean_g(gamma * dy * xhat))  (+ add [B][HW][C0+C1]: gradients that reach x
  *   along other paths, e.g. the residual projection), written to the two halves of the concat (dx1 NULL when C1 == 0).
  * gn_ab: the full table of hsidm_gn_finalize (its (mean, rstd) part is read); gamma [C0+C1]; da NHWC [B][HW][C0+C1].
- * Four launches: per-(image, split, channel) sums, group means, parameter gradients, dx.  Deterministic.
+ * Three launches: per-(image, split, channel) sums; group means; dx (whose first workgroup also writes the parameter gradients).  Deterministic.
  * workspace: hsidm_gn_act_bwd_workspace_floats(B, C0+C1, groups, nsplit) floats. */
 int hsidm_gn_act_bwd_workspace_floats(int B, int C, int groups, int nsplit);
 int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, const void* src1, int C0, int C1, const float* gn_ab,
