@@ -5,7 +5,6 @@ the storage type of the precision mode (bf16 / fp32), fp32 everywhere else.  tor
 device memory and the current stream.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -219,28 +218,6 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
                                 stride=stride, ups=bool(ups), cin=pw.cin, cout=pw.cout, hw=(Ho, Wo),
                                 out_nchw=pw.out_nchw, tile=0 if Wo >= 16 else 1))
     return out
-
-
-_side = {"max_batch": int(os.environ.get("HSIDM_SIDE_BATCH", "64")), "streams": {}}      # (env: A/B measurements)
-
-
-def set_side_stream_batch(max_batch):
-    """Batches up to `max_batch` latents run a ResnetBlock's 1x1 residual projection on a second stream beside block1's
-    convolution (0: never).  Above ~64 latents the persistent convolutions occupy every CU and the overlap buys nothing
-    (measured at 120); below, a launch fills a fraction of the 512 workgroup slots."""
-    _side["max_batch"] = int(max_batch)
-
-
-def side_stream(batch, device):
-    """The second stream for this device when the batch is small enough, else None."""
-    if batch > _side["max_batch"] or device.type != "cuda":
-        return None
-    key = device.index
-    st = _side["streams"].get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side["streams"][key] = st
-    return st
 
 
 _conv_probe = None

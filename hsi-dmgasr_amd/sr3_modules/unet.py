@@ -192,30 +192,19 @@ class ResnetBlock(_HipModule):
         """x = cat(x0, x1) on channels (x1 may be None); film: [B, dim_out] slice of the FiLM table ([B, 2*dim_out] = (gamma | beta)
         with use_affine_level: h = (1 + gamma) * block1(x) + beta, reference unet.py:44-47, as its own pass - the reference's UNet
         never enables it, so it is not fused into the convolution's epilogue)."""
-        proj_launch = isinstance(self.res_conv, nn.Conv2d) and precision == "bf16" and ops.use_v2()
-        r, side = None, None
-        if proj_launch:
-            # throughput mode: the persistent 3x3 kernel is single-phase; the 1x1 projection is its own launch and enters
-            # block2's epilogue as the residual.  It only depends on x: at small batches, where a launch fills a fraction of the
-            # chip, it runs on a second stream BESIDE block1's convolution (a parallel branch of the captured step graph)
-            rc = self.res_conv
-            pk = self._cache.get(("proj", precision), [rc.weight, rc.bias], lambda: ops.PackedConv(rc.weight, rc.bias, precision))
-            side = ops.side_stream(x0.shape[0], x0.device)
-            if side is not None:
-                cur = torch.cuda.current_stream()
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    r = ops.conv2d(x0, pk, x1=x1)
-            else:
-                r = ops.conv2d(x0, pk, x1=x1)
         if self.noise_func.use_affine_level:
             h = ops.film_affine(self.block1._run(x0, precision, x1=x1), film.contiguous(), precision)
         else:
             h = self.block1._run(x0, precision, x1=x1, film=film)
         if isinstance(self.res_conv, nn.Conv2d):
-            if proj_launch:
-                if side is not None:
-                    torch.cuda.current_stream().wait_stream(side)
+            if precision == "bf16" and ops.use_v2():
+                # throughput mode: the persistent 3x3 kernel is single-phase; the 1x1 projection is its own launch and enters
+                # block2's epilogue as the residual.  (Measured and dropped, round 2: running it on a second stream beside block1's
+                # convolution - a parallel branch of the captured step - at batches that leave workgroup slots free: the fork / join
+                # costs more than the overlap returns, 2.98 vs 2.83 ms per step at 5 latents, 5.03 vs 4.93 at 40, in-box A/B.)
+                rc = self.res_conv
+                pk = self._cache.get(("proj", precision), [rc.weight, rc.bias], lambda: ops.PackedConv(rc.weight, rc.bias, precision))
+                r = ops.conv2d(x0, pk, x1=x1)
                 return self.block2._run(h, precision, res=r)
             return self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1)
         assert x1 is None
