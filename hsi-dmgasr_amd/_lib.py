@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("film", _vp), ("film_stride", _i32), ("res", _vp), ("res_scale", _f32), ("out", _vp),
                 ("stats", _vp), ("B", _i32), ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32),
                 ("Cout", _i32), ("ksize", _i32), ("stride", _i32), ("ups", _i32), ("act", _i32),
-                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32)]
+                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32), ("workspace", _vp), ("workspace_bytes", _i64)]
 
 
 class WgradItem(C.Structure):
@@ -45,6 +45,7 @@ SIGNATURES = {
     "hsidm_conv2d": [C.POINTER(ConvDesc), _vp],
     "hsidm_conv_stats_nsplit": [C.POINTER(ConvDesc)],
     "hsidm_conv_kernel_id": [C.POINTER(ConvDesc)],
+    "hsidm_conv_workspace_bytes": [C.POINTER(ConvDesc)],
     "hsidm_gn_partial": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "hsidm_gn_finalize": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "hsidm_noise_film": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
@@ -94,7 +95,7 @@ SIGNATURES = {
     "hsidm_gather_pack": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hsidm_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp],
 }
-RESTYPE_I64 = {"hsidm_conv_wgrad_workspace_bytes"}
+RESTYPE_I64 = {"hsidm_conv_wgrad_workspace_bytes", "hsidm_conv_workspace_bytes"}
 
 _lib = None
 

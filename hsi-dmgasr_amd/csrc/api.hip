@@ -20,6 +20,10 @@ int conv_v2_subs(int tile_kind, int bn);
 int conv_v2_slots();
 int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s);
 void conv_v2_set_stamps(unsigned long long* p);
+int conv_sk_parts(int B, int H, int W, int Cout, int nchunks);
+int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
+                const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
+                int Cout, int Cout_pad, int nchunks, float* workspace, hipStream_t s);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
                   int nch, int im_H, int im_W, hipStream_t s);
@@ -43,7 +47,22 @@ extern "C" const char* hsidm_error_string(int code) {
 
 extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
 
-enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4 };
+enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
+
+// Split-K form (conv_sk.hip): a bf16 3x3 stride-1 convolution whose persistent form would leave most workgroup slots empty
+// (tiles x slices <= a quarter of them) while every item walks >= 4 channel chunks.  Returns the number of K parts, 0 = not eligible.
+static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
+    const int xf = d->ph[0].transform;
+    if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || d->stride != 1 || d->ups ||
+        (xf != HSIDM_XF_NONE && xf != HSIDM_XF_AFFINE_SILU) || d->bn != 128 || d->Cout % 128 || (Hout & 7) || (Wout & 7) ||
+        d->act != HSIDM_ACT_NONE || debug_get(DBG_NO_SPLIT_K)) return 0;
+    const int nchunks = (d->ph[0].C0 + d->ph[0].C1 + 63) / 64;
+    if (nchunks < 4) return 0;
+    const int TW = Wout >= 16 ? 16 : 8;
+    const long long items = (long long)((d->B + (TW == 8)) / (TW == 8 ? 2 : 1)) * ((Wout + TW - 1) / TW) * ((Hout + 7) / 8) * (d->Cout / 128);
+    if (items * 4 > conv_v2_slots()) return 0;
+    return conv_sk_parts(d->B, Hout, Wout, d->Cout, nchunks);
+}
 
 // ---- diagnostic switches (common.h: DebugKey) ------------------------------------------------------
 namespace {
@@ -59,10 +78,11 @@ struct DebugTable {
         v[hsidm::DBG_1X1_V1] = (e && e[0] == 'v') ? 1 : 0;
         v[hsidm::DBG_V2_ABL] = env_int("HSIDM_V2_ABL", 0);
         v[hsidm::DBG_NO_FUSED_PROJ] = getenv("HSIDM_NO_FUSED_PROJ") ? 1 : 0;
+        v[hsidm::DBG_NO_SPLIT_K] = getenv("HSIDM_NO_SPLIT_K") ? 1 : 0;
     }
 };
 DebugTable g_debug;          // constructed when the library is loaded
-const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "NO_FUSED_PROJ"};
+const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "NO_FUSED_PROJ", "NO_SPLIT_K"};
 }  // namespace
 int hsidm::debug_get(int key) { return g_debug.v[key].load(std::memory_order_relaxed); }
 
@@ -136,6 +156,10 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
     }
+    if (path == PATH_V2 && d->workspace) {
+        const int parts = sk_parts(d, Hout, Wout);
+        if (parts > 0 && d->workspace_bytes >= (int64_t)parts * d->B * Hout * Wout * d->Cout * 4) path = PATH_SK;
+    }
     return HSIDM_OK;
 }
 
@@ -152,11 +176,23 @@ static int v2_slice(const hsidm_conv_desc* d, int Hout, int Wout, int tile_kind,
     return tiles * (d->Cout / 256) >= conv_v2_slots() / 4 ? 256 : d->bn;       // at least half of the CUs get an item
 }
 
+extern "C" int64_t hsidm_conv_workspace_bytes(const hsidm_conv_desc* d) {
+    int Hout, Wout, tile_kind, path;
+    hsidm_conv_desc probe = *d;
+    probe.workspace = nullptr;
+    const int rc = conv_validate(&probe, Hout, Wout, tile_kind, path);
+    if (rc != HSIDM_OK) return rc;
+    if (path != PATH_V2) return 0;
+    const int parts = sk_parts(d, Hout, Wout);
+    return (int64_t)parts * d->B * Hout * Wout * d->Cout * 4;
+}
+
 extern "C" int hsidm_conv_kernel_id(const hsidm_conv_desc* d) {
     int Hout, Wout, tile_kind, path;
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
     /* tile kinds: 0 8x16, 1 8x8 of two images, 2 8x8 of one; bits 8.. = couts per work item */
+    if (path == PATH_SK) return path | (2 << 4) | (128 << 8);          /* 8x8 tiles of one image, 128 couts per workgroup */
     return path | ((path == PATH_G1 ? 0 : tile_kind) << 4) | (v2_slice(d, Hout, Wout, tile_kind, path) << 8);
 }
 
@@ -166,7 +202,7 @@ extern "C" int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d) {
     if (rc != HSIDM_OK) return rc;
     if (d->out_nchw) return HSIDM_E_UNSUPPORTED;
     if (path == PATH_V3) return (Hout / 16) * (Wout / 16) * 2;
-    if (path == PATH_G1) return Hout * Wout / 64;
+    if (path == PATH_G1 || path == PATH_SK) return Hout * Wout / 64;
     const bool use_v2 = path == PATH_V2;
     const int TW = tile_kind == 0 ? 16 : 8;
     if (d->ups == HSIDM_UPS_FOLDED)      // one entry per (input tile, parity, wave row)
@@ -221,6 +257,15 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
                              d->res_scale, reinterpret_cast<bf16*>(d->out), reinterpret_cast<float2*>(d->stats), d->B * Hout * Wout,
                              Hout * Wout, d->Cout, d->ksize == 3 ? 2 : (s0.C0 + s0.C1 + 127) / 128 * 2, d->ksize == 3 ? Hout : 0,
                              d->ksize == 3 ? Wout : 0, s);
+    }
+    if (path == PATH_SK) {
+        const hsidm_conv_phase& s0 = d->ph[0];
+        return conv_sk_run(reinterpret_cast<const bf16*>(s0.src0), reinterpret_cast<const bf16*>(s0.C1 > 0 ? s0.src1 : nullptr), s0.C0, s0.C1,
+                           reinterpret_cast<const float2*>(s0.transform != HSIDM_XF_NONE ? s0.gn_ab : nullptr),
+                           s0.transform == HSIDM_XF_AFFINE_SILU, reinterpret_cast<const bf16*>(d->w_v2), d->bias, d->film, d->film_stride,
+                           reinterpret_cast<const bf16*>(d->res), d->res_scale, reinterpret_cast<bf16*>(d->out),
+                           reinterpret_cast<float2*>(d->stats), d->B, Hout, Wout, d->Cout, cout_pad, p.ph[0].nchunks,
+                           reinterpret_cast<float*>(d->workspace), s);
     }
     if (use_v2) {
         ConvV2Params v;

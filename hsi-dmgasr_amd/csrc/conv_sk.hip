@@ -1,0 +1,233 @@
+// conv_sk: split-K form of the bf16 3x3 stride-1 convolution for launches with FEW pixel tiles and a LONG contraction - the 8x8 and
+// 16x16 levels of the UNet (Cin 512...1024, Cout 512) at small batches: one CAVE image (5 latents), the 8-GPU shard of configs[3]
+// (40 latents), a training step (4 latents, forward and input gradient).
+//
+// Why: the persistent kernel (conv_v2.h) gives such a launch tiles x slices work items - 20 at 5 latents on the 8x8 level, 80 at 40 -
+// for 512 workgroup slots, and every item walks the whole contraction: 9 taps x 16 chunks in sequence.  Measured at 5 latents
+// (profiles/r02_small_batch/conv_bench_b5.txt): 8x8 level 1024 -> 512 in 78.6 us = 38 TFLOP/s, the two deep levels 1.0 ms of a
+// 2.83 ms step.  The contraction is the only axis left to parallelise.
+//
+// Here a workgroup owns (64 pixels of one image) x (128 couts) x (a RANGE of 64-channel chunks, all 9 taps): grid = tiles x slices x
+// parts.  Partial sums go to an fp32 workspace [part][pixel][cout] with plain stores, and conv_sk_finish adds the parts in order
+// and applies the epilogue the fused kernel has (bias, FiLM, residual, bf16 store, GroupNorm statistics of the stored tensor):
+// deterministic, no atomics.  Operand formats are the persistent kernel's: NHWC activations (two-pointer concat, GroupNorm + SiLU
+// applied while staging), weights in the register-streaming order w_v2 (one contiguous 1 KiB per wave-load of an MFMA B fragment).
+#include "conv_v2.h"
+#include "../../include/hsidm.h"
+
+namespace hsidm {
+
+struct ConvSkParams {
+    const bf16* src0; const bf16* src1;
+    const float2* gn_ab;            // fp32 (scale, shift) pairs [B][C0+C1], or null
+    const bf16* w;                  // w_v2 layout
+    float* partial;                 // [parts][B*H*W][Cout]
+    int C0, C1, nchunks, cpp;       // chunks of 64 channels; chunks per part
+    int B, H, W, Cout, Cout_pad;
+    int tiles_x, tiles_y;
+    int silu;
+};
+
+namespace sk {
+constexpr int TH = 8, TW = 8, HR = TH + 2, HC = TW + 2, HPIX = HR * HC, PSTR = 72, VPP = 8;
+constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;            // 800 vectors, 4 per thread (the last round partial)
+}  // namespace sk
+
+__global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
+    using namespace sk;
+    __shared__ __attribute__((aligned(16))) bf16 halo[HPIX * PSTR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tile = blockIdx.x, slice = blockIdx.y, part = blockIdx.z;
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int b = tile / tpi, tr = tile - b * tpi;
+    const int ty0 = (tr / p.tiles_x) * TH, tx0 = (tr % p.tiles_x) * TW;
+    const int ctot = p.C0 + p.C1;
+    const int c_begin = part * p.cpp, c_end = min(p.nchunks, c_begin + p.cpp);
+
+    // weight fragments of this wave's 32 couts: [step][Cout_pad/32][kk][lane][8]
+    const int nsw = p.Cout_pad >> 5;
+    const bf16* wlane = p.w + ((size_t)(slice * 4 + wave) * 4 * 64 + lane) * 8;
+    const size_t wstep = (size_t)nsw * 4 * 64 * 8;
+
+    // A fragment base of the two 32-pixel MFMA tiles (tile rows 4 mt .. 4 mt + 3): lane = (row lr / 8, column lr % 8), k half lh
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) abase[mt] = ((4 * mt + (lr >> 3)) * HC + (lr & 7)) * PSTR + 8 * lh;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
+
+    const int cv = tid & 7;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        // ---- stage the 10 x 10 halo of this chunk's 64 channels (GroupNorm + SiLU on the way; zero padding AFTER the activation) ----
+        const int c = chunk * 64 + cv * 8;
+        const bool cok = c < ctot;
+        const int cc = cok ? c : 0;
+        const bf16* src;
+        int cs, cl;
+        if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; } else { src = p.src1; cs = p.C1; cl = cc - p.C0; }
+        float sc[8], sh[8];
+        if (p.gn_ab) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float2 ab = p.gn_ab[(size_t)b * ctot + cc + k]; sc[k] = ab.x; sh[k] = ab.y; }
+        }
+        __syncthreads();                                         // the previous chunk's readers are done
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) {
+            const int hp = (tid >> 3) + i * 32;
+            if (hp < HPIX) {
+                const int hy = hp / HC, hx = hp - hy * HC;
+                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                const bool ok = cok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                u32x4 raw = {0u, 0u, 0u, 0u};
+                if (ok) raw = *reinterpret_cast<const u32x4*>(src + ((size_t)(b * p.H + iy) * p.W + ix) * cs + cl);
+                if (ok && p.gn_ab) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(raw[k] << 16); v[2 * k + 1] = __uint_as_float(raw[k] & 0xffff0000u); }
+                    bf16x8 o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float u = fmaf(v[k], sc[k], sh[k]);
+                        o[k] = (bf16)(p.silu ? silu_fast(u) : u);
+                    }
+                    raw = __builtin_bit_cast(u32x4, o);
+                }
+                *reinterpret_cast<u32x4*>(halo + hp * PSTR + cv * 8) = raw;
+            }
+        }
+        __syncthreads();
+        // ---- 9 taps x 4 k-slices; the weights of a tap are requested one tap ahead ----
+        const bf16* wc = wlane + (size_t)chunk * 9 * wstep;
+        bf16x8 wr[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *reinterpret_cast<const bf16x8*>(wc + kk * 64 * 8);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) wr[(tap + 1) & 1][kk] = *reinterpret_cast<const bf16x8*>(wc + (size_t)(tap + 1) * wstep + kk * 64 * 8);
+            }
+            const int toff = ((tap / 3) * HC + (tap % 3)) * PSTR;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + abase[mt] + toff + kk * 16);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[tap & 1][kk], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial sums: register j of a lane = tile pixel (j&3) + 8(j>>2) + 4 lh of its 32-pixel MFMA tile, column = cout ----
+    const int n = slice * 128 + wave * 32 + lr;
+    if (n < p.Cout) {
+        float* dst = p.partial + (size_t)part * p.B * p.H * p.W * p.Cout;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int pr = (j & 3) + 8 * (j >> 2) + 4 * lh;
+                const int y = ty0 + 4 * mt + (pr >> 3), x = tx0 + (pr & 7);
+                if (y < p.H && x < p.W) dst[((size_t)(b * p.H + y) * p.W + x) * p.Cout + n] = acc[mt][j];
+            }
+    }
+}
+
+// out = res_scale * (sum of the parts + bias + FiLM) + res, rounded to bf16; statistics slab [B][HW/64][Cout] of what was stored.
+// grid (HW / 64, B, Cout / 64): a workgroup owns 64 pixels x 64 channels; thread = (channel vector of 8, pixel row of 32).
+__global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ bias,
+                                                             const float* __restrict__ film, int film_stride, const bf16* __restrict__ res,
+                                                             float res_scale, bf16* __restrict__ out, float2* __restrict__ stats, int B, int HW,
+                                                             int Cout) {
+    __shared__ float red[32][64][2];
+    const int grp = blockIdx.x, b = blockIdx.y, cg = blockIdx.z;
+    const int t = threadIdx.x, cvi = t & 7, prow = t >> 3;
+    const int c = cg * 64 + cvi * 8;
+    const size_t plane = (size_t)B * HW * Cout;
+    float s1[8], s2[8], add[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s1[k] = s2[k] = 0.f;
+        add[k] = (bias ? bias[c + k] : 0.f) + (film ? film[(size_t)b * film_stride + c + k] : 0.f);
+    }
+    for (int pl = prow; pl < 64; pl += 32) {
+        const int pix = grp * 64 + pl;
+        if (pix >= HW) break;
+        const size_t off = ((size_t)b * HW + pix) * Cout + c;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        for (int q = 0; q < nparts; ++q) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(partial + (size_t)q * plane + off);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(partial + (size_t)q * plane + off + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += a0[k]; v[4 + k] += a1[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = res_scale * (v[k] + add[k]);
+        if (res) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)r[k];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o[k] = (bf16)v[k];
+            s1[k] += v[k];
+            s2[k] = fmaf(v[k], v[k], s2[k]);
+        }
+        *reinterpret_cast<bf16x8*>(out + off) = o;
+    }
+    if (stats) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[prow][cvi * 8 + k][0] = s1[k]; red[prow][cvi * 8 + k][1] = s2[k]; }
+        __syncthreads();
+        if (t < 64) {
+            float a = 0.f, d = 0.f;
+            for (int r = 0; r < 32; ++r) { a += red[r][t][0]; d += red[r][t][1]; }
+            stats[((size_t)b * gridDim.x + grp) * Cout + cg * 64 + t] = make_float2(a, d);
+        }
+    }
+}
+
+// chunks per part: about four workgroups per CU over the launch, at least one chunk each
+static int sk_cpp(int tiles, int slices, int nchunks) {
+    const int want = 4 * device_cus();
+    int parts = (want + tiles * slices - 1) / (tiles * slices);
+    if (parts > nchunks) parts = nchunks;
+    if (parts < 1) parts = 1;
+    return (nchunks + parts - 1) / parts;
+}
+
+int conv_sk_parts(int B, int H, int W, int Cout, int nchunks) {
+    const int tiles = B * (H / 8) * (W / 8), slices = Cout / 128;
+    const int cpp = sk_cpp(tiles, slices, nchunks);
+    return (nchunks + cpp - 1) / cpp;
+}
+
+int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
+                const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
+                int Cout, int Cout_pad, int nchunks, float* workspace, hipStream_t s) {
+    ConvSkParams p;
+    p.src0 = src0; p.src1 = src1; p.gn_ab = gn_ab; p.w = w; p.partial = workspace;
+    p.C0 = C0; p.C1 = C1; p.nchunks = nchunks;
+    p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.Cout_pad = Cout_pad;
+    p.tiles_x = W / 8; p.tiles_y = H / 8;
+    p.silu = silu;
+    const int tiles = B * p.tiles_x * p.tiles_y, slices = Cout / 128;
+    p.cpp = sk_cpp(tiles, slices, nchunks);
+    const int parts = (nchunks + p.cpp - 1) / p.cpp;
+    hipLaunchKernelGGL(conv_sk_kernel, dim3(tiles, slices, parts), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(conv_sk_finish_kernel, dim3(H * W / 64, B, Cout / 64), dim3(256), 0, s, (const float*)workspace, parts, bias, film,
+                       film_stride, res, res_scale, out, stats, B, H * W, Cout);
+    return (int)hipGetLastError();
+}
+
+}  // namespace hsidm

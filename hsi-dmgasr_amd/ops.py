@@ -195,6 +195,12 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         slab = torch.empty((B, nsplit, pw.cout, 2), dtype=torch.float32, device=x0.device)
         d.stats = _lib.ptr(slab)
         out._hsidm_stats = (slab, nsplit)
+    if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and stride == 1 and not ups and pw.bn == 128 and pw.cin >= 200:
+        # few pixel tiles x a long contraction (the 8x8 / 16x16 levels at small batches): the split-K form needs scratch
+        nb = _lib.lib().hsidm_conv_workspace_bytes(C.byref(d))
+        if nb > 0:
+            ws = _sk_workspace(int(nb), x0.device)
+            d.workspace, d.workspace_bytes = _lib.ptr(ws), ws.numel()
     trk = getattr(pw, "_track", None)
     if trk is not None:     # the training step records which packed layout the dispatch reads (training.Trainer._prune_layouts)
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
@@ -208,7 +214,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         e1.record()
         k_total = pw.cin * (4 if folded else (16 if planes else pw.ksize * pw.ksize)) + pw.proj_cin      # multiplications actually executed
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
-        label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "-", "conv1x1_g", "conv_v3")[kid & 15], kid >> 8,
+        label = "%s bn%d %s k%d s%d%s%s" % (("conv_igemm", "conv_v2", "-", "conv1x1_g", "conv_v3", "conv_sk")[kid & 15], kid >> 8,
                                             ("8x16", "8x8x2", "8x8")[(kid >> 4) & 3], pw.ksize, stride,
                                             " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else "") +
                                             (" up4" if folded else (" ups" if ups else (" dn4" if planes else ""))),
@@ -218,6 +224,19 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
                                 stride=stride, ups=bool(ups), cin=pw.cin, cout=pw.cout, hw=(Ho, Wo),
                                 out_nchw=pw.out_nchw, tile=0 if Wo >= 16 else 1))
     return out
+
+
+_sk_ws = {}
+
+
+def _sk_workspace(nbytes, dev):
+    """One growing scratch buffer per device for the split-K partial sums (written and consumed inside one hsidm_conv2d call, so
+    stream order makes sharing it between launches safe; it must exist before a step is captured: the eager first step sizes it)."""
+    buf = _sk_ws.get(dev.index)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _sk_ws[dev.index] = buf
+    return buf
 
 
 _conv_probe = None

@@ -44,7 +44,7 @@ extern "C" {
 int hsidm_version(void);
 const char* hsidm_error_string(int code);
 /* Diagnostic dispatch switches for A/B measurements and tests: "NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1",
- * "V2_ABL", "NO_FUSED_PROJ".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
+ * "V2_ABL", "NO_FUSED_PROJ", "NO_SPLIT_K".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
  * reads the environment.  Returns the previous value (>= 0) or HSIDM_E_BADARG for an unknown name. */
 int hsidm_debug_switch(const char* name, int value);
 
@@ -113,13 +113,19 @@ typedef struct hsidm_conv_desc {
     int32_t out_nchw;         /* 1: write NCHW fp32 (network outputs)                               */
     int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3                                           */
     int32_t bn;               /* cout slice the weights were packed for: 32, 64 or 128             */
+    void*   workspace;        /* optional scratch of hsidm_conv_workspace_bytes(d) bytes: enables the split-K form
+                                 (csrc/conv_sk.hip) for launches with few pixel tiles and a long contraction -
+                                 the 8x8 / 16x16 levels at small batches; NULL: the persistent kernels only    */
+    int64_t workspace_bytes;
 } hsidm_conv_desc;
 
 int hsidm_conv2d(const hsidm_conv_desc* d, void* stream);
+/* Scratch bytes with which hsidm_conv2d(d) would take its split-K form (0: it would not, whatever the workspace). */
+int64_t hsidm_conv_workspace_bytes(const hsidm_conv_desc* d);
 /* Number of partial entries per image that hsidm_conv2d(d) writes into d->stats (>0), or an error code. */
 int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d);
 /* Which kernel hsidm_conv2d(d) dispatches to, for measurement tools: bits 0-3 = 0 LDS-tiled (conv_igemm), 1 persistent 3x3
- * (conv_v2), 3 LDS-staged 1x1 GEMM (conv1x1_g), 4 256-pixel 3x3 (conv_v3); bits 4-5 = tile (0: 8x16, 1: 8x8 of two images, 2: 8x8 of one image); bits 8.. = couts per work item (256: the 8-wave form of a 128-packed GroupNorm+SiLU conv).
+ * (conv_v2), 3 LDS-staged 1x1 GEMM (conv1x1_g), 4 256-pixel 3x3 (conv_v3), 5 split-K 3x3 (conv_sk, only with d->workspace); bits 4-5 = tile (0: 8x16, 1: 8x8 of two images, 2: 8x8 of one image); bits 8.. = couts per work item (256: the 8-wave form of a 128-packed GroupNorm+SiLU conv).
  * <0 on error. */
 int hsidm_conv_kernel_id(const hsidm_conv_desc* d);
 /* K-chunk (input channels per packed step) of a precision mode: 64 for BF16, 32 for F32X3. */

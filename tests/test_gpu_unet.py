@@ -476,6 +476,52 @@ def test_256_cout_items_on_8_waves_match_the_128_cout_form(dev, monkeypatch, cas
     assert torch.equal(slabs[0], slabs[1])
 
 
+SK_CASES = [  # B, H, W, C0, C1, Cout, xf, residual
+    (5, 8, 8, 512, 512, 512, True, True),      # the 8x8 level's 1024 -> 512 block at one CAVE image: 16 chunks over 16 parts
+    (5, 16, 16, 512, 0, 512, True, False),     # 16x16 level
+    (4, 8, 8, 512, 0, 1024, False, False),     # an input-gradient convolution of the training step (no transform)
+    (3, 8, 16, 256, 72, 128, True, True),      # ragged last chunk (328 channels), non-square map, one cout slice
+    (40, 8, 8, 512, 0, 512, True, False),      # the 8-GPU shard of configs[3]
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_split_k_convolution_matches_the_persistent_kernel(dev, case):
+    """conv_sk (split over the contraction, fp32 partial sums, finishing kernel) against conv_v2 on the same inputs (debug switch
+    NO_SPLIT_K) and against torch; output, dispatch label and statistics slab."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, C0, C1, Co, xf, with_res = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    w = torch.randn(Co, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pk = ops.PackedConv(w.to(dev), bias.to(dev), "bf16")
+    x0 = torch.randn(B, H, W, C0, generator=g).to(dev, torch.bfloat16)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
+    res = torch.randn(B, H, W, Co, generator=g).to(dev, torch.bfloat16) if with_res else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, C0 + C1, generator=g), 0.1 * torch.randn(B, C0 + C1, generator=g)], 2).contiguous()
+    film = torch.randn(B, Co, generator=g).to(dev)
+    outs, labels = [], []
+    for no_sk in (1, 0):
+        recs = []
+        with _lib.debug_switch("NO_SPLIT_K", no_sk):
+            ops.set_conv_probe(recs)
+            y = ops.conv2d(x0, pk, x1=x1, gn_ab=ops.gn_table(ab.to(dev)) if xf else None,
+                           transform=ops.XF_AFFINE_SILU if xf else ops.XF_NONE, film=film, res=res, stats=True)
+            ops.set_conv_probe(None)
+            torch.cuda.synchronize()
+        slab, nsplit = y._hsidm_stats
+        assert_stats(slab, y, no_sk)
+        outs.append(y.float().cpu())
+        labels.append(recs[-1]["kernel"])
+    assert labels[0].startswith("conv_v2") and labels[1].startswith("conv_sk"), labels
+    check("conv_sk_vs_v2%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
+    xin = torch.cat([x0, x1], dim=3).float().cpu() if C1 else x0.float().cpu()
+    a = torch.nn.functional.silu(xin * ab[:, None, None, :, 0] + ab[:, None, None, :, 1]).to(torch.bfloat16).float() if xf else xin
+    want = torch.nn.functional.conv2d(a.permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), bias, padding=1) + film.cpu()[:, :, None, None]
+    want = want.permute(0, 2, 3, 1) + (res.float().cpu() if with_res else 0)
+    check("conv_sk_vs_torch%s" % (case,), "bf16", outs[1], want, tol=6e-3)
+
+
 def test_final_block_conv_on_the_256_pixel_kernel(dev, monkeypatch):
     """The UNet's last conv (GroupNorm + SiLU + 3x3, 64 -> 3, fp32 NCHW out; reference unet.py:231,262) on conv_v3<WN = 1, NCHW>
     against the generic kernel (HSIDM_NO_V3=1) and against torch fp32."""
