@@ -188,6 +188,13 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
     d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, (UPS_FOLDED if folded else int(bool(ups))), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
+    if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and stride == 1 and not ups and pw.bn == 128 and pw.cin >= 200:
+        # few pixel tiles x a long contraction (the 8x8 / 16x16 levels at small batches): the split-K form needs scratch
+        # (set before the statistics query: the slab's split count depends on the kernel the dispatch picks)
+        nb = _lib.lib().hsidm_conv_workspace_bytes(C.byref(d))
+        if nb > 0:
+            ws = _sk_workspace(int(nb), x0.device)
+            d.workspace, d.workspace_bytes = _lib.ptr(ws), ws.numel()
     if stats and not pw.out_nchw:
         nsplit = _lib.lib().hsidm_conv_stats_nsplit(C.byref(d))
         if nsplit <= 0:
@@ -195,12 +202,6 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         slab = torch.empty((B, nsplit, pw.cout, 2), dtype=torch.float32, device=x0.device)
         d.stats = _lib.ptr(slab)
         out._hsidm_stats = (slab, nsplit)
-    if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and stride == 1 and not ups and pw.bn == 128 and pw.cin >= 200:
-        # few pixel tiles x a long contraction (the 8x8 / 16x16 levels at small batches): the split-K form needs scratch
-        nb = _lib.lib().hsidm_conv_workspace_bytes(C.byref(d))
-        if nb > 0:
-            ws = _sk_workspace(int(nb), x0.device)
-            d.workspace, d.workspace_bytes = _lib.ptr(ws), ws.numel()
     trk = getattr(pw, "_track", None)
     if trk is not None:     # the training step records which packed layout the dispatch reads (training.Trainer._prune_layouts)
         kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
