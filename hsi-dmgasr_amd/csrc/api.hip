@@ -50,7 +50,7 @@ extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec 
 enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 
 // Split-K form (conv_sk.hip): a bf16 3x3 stride-1 convolution whose persistent form would leave most workgroup slots empty
-// (tiles x slices <= a quarter of them) while every item walks >= 4 channel chunks.  Returns the number of K parts, 0 = not eligible.
+// (tiles x slices <= an eighth of them) while every item walks >= 4 channel chunks.  Returns the number of K parts, 0 = not eligible.
 static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     const int xf = d->ph[0].transform;
     if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || d->stride != 1 || d->ups ||
@@ -60,7 +60,10 @@ static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     if (nchunks < 4) return 0;
     const int TW = Wout >= 16 ? 16 : 8;
     const long long items = (long long)((d->B + (TW == 8)) / (TW == 8 ? 2 : 1)) * ((Wout + TW - 1) / TW) * ((Hout + 7) / 8) * (d->Cout / 128);
-    if (items * 4 > conv_v2_slots()) return 0;
+    // measured (profiles/r02_small_batch/sk_conv_bench.txt): the split form runs at ~400 TFLOP/s whatever the shape; the persistent
+    // kernel passes that once it has ~80 work items (8x8 level at 40 latents: 55 us vs 61 us), and falls to 37-170 TFLOP/s below
+    // 40 (8x8 / 16x16 levels at 5 latents: 81 -> 37 us, 72 -> 43 us)
+    if (items * 8 > conv_v2_slots()) return 0;
     return conv_sk_parts(d->B, Hout, Wout, d->Cout, nchunks);
 }
 
