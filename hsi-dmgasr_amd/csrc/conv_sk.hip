@@ -64,6 +64,14 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
 
     const int cv = tid & 7;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        // the chunk's 36 weight fragments (9 taps x 4 k-slices, 1 KiB per wave-load) are requested first: their L2 latency hides
+        // behind the staging of the halo tile (a one-tap-ahead ring was latency-bound: 8 MFMAs per tap against ~0.7 us per fetch)
+        const bf16* wc = wlane + (size_t)chunk * 9 * wstep;
+        bf16x8 wr[9][4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const bf16x8*>(wc + (size_t)tap * wstep + kk * 64 * 8);
         // ---- stage the 10 x 10 halo of this chunk's 64 channels (GroupNorm + SiLU on the way; zero padding AFTER the activation) ----
         const int c = chunk * 64 + cv * 8;
         const bool cok = c < ctot;
@@ -102,24 +110,16 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
             }
         }
         __syncthreads();
-        // ---- 9 taps x 4 k-slices; the weights of a tap are requested one tap ahead ----
-        const bf16* wc = wlane + (size_t)chunk * 9 * wstep;
-        bf16x8 wr[2][4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *reinterpret_cast<const bf16x8*>(wc + kk * 64 * 8);
+        // ---- 9 taps x 4 k-slices ----
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) wr[(tap + 1) & 1][kk] = *reinterpret_cast<const bf16x8*>(wc + (size_t)(tap + 1) * wstep + kk * 64 * 8);
-            }
             const int toff = ((tap / 3) * HC + (tap % 3)) * PSTR;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + abase[mt] + toff + kk * 16);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[tap & 1][kk], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[tap][kk], acc[mt], 0, 0, 0);
                 }
             }
         }
@@ -140,15 +140,15 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
 }
 
 // out = res_scale * (sum of the parts + bias + FiLM) + res, rounded to bf16; statistics slab [B][HW/64][Cout] of what was stored.
-// grid (HW / 64, B, Cout / 64): a workgroup owns 64 pixels x 64 channels; thread = (channel vector of 8, pixel row of 32).
+// grid (HW / 64, B, Cout / 32): a workgroup owns 64 pixels x 32 channels; thread = (channel vector of 8, pixel).
 __global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ bias,
                                                              const float* __restrict__ film, int film_stride, const bf16* __restrict__ res,
                                                              float res_scale, bf16* __restrict__ out, float2* __restrict__ stats, int B, int HW,
                                                              int Cout) {
-    __shared__ float red[32][64][2];
+    __shared__ float red[64][32][2];
     const int grp = blockIdx.x, b = blockIdx.y, cg = blockIdx.z;
-    const int t = threadIdx.x, cvi = t & 7, prow = t >> 3;
-    const int c = cg * 64 + cvi * 8;
+    const int t = threadIdx.x, cvi = t & 3, prow = t >> 2;
+    const int c = cg * 32 + cvi * 8;
     const size_t plane = (size_t)B * HW * Cout;
     float s1[8], s2[8], add[8];
 #pragma unroll
@@ -156,9 +156,8 @@ __global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __rest
         s1[k] = s2[k] = 0.f;
         add[k] = (bias ? bias[c + k] : 0.f) + (film ? film[(size_t)b * film_stride + c + k] : 0.f);
     }
-    for (int pl = prow; pl < 64; pl += 32) {
-        const int pix = grp * 64 + pl;
-        if (pix >= HW) break;
+    {
+        const int pix = grp * 64 + prow;
         const size_t off = ((size_t)b * HW + pix) * Cout + c;
         float v[8];
 #pragma unroll
@@ -189,10 +188,10 @@ __global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 8; ++k) { red[prow][cvi * 8 + k][0] = s1[k]; red[prow][cvi * 8 + k][1] = s2[k]; }
         __syncthreads();
-        if (t < 64) {
+        if (t < 32) {
             float a = 0.f, d = 0.f;
-            for (int r = 0; r < 32; ++r) { a += red[r][t][0]; d += red[r][t][1]; }
-            stats[((size_t)b * gridDim.x + grp) * Cout + cg * 64 + t] = make_float2(a, d);
+            for (int r = 0; r < 64; ++r) { a += red[r][t][0]; d += red[r][t][1]; }
+            stats[((size_t)b * gridDim.x + grp) * Cout + cg * 32 + t] = make_float2(a, d);
         }
     }
 }
@@ -225,7 +224,7 @@ int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2
     p.cpp = sk_cpp(tiles, slices, nchunks);
     const int parts = (nchunks + p.cpp - 1) / p.cpp;
     hipLaunchKernelGGL(conv_sk_kernel, dim3(tiles, slices, parts), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(conv_sk_finish_kernel, dim3(H * W / 64, B, Cout / 64), dim3(256), 0, s, (const float*)workspace, parts, bias, film,
+    hipLaunchKernelGGL(conv_sk_finish_kernel, dim3(H * W / 64, B, Cout / 32), dim3(256), 0, s, (const float*)workspace, parts, bias, film,
                        film_stride, res, res_scale, out, stats, B, H * W, Cout);
     return (int)hipGetLastError();
 }
