@@ -63,7 +63,8 @@ static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     // measured (profiles/r02_small_batch/sk_conv_bench.txt): the split form runs at ~400 TFLOP/s whatever the shape; the persistent
     // kernel passes that once it has ~80 work items (8x8 level at 40 latents: 55 us vs 61 us), and falls to 37-170 TFLOP/s below
     // 40 (8x8 / 16x16 levels at 5 latents: 81 -> 37 us, 72 -> 43 us)
-    if (items * 8 > conv_v2_slots()) return 0;
+    // (two-image 8x8 tiles keep the persistent kernel efficient down to fewer items than one-image 8x16 tiles do)
+    if (items * (TW == 8 ? 8 : 4) > conv_v2_slots()) return 0;
     return conv_sk_parts(d->B, Hout, Wout, d->Cout, nchunks);
 }
 
