@@ -250,6 +250,18 @@ def train_bench(dev, batch=4, steps=10, warm=3, precisions=("bf16", "fp32"), red
     return out
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when its first communicator comes up; left in the C buffer it would be
+    flushed at process exit, i.e. AFTER rank 0's JSON line.  Flushing every rank's C buffers right after the first collective
+    keeps the JSON line the last line of the job's stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a plain shell: re-run under torch.distributed.run as a CHILD process (never exec:
     nothing here has touched the GPU yet, and nothing will in this parent)."""
@@ -276,6 +288,10 @@ def main_train(args, dev, rank, world, use_dist):
     gd.set_loss(dev)
     gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), dev)
     parallel.broadcast_module_(gd, src=0)
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+        flush_c_stdio()
     tr = gd.trainer(lr=1e-5)
     g = torch.Generator().manual_seed(5 + rank)
     data = {"HR": torch.randn((B, 3, 128, 128), generator=g).clamp(-2.5, 2.5).to(dev),
@@ -364,6 +380,10 @@ def main():
     gd = build_model(dev, args.precision)
     log('model on device')
     parallel.broadcast_module_(gd, src=0)                  # one-time weight broadcast over xGMI
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+        flush_c_stdio()
     if args.total_patches:
         lo, hi = parallel.shard_range(args.total_patches, rank, world)
         patches, total_patches, scaling = hi - lo, args.total_patches, "strong"
@@ -472,7 +492,8 @@ def main():
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": allgather_ms,
             "roofline": roof, "fp32_mode": fp32, "gae": gae_rec, "train_step": train_rec, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        flush_c_stdio()
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
