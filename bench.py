@@ -99,6 +99,20 @@ def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1):
                     algorithmic_bytes=hb["bytes"], achieved_GBps=hb["bytes"] / (hb["ms"] * 1e-3) / 1e9, peak_GBps=HBM_PEAK_GBPS,
                     frac=hb["bytes"] / (hb["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     tflops=hb["flops"] / (hb["ms"] * 1e-3) / 1e12)
+    # the same ResnetBlock under SURVEY 8(d)'s FUSED-unit byte definition (input read once, output written once, both convs'
+    # weights; the intermediate h does not count) over the time of its two conv launches - GroupNorm 2 needs the global
+    # statistics of h, so the block is two launches here and this fraction is about half of the two-kernel one
+    pair = next(((a, b) for a, b in zip(best, best[1:]) if a["kernel"] == hb["kernel"] == b["kernel"] and
+                 (a["cin"], a["cout"], b["cin"], b["cout"]) == (hb["cin"], hb["cout"], hb["cout"], hb["cout"]) and
+                 tuple(a["hw"]) == tuple(hb["hw"]) == tuple(b["hw"])), None)
+    if pair is not None:
+        a, b = pair
+        esz = 4 if passes > 1 else 2                             # bytes per stored element (fp32 mode: fp32 storage, hi + lo weights)
+        px = batch * hb["hw"][0] * hb["hw"][1]
+        fb = esz * px * (a["cin"] + b["cout"]) + esz * 9 * (a["cin"] * a["cout"] + b["cin"] * b["cout"])
+        ft = (a["ms"] + b["ms"]) * 1e-3
+        hbm_view["fused_unit"] = dict(definition="SURVEY 8(d) fused ResnetBlock: in + out + both weights, h not counted",
+                                      algorithmic_bytes=fb, us=ft * 1e6, achieved_GBps=fb / ft / 1e9, frac=fb / ft / 1e9 / HBM_PEAK_GBPS)
     return dict(bound="mfma", hbm_view=hbm_view, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, mfma_passes_per_product=passes,
                 traffic=traffic, kernel=name, launches=dom["n"], avg_launch_us=dom["ms"] / dom["n"] * 1e3,
                 algorithmic_flops_per_launch=dom["flops"] / dom["n"], algorithmic_bytes_per_launch=dom["bytes"] / dom["n"],
