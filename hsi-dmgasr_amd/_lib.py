@@ -78,8 +78,8 @@ SIGNATURES = {
     "hsidm_gn_act_bwd": [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u64, _vp, _u32, _i32, _vp, _vp, _vp,
                          _vp, _vp, _vp, _vp],
     "hsidm_conv_wgrad_workspace_bytes": [_i32] * 11,
-    "hsidm_conv_wgrad": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
-                         _i64, _vp],
+    "hsidm_conv_wgrad": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
+                         _vp, _vp, _i64, _vp],
     "hsidm_conv_wgrad_plan": [_i32] * 11 + [_vp],
     "hsidm_wgrad_reduce_all": [_vp, _i32, _i32, _vp],
     "hsidm_add": [_i32, _vp, _vp, _vp, _i64, _vp],

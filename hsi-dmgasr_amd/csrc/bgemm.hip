@@ -23,59 +23,100 @@ __device__ __forceinline__ float ld_elem(const void* p, int64_t i, int is_f32) {
 }
 
 // C[b] (M x N, row-major, unit column stride) = alpha * A[b] (M x K) * B[b] (K x N).
-// Workgroup = one 32 x 32 tile of C, its four waves split every 64-deep K chunk four ways (16 k each = 8 MFMAs) and meet in
-// LDS at the end: the attention backward's products are 256 x 256 ... 512 per image at batch 4, so 64 x 64 tiles would be 64
-// workgroups on 256 CUs; 32 x 32 tiles with the K split inside the workgroup give 256-512 of them at the same staging cost.
-__global__ __launch_bounds__(256) void bgemm_kernel(GemmParams p) {
-    constexpr int KC = 64, PITCH = 33;
-    __shared__ float As[KC * PITCH], Bs[KC * PITCH];
-    __shared__ float red[3][32 * 33];
+// Workgroup = one 32 x 32 tile of C; its four waves split K by 32-deep chunks (wave w takes chunks w, w + 4, ...) and meet in LDS
+// at the end.  Every wave is a stream of its own - private LDS staging tiles, no workgroup barrier inside the K loop, the
+// operands of its next chunk requested before the current one is multiplied: the attention backward's products are 256 x 256
+// ... 512 per image at batch 4 with K = 256 or 512, i.e. two to four chunks per wave, two of them in flight at any time.  (The first version
+// shared every chunk between the four waves: two barriers and one exposed L2 / HBM round trip per chunk, 32 us per launch for
+// 0.27 GFLOP; the products are latency, not arithmetic.)
+__global__ __launch_bounds__(256, 2) void bgemm_kernel(GemmParams p) {
+    constexpr int KC = 32, PITCH = 33, NL = KC * 32 / 64;        // NL elements per lane, operand and chunk
+    extern __shared__ float bg_lds[];                           // per wave: As[KC][PITCH], Bs[KC][PITCH]; afterwards red[3][32][33]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* As = bg_lds + wave * (2 * KC * PITCH);
+    float* Bs = As + KC * PITCH;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, bz = blockIdx.z;
     const int64_t abase = (int64_t)bz * p.sab, bbase = (int64_t)bz * p.sbb;
-    // consecutive threads walk the unit-stride axis of each operand
+    // consecutive lanes walk the unit-stride axis of each operand
     const bool a_kfast = p.sak == 1, b_kfast = p.sbk == 1;
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    float ra[8], rb[8];
-    auto issue = [&](int k0) __attribute__((always_inline)) {
+    const int nchunks = (p.K + KC - 1) / KC;
+    float ra[2][NL], rb[2][NL];
+    // element i of a lane's share of a chunk: (fast, slow) index = (lane % 32, lane / 32 + 2 i), fast = k when the operand's unit
+    // stride is k, else the row / column - either way the address is linear in i and the bounds test is i < a per-lane limit
+    const int lf = lane & 31, ls = lane >> 5;
+    auto coords = [&](bool kfast, int i, int& k, int& r) __attribute__((always_inline)) {
+        if (kfast) { k = lf; r = ls + 2 * i; } else { r = lf; k = ls + 2 * i; }
+    };
+    // every load is unconditional (out-of-range elements re-read the lane's last valid one, or the batch's first element, and
+    // are zeroed afterwards): a guarded load is a branch and a wait of its own, and 32 of those in sequence were the kernel
+    auto fetch = [&](float (&dst)[NL], const void* base, int is_f32, int64_t safe, int64_t off0, int64_t step, int lim) __attribute__((always_inline)) {
+        const int64_t o = lim > 0 ? off0 : safe;
+        const int last = lim > 0 ? lim - 1 : 0;
+        if (is_f32) {
+            const float* q = reinterpret_cast<const float*>(base) + o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int k, m;
-            if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 31; k = (tid >> 5) + 8 * i; }
-            ra[i] = (m0 + m < p.M && k0 + k < p.K) ? ld_elem(p.a, abase + (int64_t)(m0 + m) * p.sam + (int64_t)(k0 + k) * p.sak, p.a_f32) : 0.f;
-            int kb, n;
-            if (b_kfast) { kb = tid & 63; n = (tid >> 6) + 4 * i; } else { n = tid & 31; kb = (tid >> 5) + 8 * i; }
-            rb[i] = (n0 + n < p.N && k0 + kb < p.K) ? ld_elem(p.b, bbase + (int64_t)(k0 + kb) * p.sbk + (int64_t)(n0 + n) * p.sbn, p.b_f32) : 0.f;
+            for (int i = 0; i < NL; ++i) dst[i] = q[(i < last ? i : last) * step];
+        } else {
+            const bf16* q = reinterpret_cast<const bf16*>(base) + o;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) dst[i] = (float)q[(i < last ? i : last) * step];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) dst[i] = i < lim ? dst[i] : 0.f;
+    };
+    auto issue = [&](int S, int chunk) __attribute__((always_inline)) {
+        const int k0 = chunk * KC;
+        {
+            const int kl = a_kfast ? lf : ls, rl = a_kfast ? ls : lf;
+            const int lim = (k0 + kl < p.K && m0 + rl < p.M) ? ((a_kfast ? p.M - m0 - rl : p.K - k0 - kl) + 1) / 2 : 0;
+            fetch(ra[S], p.a, p.a_f32, abase, abase + (int64_t)(m0 + rl) * p.sam + (int64_t)(k0 + kl) * p.sak, 2 * (a_kfast ? p.sam : p.sak), lim);
+        }
+        {
+            const int kl = b_kfast ? lf : ls, rl = b_kfast ? ls : lf;
+            const int lim = (k0 + kl < p.K && n0 + rl < p.N) ? ((b_kfast ? p.N - n0 - rl : p.K - k0 - kl) + 1) / 2 : 0;
+            fetch(rb[S], p.b, p.b_f32, bbase, bbase + (int64_t)(k0 + kl) * p.sbk + (int64_t)(n0 + rl) * p.sbn, 2 * (b_kfast ? p.sbn : p.sbk), lim);
         }
     };
-    auto commit = [&]() __attribute__((always_inline)) {
+    auto commit = [&](int S) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NL; ++i) {
             int k, m;
-            if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 31; k = (tid >> 5) + 8 * i; }
-            As[k * PITCH + m] = ra[i];
+            coords(a_kfast, i, k, m);
+            As[k * PITCH + m] = ra[S][i];
             int kb, n;
-            if (b_kfast) { kb = tid & 63; n = (tid >> 6) + 4 * i; } else { n = tid & 31; kb = (tid >> 5) + 8 * i; }
-            Bs[kb * PITCH + n] = rb[i];
+            coords(b_kfast, i, kb, n);
+            Bs[kb * PITCH + n] = rb[S][i];
         }
     };
-    issue(0);
-    for (int k0 = 0; k0 < p.K; k0 += KC) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (k0 + KC < p.K) issue(k0 + KC);
+    auto multiply = [&]() __attribute__((always_inline)) {
         const int h = lane >> 5, r = lane & 31;
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
-            const int k = 16 * wave + kk + h;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * PITCH + r], Bs[k * PITCH + r], acc, 0, 0, 0);
-        }
+#pragma unroll 8
+        for (int kk = 0; kk < KC; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + h) * PITCH + r], Bs[(kk + h) * PITCH + r], acc, 0, 0, 0);
+    };
+    // the wave's LDS accesses execute in order; the fences keep the compiler from moving them across the hand-over points
+    auto wave_sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    int c = wave;
+    if (c < nchunks) issue(0, c);
+    if (c + 4 < nchunks) issue(1, c + 4);
+    for (int s = 0; c < nchunks; c += 4, s ^= 1) {
+        wave_sync();                                            // the previous chunk's fragment reads are done
+        if (s == 0) commit(0); else commit(1);
+        wave_sync();
+        if (c + 8 < nchunks) { if (s == 0) issue(0, c + 8); else issue(1, c + 8); }
+        multiply();
     }
-    // the four K quarters meet in a fixed order (wave 0 + 1 + 2 + 3): deterministic
+    // the four K streams meet in a fixed order (wave 0 + 1 + 2 + 3): deterministic
+    __syncthreads();                                            // every wave is done with its staging tiles: red aliases them
+    float (*red)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(bg_lds);
     const int col = lane & 31;
     if (wave > 0) {
 #pragma unroll
@@ -167,7 +208,10 @@ extern "C" int hsidm_bgemm(const void* a, int a_f32, int64_t sab, int64_t sam, i
     p.a = a; p.b = b; p.c = c;
     p.sab = sab; p.sam = sam; p.sak = sak; p.sbb = sbb; p.sbk = sbk; p.sbn = sbn; p.scb = scb; p.scm = scm;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.a_f32 = a_f32; p.b_f32 = b_f32; p.c_f32 = c_f32;
-    hipLaunchKernelGGL(bgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, p);
+    constexpr size_t lds = (size_t)4 * 2 * 32 * 33 * sizeof(float);
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &bgemm_kernel, lds)) return rc;
+    hipLaunchKernelGGL(bgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(256), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

@@ -79,35 +79,49 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
         const bf16* src;
         int cs, cl;
         if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; } else { src = p.src1; cs = p.C1; cl = cc - p.C0; }
+        // every request of the chunk goes out before anything waits: the 4 halo vectors are read unconditionally (positions outside
+        // the image or the tile re-read a clamped, valid one and are zeroed at the store) and the GroupNorm parameters come as four
+        // 16-byte loads - a guarded load with its transform behind it was a dependent round trip per vector
         float sc[8], sh[8];
         if (p.gn_ab) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(p.gn_ab + (size_t)b * ctot + cc);
+            f32x4 r[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float2 ab = p.gn_ab[(size_t)b * ctot + cc + k]; sc[k] = ab.x; sh[k] = ab.y; }
+            for (int k = 0; k < 4; ++k) r[k] = q[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sc[2 * k] = r[k][0]; sh[2 * k] = r[k][1]; sc[2 * k + 1] = r[k][2]; sh[2 * k + 1] = r[k][3]; }
+        }
+        u32x4 raw[MAXHV];
+        bool okv[MAXHV];
+#pragma unroll
+        for (int i = 0; i < MAXHV; ++i) {
+            const int hp = min((tid >> 3) + i * 32, HPIX - 1);
+            const int hy = hp / HC, hx = hp - hy * HC;
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            okv[i] = cok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            raw[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b * p.H + cy) * p.W + cx) * cs + cl);
         }
         __syncthreads();                                         // the previous chunk's readers are done
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
             const int hp = (tid >> 3) + i * 32;
-            if (hp < HPIX) {
-                const int hy = hp / HC, hx = hp - hy * HC;
-                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-                const bool ok = cok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                u32x4 raw = {0u, 0u, 0u, 0u};
-                if (ok) raw = *reinterpret_cast<const u32x4*>(src + ((size_t)(b * p.H + iy) * p.W + ix) * cs + cl);
-                if (ok && p.gn_ab) {
-                    float v[8];
+            u32x4 o4 = raw[i];
+            if (p.gn_ab) {
+                float v[8];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(raw[k] << 16); v[2 * k + 1] = __uint_as_float(raw[k] & 0xffff0000u); }
-                    bf16x8 o;
+                for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(o4[k] << 16); v[2 * k + 1] = __uint_as_float(o4[k] & 0xffff0000u); }
+                bf16x8 o;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float u = fmaf(v[k], sc[k], sh[k]);
-                        o[k] = (bf16)(p.silu ? silu_fast(u) : u);
-                    }
-                    raw = __builtin_bit_cast(u32x4, o);
+                for (int k = 0; k < 8; ++k) {
+                    const float u = fmaf(v[k], sc[k], sh[k]);
+                    o[k] = (bf16)(p.silu ? silu_fast(u) : u);
                 }
-                *reinterpret_cast<u32x4*>(halo + hp * PSTR + cv * 8) = raw;
+                o4 = __builtin_bit_cast(u32x4, o);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o4[k] = okv[i] ? o4[k] : 0u;
+            if (hp < HPIX) *reinterpret_cast<u32x4*>(halo + hp * PSTR + cv * 8) = o4;
         }
         __syncthreads();
         // ---- 9 taps x 4 k-slices ----
@@ -162,7 +176,20 @@ __global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __rest
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = 0.f;
-        for (int q = 0; q < nparts; ++q) {
+        int q = 0;
+        for (; q + 3 < nparts; q += 4) {                         // four parts in flight, added in order
+            f32x4 a0[4], a1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = *reinterpret_cast<const f32x4*>(partial + (size_t)(q + j) * plane + off);
+                a1[j] = *reinterpret_cast<const f32x4*>(partial + (size_t)(q + j) * plane + off + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] += a0[j][k]; v[4 + k] += a1[j][k]; }
+        }
+        for (; q < nparts; ++q) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(partial + (size_t)q * plane + off);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(partial + (size_t)q * plane + off + 4);
 #pragma unroll

@@ -75,18 +75,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
     float a = 0.f, d = 0.f;
     if (r < R) {
         const int c = c0 + cl;
-        if (c < C0) {
-            for (int s = r; s < nsplit0; s += R) {
-                const float2 v = part0[((size_t)b * nsplit0 + s) * C0 + c];
-                a += v.x;
-                d += v.y;
-            }
-        } else {
-            for (int s = r; s < nsplit1; s += R) {
-                const float2 v = part1[((size_t)b * nsplit1 + s) * C1 + (c - C0)];
-                a += v.x;
-                d += v.y;
-            }
+        // this thread's entries s = r, r + R, ...: four requested at a time, added in order (one load per trip was one exposed
+        // round trip per entry - the whole duration of a launch this small)
+        const float2* src = c < C0 ? part0 + (size_t)b * nsplit0 * C0 + c : part1 + (size_t)b * nsplit1 * C1 + (c - C0);
+        const int ns = c < C0 ? nsplit0 : nsplit1, cs = c < C0 ? C0 : C1;
+        int s = r;
+        for (; s + 3 * R < ns; s += 4 * R) {
+            float2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = src[(size_t)(s + j * R) * cs];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a += v[j].x; d += v[j].y; }
+        }
+        for (; s < ns; s += R) {
+            const float2 v = src[(size_t)s * cs];
+            a += v.x;
+            d += v.y;
         }
     }
     scr[2 * t] = a;

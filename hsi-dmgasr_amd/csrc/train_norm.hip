@@ -22,6 +22,17 @@ __device__ __forceinline__ void load_cat8(const T* __restrict__ s0, const T* __r
 
 __device__ __forceinline__ float sigmoid_precise(float u) { return 1.0f / (1.0f + expf(-u)); }
 
+// (scale, shift) of 8 consecutive channels of the GroupNorm table (idx % 8 == 0: four 16-byte loads, requested together - a load
+// per channel inside the arithmetic loop was a dependent L2 round trip each, which is what a launch of a few microseconds is made of)
+__device__ __forceinline__ void load_ab8(const float2* __restrict__ ab, size_t idx, float (&sc)[8], float (&sh)[8]) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(ab + idx);
+    f32x4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sc[2 * k] = r[k][0]; sh[2 * k] = r[k][1]; sc[2 * k + 1] = r[k][2]; sh[2 * k + 1] = r[k][3]; }
+}
+
 // keep/scale factors of the 8 elements e0 .. e0+7 (e0 % 8 == 0) of a dropout mask: element e keeps its value iff word (e & 3) of
 // Philox4x32-10(key = seed, counter = (e >> 2, stream = layer)) >= thresh; restated in oracle/train.py
 __device__ __forceinline__ void dropout8(uint64_t e0, uint32_t layer, uint64_t seed, uint32_t thresh, float inv_keep, float (&f)[8]) {
@@ -48,12 +59,12 @@ __global__ __launch_bounds__(256) void gn_act_apply_kernel(const T* __restrict__
         const int64_t bp = i / nv;
         const int c = (int)(i - bp * nv) * 8;
         const int b = (int)(bp / HW);
-        float x[8], a[8];
+        float x[8], a[8], sc[8], sh[8];
         load_cat8<T>(s0, s1, C0, C1, (size_t)bp, c, x);
+        load_ab8(ab, (size_t)b * C + c, sc, sh);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float2 p = ab[(size_t)b * C + c + k];
-            const float u = fmaf(x[k], p.x, p.y);
+            const float u = fmaf(x[k], sc[k], sh[k]);
             a[k] = silu_on ? u * sigmoid_precise(u) : u;
         }
         if (dr.thresh) {
@@ -98,17 +109,27 @@ __global__ __launch_bounds__(256) void gn_act_bwd_reduce_kernel(const T* __restr
     if (prow < rows) {
         const int c = cvi * 8;
         float sc[8], sh[8], mu[8], rs[8];
+        load_ab8(ab, (size_t)b * C + c, sc, sh);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float2 p = ab[(size_t)b * C + c + k];
             const float2 m = mr[(size_t)b * groups + (c + k) / cpg];
-            sc[k] = p.x; sh[k] = p.y; mu[k] = m.x; rs[k] = m.y;
+            mu[k] = m.x; rs[k] = m.y;
         }
-        for (int p = p_begin + prow; p < p_end; p += rows) {
+        // the operands of the next pixel are requested before this one's arithmetic (a Philox mask and two expf per element):
+        // with 4 ... 16 pixels per thread on the deep levels the loop was one exposed round trip per pixel
+        float x[8], g[8], xn[8], gn[8];
+        int p = p_begin + prow;
+        if (p < p_end) {
+            load_cat8<T>(s0, s1, C0, C1, (size_t)b * HW + p, c, x);
+            Vec8<T>::load(da + ((size_t)b * HW + p) * C + c, g);
+        }
+        for (; p < p_end; p += rows) {
             const size_t bp = (size_t)b * HW + p;
-            float x[8], g[8], u[8], f[8], dy[8];
-            load_cat8<T>(s0, s1, C0, C1, bp, c, x);
-            Vec8<T>::load(da + bp * C + c, g);
+            const bool more = p + rows < p_end;
+            const size_t bpn = more ? bp + rows : bp;
+            load_cat8<T>(s0, s1, C0, C1, bpn, c, xn);
+            Vec8<T>::load(da + bpn * C + c, gn);
+            float u[8], f[8], dy[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) u[k] = fmaf(x[k], sc[k], sh[k]);
             if (dr.thresh) dropout8((uint64_t)bp * C + c, dr.layer, drop_key(dr), dr.thresh, dr.inv_keep, f);
@@ -118,6 +139,8 @@ __global__ __launch_bounds__(256) void gn_act_bwd_reduce_kernel(const T* __restr
                 s1a[k] += dy[k];
                 s2a[k] = fmaf(dy[k], (x[k] - mu[k]) * rs[k], s2a[k]);
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { x[k] = xn[k]; g[k] = gn[k]; }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -145,11 +168,20 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __re
         const int cw = min(256, C - c0), ng = 256 / cw;
         const int cl = t % cw, sg = t / cw;
         float a = 0.f, d = 0.f;
-        if (sg < ng)
-            for (int s = sg; s < nsplit; s += ng) {
+        if (sg < ng) {
+            int s = sg;
+            for (; s + 7 * ng < nsplit; s += 8 * ng) {          // eight entries in flight, added in order
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = part[((size_t)b * nsplit + s + j * ng) * C + c0 + cl];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a += v[j].x; d += v[j].y; }
+            }
+            for (; s < nsplit; s += ng) {
                 const float2 v = part[((size_t)b * nsplit + s) * C + c0 + cl];
                 a += v.x; d += v.y;
             }
+        }
         __syncthreads();
         scr[2 * t] = a; scr[2 * t + 1] = d;
         __syncthreads();
@@ -205,20 +237,24 @@ __global__ __launch_bounds__(256) void gn_act_bwd_apply_kernel(const T* __restri
         float x[8], g[8], u[8], f[8], dy[8], o[8];
         load_cat8<T>(s0, s1, C0, C1, (size_t)bp, c, x);
         Vec8<T>::load(da + (size_t)bp * C + c, g);
-        float sc[8];
+        float sc[8], sh[8];
+        load_ab8(ab, (size_t)b * C + c, sc, sh);
+        float2 mk[8], Mk[8];                    // every table read is requested before the arithmetic (see load_ab8)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float2 p = ab[(size_t)b * C + c + k];
-            sc[k] = p.x;
-            u[k] = fmaf(x[k], p.x, p.y);
+            const int gi = (c + k) / cpg;
+            mk[k] = mr[(size_t)b * groups + gi];
+            Mk[k] = gm[(size_t)b * groups + gi];
         }
+        float rres[8];
+        if (add) Vec8<T>::load(add + (size_t)bp * C + c, rres);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = fmaf(x[k], sc[k], sh[k]);
         if (dr.thresh) dropout8((uint64_t)bp * C + c, dr.layer, drop_key(dr), dr.thresh, dr.inv_keep, f);
         dy8(g, u, silu_on, dr.thresh != 0, f, dy);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int gi = (c + k) / cpg;
-            const float2 m = mr[(size_t)b * groups + gi];
-            const float2 M = gm[(size_t)b * groups + gi];
+            const float2 m = mk[k], M = Mk[k];
             const float xh = (x[k] - m.x) * m.y;
             // rstd*gamma*dy = scale*dy (scale is the table's rstd*gamma)
             o[k] = sc[k] * dy[k] - m.y * (M.x + xh * M.y);
@@ -227,10 +263,8 @@ __global__ __launch_bounds__(256) void gn_act_bwd_apply_kernel(const T* __restri
         T* dst = first ? dx0 : dx1;
         const size_t off = first ? (size_t)bp * C0 + c : (size_t)bp * C1 + (c - C0);
         if (add) {
-            float r[8];
-            Vec8<T>::load(add + (size_t)bp * C + c, r);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] += r[k];
+            for (int k = 0; k < 8; ++k) o[k] += rres[k];
         }
         Vec8<T>::store(dst + off, o);
     }

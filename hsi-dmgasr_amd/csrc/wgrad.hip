@@ -9,6 +9,9 @@
 // Work decomposition: workgroup = (64 couts x 64 cins x all taps) x a contiguous range of pixel tiles (split K); a wave owns a
 // 32 x 32 corner for all taps (9 accumulator tiles); partial sums go to a workspace [split][tap][cout][cin] with plain stores and
 // a second kernel adds the splits in order into the PyTorch layout [cout][cin][ky][kx]: deterministic, no atomics.
+// Bias gradient (sum of dy over the pixels) on request: the workgroups of cin tile 0 carry one more accumulator tile whose B operand
+// is all ones - D[co][*] += dY^T[co][pixel] * 1 - fed by the dY fragments they fetch anyway: one MFMA per k-group, no extra LDS
+// read and no reduction code; its column 0 goes to the workspace like the other partial tiles.
 #include "common.h"
 #include "../../include/hsidm.h"
 #include <type_traits>
@@ -18,6 +21,7 @@ namespace hsidm {
 struct WgradParams {
     const void* a0; const void* a1; const void* dy;
     float* ws;
+    float* bias_ws;                    // [nsplit][Cout_pad] partial sums of dy over the pixels (the bias gradient), or null
     int C0, C1, Cin, Cout;             // tensor channel counts (multiples of 8)
     int B, Hin, Win, Hout, Wout;
     int tiles_x, tiles_y, ksteps, nsplit;
@@ -64,6 +68,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    const bool do_bias = p.bias_ws != nullptr && ci0 == 0 && wn == 0;      // wave-uniform
+    f32x16 accb;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accb[j] = 0.f;
 
     u32x4 rd[C::NV_D], ra[C::NV_A];
     auto issue = [&](int step) __attribute__((always_inline)) {
@@ -138,6 +147,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap));
                 const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + 4 * C::PITCH));
                 const s16x8 af = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                if (do_bias) {
+                    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};      // bf16 1.0
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int ky = NT == 1 ? 0 : t / 3, kx = NT == 1 ? 0 : t % 3;
@@ -158,6 +171,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 const int y = pix / TW, x = pix % TW;
                 const float av = ld[pix * C::PITCH + 32 * wm + r];
                 const T* brow = la + (sp * y * C::HWD + sp * x) * C::PITCH + 32 * wn + r;
+                if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, 1.0f, accb, 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int ky = NT == 1 ? 0 : t / 3, kx = NT == 1 ? 0 : t % 3;
@@ -178,23 +192,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             dst[(size_t)m * p.Cin_pad + n] = acc[t][j];
         }
     }
+    if (do_bias && (lane & 31) == 0) {                       // every column of the ones-tile holds the same sums: column 0 leaves
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            p.bias_ws[(size_t)split * p.Cout_pad + co0 + 32 * wm + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)] = accb[j];
+    }
 }
 
 // dw[co][ci][tap] = sum over splits (in a fixed order) of ws[split][tap][co][ci].
-// A workgroup owns 64 consecutive (co, ci) pairs: thread (pair, q) sums the splits s = q, q + 4, ... of every tap (consecutive
-// threads = consecutive ci: coalesced reads), the four partial sums meet in LDS in the order q = 0..3, and the 64 x NT results
-// leave as one contiguous run of the PyTorch layout (coalesced writes).
+// Two shapes of workgroup, by the number of splits (reduce_ppb):
+//   many splits (> 8: the 64 ... 128-channel layers, up to 128 splits of a few hundred KB): 64 consecutive (co, ci) pairs, thread
+//     (pair, q) sums the splits s = q, q + 4, ... of every tap, the four partial sums meet in LDS in the order q = 0..3;
+//   few splits (<= 8: the wide layers, 2 ... 8 splits of 9 ... 19 MB): 256 consecutive pairs, one thread per pair walks the splits
+//     in order with two splits' taps in flight - 1 KiB contiguous per (split, tap) row instead of 256 B, a quarter of the workgroups.
+// Either way consecutive threads = consecutive ci (coalesced reads) and the results leave through LDS as one contiguous run of
+// the PyTorch layout (coalesced writes).
+__host__ __device__ inline int reduce_ppb(int nsplit) { return nsplit <= 8 ? 256 : 64; }
+
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
-                                                   int Cout_w, int Cin_w, float* __restrict__ dw, int blk, float (*sm)[64][10]) {
-    const int pair = threadIdx.x & 63, q = threadIdx.x >> 6;
+                                                   int Cout_w, int Cin_w, float* __restrict__ dw, int blk, float* sm) {
     const int64_t npairs = (int64_t)Cout_w * Cin_w;
-    const int64_t i = (int64_t)blk * 64 + pair;
+    const size_t plane = (size_t)Cout_pad * Cin_pad;
+    const int ppb = reduce_ppb(nsplit);
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (ppb == 256) {
+        const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+        if (i < npairs) {
+            const int co = (int)(i / Cin_w), ci = (int)(i % Cin_w);
+            const float* src = ws + (size_t)co * Cin_pad + ci;
+            int s = 0;
+            for (; s + 1 < nsplit; s += 2) {
+                const float* p0 = src + (size_t)s * NT * plane;
+                const float* p1 = p0 + (size_t)NT * plane;
+                float v0[9], v1[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { v0[t] = t < NT ? p0[(size_t)t * plane] : 0.f; v1[t] = t < NT ? p1[(size_t)t * plane] : 0.f; }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = (acc[t] + v0[t]) + v1[t];
+            }
+            if (s < nsplit) {
+                const float* p0 = src + (size_t)s * NT * plane;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if (t < NT) acc[t] += p0[(size_t)t * plane];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sm[threadIdx.x * 9 + t] = acc[t];
+        __syncthreads();
+        const int64_t base = (int64_t)blk * 256 * NT, total = npairs * NT;
+        for (int e = threadIdx.x; e < 256 * NT; e += 256) {
+            if (base + e < total) {
+                const int pr = e / NT, t = e - pr * NT;
+                dw[base + e] = sm[pr * 9 + t];
+            }
+        }
+        return;
+    }
+    const int pair = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blk * 64 + pair;
     if (i < npairs) {
         const int co = (int)(i / Cin_w), ci = (int)(i % Cin_w);
-        const size_t plane = (size_t)Cout_pad * Cin_pad;
         const float* src = ws + (size_t)co * Cin_pad + ci;
         for (int s = q; s < nsplit; s += 4) {
             const float* ps = src + (size_t)s * NT * plane;
@@ -204,37 +264,48 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ ws,
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) sm[q][pair][t] = acc[t];
+    for (int t = 0; t < 9; ++t) sm[(q * 64 + pair) * 10 + t] = acc[t];
     __syncthreads();
     const int64_t base = (int64_t)blk * 64 * NT, total = npairs * NT;
     for (int e = threadIdx.x; e < 64 * NT; e += 256) {
         if (base + e < total) {
             const int pr = e / NT, t = e - pr * NT;
-            dw[base + e] = ((sm[0][pr][t] + sm[1][pr][t]) + sm[2][pr][t]) + sm[3][pr][t];
+            dw[base + e] = ((sm[pr * 10 + t] + sm[(64 + pr) * 10 + t]) + sm[(128 + pr) * 10 + t]) + sm[(192 + pr) * 10 + t];
         }
     }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
                                                            int Cout_w, int Cin_w, float* __restrict__ dw) {
-    __shared__ float sm[4][64][10];
+    __shared__ float sm[4 * 64 * 10];
     wgrad_reduce_block(ws, nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, dw, blockIdx.x, sm);
 }
 
 // every layer's reduction in ONE launch (the training step on one GPU defers them to the end of the backward pass: 94 launches
-// of 10-20 us each are latency, this one runs at bandwidth).  items[] is sorted by block0; a block finds its item by bisection.
+// of 10-20 us each are latency, this one runs at bandwidth).  items[] is sorted by block0 (an item has
+// ceil(Cout_w * Cin_w / reduce_ppb(nsplit)) blocks); a block finds its item by bisection on a copy of the block0 column in LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const hsidm_wgrad_item* __restrict__ items, int n_items) {
-    __shared__ float sm[4][64][10];
+    __shared__ float sm[4 * 64 * 10];
+    __shared__ int blk0[256];
     int lo = 0, hi = n_items - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (n_items <= 256) {
+        if ((int)threadIdx.x < n_items) blk0[threadIdx.x] = items[threadIdx.x].block0;
+        __syncthreads();
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+    } else {
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (items[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
     }
     const hsidm_wgrad_item it = items[lo];
     wgrad_reduce_block(it.ws, it.nsplit, it.NT, it.Cout_pad, it.Cin_pad, it.Cout_w, it.Cin_w, it.dw, (int)blockIdx.x - it.block0, sm);
 }
 
-struct WgPlan { int TW, TH, tiles_x, tiles_y, ksteps, nsplit, cin_tiles, cout_tiles, Cin_pad, Cout_pad, NT, mode; size_t ws_bytes; };
+struct WgPlan { int TW, TH, tiles_x, tiles_y, ksteps, nsplit, cin_tiles, cout_tiles, Cin_pad, Cout_pad, NT, mode; size_t ws_bytes, bias_off; };
 
 static int wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize, int stride, int ups, WgPlan& pl) {
     const int Cin = C0 + C1;
@@ -265,7 +336,8 @@ static int wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wou
     if (ns < 1) ns = 1;                                               // writes (147 KB with 9 taps) must not outweigh what it computes
     const int per = (pl.ksteps + ns - 1) / ns;
     pl.nsplit = (pl.ksteps + per - 1) / per;                          // no empty split
-    pl.ws_bytes = (size_t)pl.nsplit * per_split;
+    pl.bias_off = (size_t)pl.nsplit * per_split;                      // [nsplit][Cout_pad] bias partials behind the weight partials
+    pl.ws_bytes = pl.bias_off + (size_t)pl.nsplit * pl.Cout_pad * sizeof(float);
     return HSIDM_OK;
 }
 
@@ -301,12 +373,12 @@ extern "C" int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int H
 }
 
 extern "C" int hsidm_conv_wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize, int stride, int ups,
-                                     int32_t* plan4) {
+                                     int32_t* plan5) {
     WgPlan pl;
     const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
     if (rc != HSIDM_OK) return rc;
-    if (!plan4) return HSIDM_E_BADARG;
-    plan4[0] = pl.nsplit; plan4[1] = pl.NT; plan4[2] = pl.Cout_pad; plan4[3] = pl.Cin_pad;
+    if (!plan5) return HSIDM_E_BADARG;
+    plan5[0] = pl.nsplit; plan5[1] = pl.NT; plan5[2] = pl.Cout_pad; plan5[3] = pl.Cin_pad; plan5[4] = reduce_ppb(pl.nsplit);
     return HSIDM_OK;
 }
 
@@ -318,14 +390,16 @@ extern "C" int hsidm_wgrad_reduce_all(const hsidm_wgrad_item* items_dev, int n_i
 
 extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
                                 int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                int with_bias, float* db, void* workspace, int64_t workspace_bytes, void* stream) {
     WgPlan pl;
     const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
     if (rc != HSIDM_OK) return rc;
     if (!a0 || (C1 > 0 && !a1) || !dy || !workspace || Cout_w <= 0 || Cout_w > Cout || Cin_w <= 0 || Cin_w > C0 + C1) return HSIDM_E_BADARG;
     if ((size_t)workspace_bytes < pl.ws_bytes) return HSIDM_E_BADARG;
+    if (with_bias && dw && !db) return HSIDM_E_BADARG;
     WgradParams p;
     p.a0 = a0; p.a1 = C1 > 0 ? a1 : nullptr; p.dy = dy; p.ws = (float*)workspace;
+    p.bias_ws = with_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.bias_off) : nullptr;
     p.C0 = C0; p.C1 = C1; p.Cin = C0 + C1; p.Cout = Cout;
     p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ksteps = pl.ksteps; p.nsplit = pl.nsplit;
@@ -338,7 +412,11 @@ extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0
     if (e) return e;
     if (!dw) return HSIDM_OK;                       // deferred: the caller sums the partial tiles later (hsidm_wgrad_reduce_all)
     const int64_t n = (int64_t)Cout_w * Cin_w;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
+    const int ppb = reduce_ppb(pl.nsplit);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
                        pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw);
+    if (with_bias)                                  // the bias partials are a [nsplit][1 tap][Cout_pad][1] stack of the same kind
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout_w + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)p.bias_ws, pl.nsplit,
+                           1, pl.Cout_pad, 1, Cout_w, 1, db);
     return (int)hipGetLastError();
 }

@@ -37,7 +37,7 @@ def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta,
     C1 = 0 if x1 is None else x1.shape[3]
     C = C0 + C1
     HW = H * W
-    nsplit = _nsplit(B, HW)
+    nsplit = _nsplit(B, HW, C)
     L = _lib.lib()
     ws = torch.empty(L.hsidm_gn_act_bwd_workspace_floats(B, C, groups, nsplit), dtype=torch.float32, device=x0.device)
     dx0 = torch.empty_like(x0)
@@ -51,10 +51,11 @@ def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta,
     return dx0, dx1
 
 
-def _nsplit(B, HW):
+def _nsplit(B, HW, C=64):
     """Pixel ranges per image for the streaming reductions: about four workgroups per CU over the batch (training batches are
-    small: 4 latents per GPU in the reference, sr_gae.py:182), at least 64 pixels each."""
-    return max(1, min(HW // 64, (1024 + B - 1) // B))
+    small: 4 latents per GPU in the reference, sr_gae.py:182), at least 64 pixels each - 16 on the wide layers (C >= 256: a
+    256-thread workgroup covers only 256 * 8 / C pixels at a time, and the deep levels have 64 ... 1024 pixels per image)."""
+    return max(1, min(HW // (16 if C >= 256 else 64), (1024 + B - 1) // B))
 
 
 _ws_cache = {}
@@ -70,9 +71,10 @@ def _workspace(nbytes, dev):
     return buf
 
 
-def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None):
+def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db=None):
     """dw [Cout_w, Cin_w, k, k] (fp32, contiguous view of the gradient buffer) = weight gradient of the convolution that
-    maps a = cat(a0, a1) to the tensor whose gradient is dy.
+    maps a = cat(a0, a1) to the tensor whose gradient is dy.  db [Cout_w] (optional): the bias gradient, the per-channel sum of dy,
+    from the same launch.
 
     deferred: a DeferredReductions collector - the split-K partial tiles stay in a workspace of this layer's own and ONE launch sums
     all layers at the end (reduce_deferred)."""
@@ -86,14 +88,17 @@ def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None):
     if nb < 0:
         _check(int(nb), "conv_wgrad_workspace_bytes")
     assert dw.is_contiguous() and dw.dtype == torch.float32
+    if db is not None:
+        assert db.is_contiguous() and db.dtype == torch.float32 and db.numel() == cout_w
     if deferred is None:
         ws = _workspace(nb, a0.device)
-        dwp = _lib.ptr(dw)
+        dwp, dbp = _lib.ptr(dw), _lib.ptr(db)
     else:
-        ws = deferred.workspace(dw, nb, geo)
-        dwp = None
+        ws = deferred.workspace(dw, nb, geo, db)
+        dwp, dbp = None, None
     _check(L.hsidm_conv_wgrad(_lib.prec_id(precision), _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(dy), B, Hin, Win, Ho, Wo, Ct, k,
-                              stride, int(bool(ups)), cout_w, cin_w, dwp, _lib.ptr(ws), int(nb), _lib.stream_ptr()), "conv_wgrad")
+                              stride, int(bool(ups)), cout_w, cin_w, dwp, int(db is not None), dbp, _lib.ptr(ws), int(nb),
+                              _lib.stream_ptr()), "conv_wgrad")
 
 
 class DeferredReductions:
@@ -103,14 +108,15 @@ class DeferredReductions:
         self.dev = device
         self.ws, self.items, self.table, self.blocks = {}, [], None, 0
 
-    def workspace(self, dw, nbytes, geo):
+    def workspace(self, dw, nbytes, geo, db=None):
         key = dw.data_ptr()
         hit = self.ws.get(key)
-        if hit is None or hit[0].numel() < nbytes or hit[1] != geo:
-            plan = (C.c_int32 * 4)()
+        dbp = None if db is None else db.data_ptr()
+        if hit is None or hit[0].numel() < nbytes or hit[1] != geo or hit[4] != dbp:
+            plan = (C.c_int32 * 5)()
             _check(_lib.lib().hsidm_conv_wgrad_plan(*geo, plan), "conv_wgrad_plan")
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
-            self.ws[key] = (buf, geo, tuple(plan), dw)
+            self.ws[key] = (buf, geo, tuple(plan), dw, dbp, db)
             self.table = None                           # addresses changed: rebuild the table
         return self.ws[key][0]
 
@@ -118,17 +124,27 @@ class DeferredReductions:
         if not self.ws:
             return
         if self.table is None:
-            arr = (_lib.WgradItem * len(self.ws))()
-            blk = 0
-            for i, (buf, geo, plan, dw) in enumerate(self.ws.values()):
+            n = len(self.ws) + sum(1 for v in self.ws.values() if v[4] is not None)
+            arr = (_lib.WgradItem * n)()
+            blk, i = 0, 0
+            for buf, geo, plan, dw, dbp, db in self.ws.values():
                 it = arr[i]
                 it.ws, it.dw = buf.data_ptr(), dw.data_ptr()
-                it.nsplit, it.NT, it.Cout_pad, it.Cin_pad = plan
+                it.nsplit, it.NT, it.Cout_pad, it.Cin_pad, ppb = plan
                 it.Cout_w, it.Cin_w, it.block0 = dw.shape[0], dw.shape[1], blk
-                blk += (dw.shape[0] * dw.shape[1] + 63) // 64
+                blk += (dw.shape[0] * dw.shape[1] + ppb - 1) // ppb
+                i += 1
+                if dbp is not None:                     # the bias partials: a [nsplit][1][Cout_pad][1] stack behind the weight partials
+                    nsplit, NT, cout_pad, cin_pad, _ = plan
+                    it = arr[i]
+                    it.ws, it.dw = buf.data_ptr() + 4 * nsplit * NT * cout_pad * cin_pad, dbp
+                    it.nsplit, it.NT, it.Cout_pad, it.Cin_pad = nsplit, 1, cout_pad, 1
+                    it.Cout_w, it.Cin_w, it.block0 = dw.shape[0], 1, blk
+                    blk += (dw.shape[0] + ppb - 1) // ppb
+                    i += 1
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.table = host.to(self.dev)
-            self.n, self.blocks = len(self.ws), blk
+            self.n, self.blocks = n, blk
         _check(_lib.lib().hsidm_wgrad_reduce_all(_lib.ptr(self.table), self.n, self.blocks, _lib.stream_ptr()), "wgrad_reduce_all")
 
 

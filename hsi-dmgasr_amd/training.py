@@ -232,11 +232,12 @@ class Trainer:
         y = ops.conv2d(a, self.pk(blk.block[3]), film=film, res=res, stats=not out_nchw)
         return y, (x0, x1, ab, a, lid, p_drop)
 
-    def _block_bwd(self, blk, ctx, dy, add=None):
-        """dy: gradient at the block's conv output (bias sums are the caller's).  -> (dx0, dx1)"""
+    def _block_bwd(self, blk, ctx, dy, add=None, bias=True):
+        """dy: gradient at the block's conv output.  bias: the conv's bias gradient (the channel sums of dy) comes out of the weight
+        gradient launch; False when the caller needs the per-image sums too and runs channel_sums.  -> (dx0, dx1)"""
         x0, x1, ab, a, lid, p_drop = ctx
         gn, conv, p = blk.block[0], blk.block[3], self.precision
-        T.conv_wgrad(a, None, dy, self.G(conv.weight), p, deferred=self._defer)
+        T.conv_wgrad(a, None, dy, self.G(conv.weight), p, deferred=self._defer, db=self.G(conv.bias) if bias else None)
         da = ops.conv2d(dy, self.dpk(conv))
         return T.gn_act_bwd(da, x0, x1, ab, gn.weight, gn.num_groups, True, p, self.G(gn.weight), self.G(gn.bias), p_drop,
                             self._drop_key(), lid, add=add)
@@ -256,17 +257,15 @@ class Trainer:
         p = self.precision
         conv1, conv2 = rb.block1.block[3], rb.block2.block[3]
         proj = isinstance(rb.res_conv, nn.Conv2d)
-        T.channel_sums(d_out, p, out_c=self.G(conv2.bias))
-        if proj:
-            self.G(rb.res_conv.bias).copy_(self.G(conv2.bias))        # both biases see the same gradient sum
         dh1, _ = self._block_bwd(rb.block2, c2, d_out)
+        # FiLM needs the per-image sums of dh1 as well: block1's bias gradient stays with channel_sums
         dfilm = T.channel_sums(dh1, p, out_c=self.G(conv1.bias), want_bc=True)
-        if proj:
-            T.conv_wgrad(x0, x1, d_out, self.G(rb.res_conv.weight), p, deferred=self._defer)
+        if proj:                                                      # (both biases see the same gradient sum)
+            T.conv_wgrad(x0, x1, d_out, self.G(rb.res_conv.weight), p, deferred=self._defer, db=self.G(rb.res_conv.bias))
             add = ops.conv2d(d_out, self.dpk(rb.res_conv), res=skip_add)
         else:
             add = d_out if skip_add is None else T.add(d_out, skip_add, p)
-        dx0, dx1 = self._block_bwd(rb.block1, c1, dh1, add=add)
+        dx0, dx1 = self._block_bwd(rb.block1, c1, dh1, add=add, bias=False)
         return dx0, dx1, dfilm
 
     def _attn_fwd(self, at, x):
@@ -281,8 +280,7 @@ class Trainer:
     def _attn_bwd(self, at, ctx, dy):
         x, ab, n, qkv, o = ctx
         p = self.precision
-        T.channel_sums(dy, p, out_c=self.G(at.out.bias))
-        T.conv_wgrad(o, None, dy, self.G(at.out.weight), p, deferred=self._defer)
+        T.conv_wgrad(o, None, dy, self.G(at.out.weight), p, deferred=self._defer, db=self.G(at.out.bias))
         do = ops.conv2d(dy, self.dpk(at.out))
         dqkv = T.attention_bwd(qkv, do, p)
         T.conv_wgrad(n, None, dqkv, self.G(at.qkv.weight), p, deferred=self._defer)
@@ -361,7 +359,6 @@ class Trainer:
         if red is None and self._defer_obj is None and self.dev.type == "cuda":
             self._defer_obj = T.DeferredReductions(self.dev)
         self._defer = self._defer_obj if red is None else None
-        T.channel_sums(d_eps, p, out_c=self.G(fconv.bias), cout=fconv.bias.shape[0])
         d, _ = self._block_bwd(net.final_conv, tp["final"], d_eps)
         if red is not None:
             red.ready(self._low(net.final_conv))
@@ -383,18 +380,15 @@ class Trainer:
                 d, _, dfilms[k] = self._unit_bwd(layer, ctx, d, skip_add)
             elif kind == "up":
                 conv = layer.conv
-                T.channel_sums(d, p, out_c=self.G(conv.bias))
-                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, ups=True, deferred=self._defer)
+                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, ups=True, deferred=self._defer, db=self.G(conv.bias))
                 d = T.sum2x2(ops.conv2d(d, self.dpk(conv)), p)
             elif kind == "down":
                 conv = layer.conv
-                T.channel_sums(d, p, out_c=self.G(conv.bias))
-                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, stride=2, deferred=self._defer)
+                T.conv_wgrad(ctx, None, d, self.G(conv.weight), p, stride=2, deferred=self._defer, db=self.G(conv.bias))
                 z = T.zero_insert2(d, ctx.shape[1], ctx.shape[2], p)
                 d = ops.conv2d(z, self.dpk(conv), res=skip_add)
             else:                          # stem: parameters only
-                T.channel_sums(d, p, out_c=self.G(layer.bias))
-                T.conv_wgrad(ctx, None, d, self.G(layer.weight), p, deferred=self._defer)
+                T.conv_wgrad(ctx, None, d, self.G(layer.weight), p, deferred=self._defer, db=self.G(layer.bias))
             # the flat gradient buffer follows the module order and the backward pass fills it from the end: every bucket
             # above this layer's lowest offset is final and can go on the wire while the earlier layers are still computing
             # (FiLM projections - first in the buffer - and the noise MLP are written after the loop)

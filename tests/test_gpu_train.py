@@ -109,16 +109,22 @@ def test_conv_weight_gradient(dev, prec, case):
     a1 = act(rnd((B, Hin, Win, C1), 12), prec, dev) if C1 else None
     dy = act(rnd((B, Ho, Wo, Ct), 13, 0.5), prec, dev)
     dw = torch.full((cout_w, cin_w, k, k), float("nan"), device=dev)
-    T.conv_wgrad(a0, a1, dy, dw, prec, stride=stride, ups=ups)
-    want = torch.empty(cout_w, cin_w, k, k)
-    ref.conv_wgrad(a0.float().cpu(), None if a1 is None else a1.float().cpu(), dy.float().cpu(), want, prec, stride=stride, ups=ups)
+    db = torch.full((cout_w,), float("nan"), device=dev)
+    T.conv_wgrad(a0, a1, dy, dw, prec, stride=stride, ups=ups, db=db)
+    want, want_b = torch.empty(cout_w, cin_w, k, k), torch.empty(cout_w)
+    ref.conv_wgrad(a0.float().cpu(), None if a1 is None else a1.float().cpu(), dy.float().cpu(), want, prec, stride=stride, ups=ups,
+                   db=want_b)
     # same inputs (already rounded to the storage type) on both sides: what remains is the accumulation order (fp32 mode)
     # or nothing at all beyond it (bf16 products are exact in fp32)
     check("conv_wgrad%s" % (case,), prec, dw, want, tol=1e-4 if prec == "fp32" else 2e-4)
-    dw2 = torch.empty_like(dw)
-    T.conv_wgrad(a0, a1, dy, dw2, prec, stride=stride, ups=ups)
+    # the bias gradient from the same launch (one more accumulator tile against an all-ones operand)
+    check("conv_wgrad_bias%s" % (case,), prec, db, want_b, tol=1e-4 if prec == "fp32" else 2e-4)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    T.conv_wgrad(a0, a1, dy, dw2, prec, stride=stride, ups=ups, db=db2)
+    dw3 = torch.empty_like(dw)
+    T.conv_wgrad(a0, a1, dy, dw3, prec, stride=stride, ups=ups)     # without the bias tile: the weight gradient is the same
     torch.cuda.synchronize()
-    assert torch.equal(dw, dw2)                                     # fixed summation order
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dw, dw3)          # fixed summation order
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -419,14 +425,17 @@ def test_deferred_weight_gradient_reductions_match_the_immediate_ones(dev):
         dy = act(rnd((B, Ho, Wo, Co), 80 + i, 0.5), "bf16", dev)
         d0 = torch.empty(Co, Ci, k, k, device=dev)
         d1 = torch.full((Co, Ci, k, k), float("nan"), device=dev)
-        T.conv_wgrad(a, None, dy, d0, "bf16", stride=stride, ups=ups)
-        T.conv_wgrad(a, None, dy, d1, "bf16", stride=stride, ups=ups, deferred=defer)
-        now.append(d0)
-        later.append(d1)
+        b0 = torch.empty(Co, device=dev)
+        b1 = torch.full((Co,), float("nan"), device=dev) if i % 2 == 0 else None      # with and without the bias item
+        T.conv_wgrad(a, None, dy, d0, "bf16", stride=stride, ups=ups, db=b0)
+        T.conv_wgrad(a, None, dy, d1, "bf16", stride=stride, ups=ups, deferred=defer, db=b1)
+        now.append((d0, b0))
+        later.append((d1, b1))
     defer.reduce()
     torch.cuda.synchronize()
-    for d0, d1 in zip(now, later):
+    for (d0, b0), (d1, b1) in zip(now, later):
         assert torch.equal(d0, d1)
+        assert b1 is None or torch.equal(b0, b1)
 
 
 def test_gradient_allreduce_over_an_rccl_group_of_one(dev):

@@ -1,0 +1,26 @@
+import sys, os, torch
+sys.path.insert(0, os.getcwd())
+from hsi_dmgasr_amd.init import init_weights_orthogonal
+from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+dev = torch.device("cuda:0")
+u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8], attn_res=[16], res_blocks=2, dropout=0.2, image_size=128, precision="bf16")
+init_weights_orthogonal(u, seed=0)
+gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, loss_type="l1", conditional=True).to(dev).train()
+gd.set_loss(dev)
+gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), dev)
+tr = gd.trainer(lr=1e-5)
+B = 4
+data = {"HR": torch.randn((B, 3, 128, 128)).to(dev), "SR": torch.randn((B, 3, 128, 128)).to(dev)}
+tr.optimize_parameters(data, use_graph=False)
+d = tr._defer_obj
+tot = 0; totw = 0
+rows = []
+for buf, geo, plan, dw, dbp, db in d.ws.values():
+    plan = plan[:4]
+    nsplit, NT, cop, cip = plan
+    byt = nsplit * NT * cop * cip * 4
+    tot += byt; totw += dw.numel() * 4
+    rows.append((byt, nsplit, NT, cop, cip, geo))
+rows.sort(reverse=True)
+for r in rows[:25]: print(r)
+print("partial MB", tot / 1e6, "weights MB", totw / 1e6, "items", len(rows), "blocks", d.blocks)
