@@ -23,7 +23,7 @@ void conv_v2_set_stamps(unsigned long long* p);
 int conv_sk_parts(int B, int H, int W, int Cout, int nchunks);
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
                 const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
-                int Cout, int Cout_pad, int nchunks, float* workspace, hipStream_t s);
+                int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, float* workspace, hipStream_t s);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
                   int nch, int im_H, int im_W, hipStream_t s);
@@ -51,9 +51,11 @@ enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 
 // Split-K form (conv_sk.hip): a bf16 3x3 stride-1 convolution whose persistent form would leave most workgroup slots empty
 // (tiles x slices <= an eighth of them) while every item walks >= 4 channel chunks.  Returns the number of K parts, 0 = not eligible.
+// A fused 1x1 projection (nphase == 2) is simply more chunks of one tap each: the split form is the only bf16 w_v2 kernel that
+// takes it (the persistent kernels are single-phase), so the caller asks hsidm_conv_workspace_bytes first.
 static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     const int xf = d->ph[0].transform;
-    if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || d->stride != 1 || d->ups ||
+    if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->ksize != 3 || d->stride != 1 || d->ups ||
         (xf != HSIDM_XF_NONE && xf != HSIDM_XF_AFFINE_SILU) || d->bn != 128 || d->Cout % 128 || (Hout & 7) || (Wout & 7) ||
         d->act != HSIDM_ACT_NONE || debug_get(DBG_NO_SPLIT_K)) return 0;
     const int nchunks = (d->ph[0].C0 + d->ph[0].C1 + 63) / 64;
@@ -65,7 +67,8 @@ static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     // 40 (8x8 / 16x16 levels at 5 latents: 81 -> 37 us, 72 -> 43 us)
     // (two-image 8x8 tiles keep the persistent kernel efficient down to fewer items than one-image 8x16 tiles do)
     if (items * (TW == 8 ? 8 : 4) > conv_v2_slots()) return 0;
-    return conv_sk_parts(d->B, Hout, Wout, d->Cout, nchunks);
+    const int pchunks = d->nphase == 2 ? (d->ph[1].C0 + d->ph[1].C1 + 63) / 64 : 0;
+    return conv_sk_parts(d->B, Hout, Wout, d->Cout, nchunks + pchunks);
 }
 
 // ---- diagnostic switches (common.h: DebugKey) ------------------------------------------------------
@@ -160,7 +163,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
     }
-    if (path == PATH_V2 && d->workspace) {
+    if ((path == PATH_V2 || d->nphase == 2) && d->workspace) {
         const int parts = sk_parts(d, Hout, Wout);
         if (parts > 0 && d->workspace_bytes >= (int64_t)parts * d->B * Hout * Wout * d->Cout * 4) path = PATH_SK;
     }
@@ -186,7 +189,7 @@ extern "C" int64_t hsidm_conv_workspace_bytes(const hsidm_conv_desc* d) {
     probe.workspace = nullptr;
     const int rc = conv_validate(&probe, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
-    if (path != PATH_V2) return 0;
+    if (path != PATH_V2 && d->nphase != 2) return 0;
     const int parts = sk_parts(d, Hout, Wout);
     return (int64_t)parts * d->B * Hout * Wout * d->Cout * 4;
 }
@@ -269,6 +272,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
                            s0.transform == HSIDM_XF_AFFINE_SILU, reinterpret_cast<const bf16*>(d->w_v2), d->bias, d->film, d->film_stride,
                            reinterpret_cast<const bf16*>(d->res), d->res_scale, reinterpret_cast<bf16*>(d->out),
                            reinterpret_cast<float2*>(d->stats), d->B, Hout, Wout, d->Cout, cout_pad, p.ph[0].nchunks,
+                           reinterpret_cast<const bf16*>(p.ph[1].src0), reinterpret_cast<const bf16*>(p.ph[1].src1), p.ph[1].C0, p.ph[1].C1,
                            reinterpret_cast<float*>(d->workspace), s);
     }
     if (use_v2) {

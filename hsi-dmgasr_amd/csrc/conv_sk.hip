@@ -23,6 +23,10 @@ struct ConvSkParams {
     const bf16* w;                  // w_v2 layout
     float* partial;                 // [parts][B*H*W][Cout]
     int C0, C1, nchunks, cpp;       // chunks of 64 channels; chunks per part
+    // fused 1x1 projection of a second input (ResnetBlock.res_conv, reference unet.py:102-103,110): pchunks more chunks of ONE tap
+    // each, untransformed; their weight steps follow the 9 * nchunks steps of the 3x3 kernel
+    const bf16* psrc0; const bf16* psrc1;
+    int PC0, PC1, pchunks;
     int B, H, W, Cout, Cout_pad;
     int tiles_x, tiles_y;
     int silu;
@@ -43,8 +47,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
     const int tpi = p.tiles_x * p.tiles_y;
     const int b = tile / tpi, tr = tile - b * tpi;
     const int ty0 = (tr / p.tiles_x) * TH, tx0 = (tr % p.tiles_x) * TW;
-    const int ctot = p.C0 + p.C1;
-    const int c_begin = part * p.cpp, c_end = min(p.nchunks, c_begin + p.cpp);
+    const int c_begin = part * p.cpp, c_end = min(p.nchunks + p.pchunks, c_begin + p.cpp);
 
     // weight fragments of this wave's 32 couts: [step][Cout_pad/32][kk][lane][8]
     const int nsw = p.Cout_pad >> 5;
@@ -66,25 +69,32 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // the chunk's 36 weight fragments (9 taps x 4 k-slices, 1 KiB per wave-load) are requested first: their L2 latency hides
         // behind the staging of the halo tile (a one-tap-ahead ring was latency-bound: 8 MFMAs per tap against ~0.7 us per fetch)
-        const bf16* wc = wlane + (size_t)chunk * 9 * wstep;
+        const bool proj = chunk >= p.nchunks;                    // workgroup-uniform
+        const int lc = proj ? chunk - p.nchunks : chunk;         // chunk within its phase
+        const bf16* wc = wlane + (size_t)(proj ? p.nchunks * 9 + lc : lc * 9) * wstep;
         bf16x8 wr[9][4];
+        if (!proj) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const bf16x8*>(wc + (size_t)tap * wstep + kk * 64 * 8);
+                for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const bf16x8*>(wc + (size_t)tap * wstep + kk * 64 * 8);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *reinterpret_cast<const bf16x8*>(wc + kk * 64 * 8);
+        }
         // ---- stage the 10 x 10 halo of this chunk's 64 channels (GroupNorm + SiLU on the way; zero padding AFTER the activation) ----
-        const int c = chunk * 64 + cv * 8;
+        const int ctot = proj ? p.PC0 + p.PC1 : p.C0 + p.C1;
+        const int c = lc * 64 + cv * 8;
         const bool cok = c < ctot;
         const int cc = cok ? c : 0;
         const bf16* src;
         int cs, cl;
-        if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; } else { src = p.src1; cs = p.C1; cl = cc - p.C0; }
-        // every request of the chunk goes out before anything waits: the 4 halo vectors are read unconditionally (positions outside
-        // the image or the tile re-read a clamped, valid one and are zeroed at the store) and the GroupNorm parameters come as four
-        // 16-byte loads - a guarded load with its transform behind it was a dependent round trip per vector
+        if (!proj) { if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; } else { src = p.src1; cs = p.C1; cl = cc - p.C0; } }
+        else       { if (cc < p.PC0) { src = p.psrc0; cs = p.PC0; cl = cc; } else { src = p.psrc1; cs = p.PC1; cl = cc - p.PC0; } }
+        const float2* gn = proj ? nullptr : p.gn_ab;
         float sc[8], sh[8];
-        if (p.gn_ab) {
-            const f32x4* q = reinterpret_cast<const f32x4*>(p.gn_ab + (size_t)b * ctot + cc);
+        if (gn) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(gn + (size_t)b * ctot + cc);
             f32x4 r[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) r[k] = q[k];
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
         for (int i = 0; i < MAXHV; ++i) {
             const int hp = (tid >> 3) + i * 32;
             u32x4 o4 = raw[i];
-            if (p.gn_ab) {
+            if (gn) {
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(o4[k] << 16); v[2 * k + 1] = __uint_as_float(o4[k] & 0xffff0000u); }
@@ -124,16 +134,28 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
             if (hp < HPIX) *reinterpret_cast<u32x4*>(halo + hp * PSTR + cv * 8) = o4;
         }
         __syncthreads();
-        // ---- 9 taps x 4 k-slices ----
+        // ---- 9 taps x 4 k-slices (projection chunk: the centre tap only) ----
+        if (!proj) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * HC + (tap % 3)) * PSTR;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * HC + (tap % 3)) * PSTR;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + abase[mt] + toff + kk * 16);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[tap][kk], acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            const int toff = (HC + 1) * PSTR;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + abase[mt] + toff + kk * 16);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[tap][kk], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[0][kk], acc[mt], 0, 0, 0);
                 }
             }
         }
@@ -241,16 +263,18 @@ int conv_sk_parts(int B, int H, int W, int Cout, int nchunks) {
 
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
                 const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
-                int Cout, int Cout_pad, int nchunks, float* workspace, hipStream_t s) {
+                int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, float* workspace, hipStream_t s) {
     ConvSkParams p;
     p.src0 = src0; p.src1 = src1; p.gn_ab = gn_ab; p.w = w; p.partial = workspace;
     p.C0 = C0; p.C1 = C1; p.nchunks = nchunks;
+    p.psrc0 = psrc0; p.psrc1 = psrc1; p.PC0 = PC0; p.PC1 = PC1; p.pchunks = (PC0 + PC1 + 63) / 64;
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.Cout_pad = Cout_pad;
     p.tiles_x = W / 8; p.tiles_y = H / 8;
     p.silu = silu;
     const int tiles = B * p.tiles_x * p.tiles_y, slices = Cout / 128;
-    p.cpp = sk_cpp(tiles, slices, nchunks);
-    const int parts = (nchunks + p.cpp - 1) / p.cpp;
+    const int allchunks = nchunks + p.pchunks;
+    p.cpp = sk_cpp(tiles, slices, allchunks);
+    const int parts = (allchunks + p.cpp - 1) / p.cpp;
     hipLaunchKernelGGL(conv_sk_kernel, dim3(tiles, slices, parts), dim3(256), 0, s, p);
     hipLaunchKernelGGL(conv_sk_finish_kernel, dim3(H * W / 64, B, Cout / 32), dim3(256), 0, s, (const float*)workspace, parts, bias, film,
                        film_stride, res, res_scale, out, stats, B, H * W, Cout);

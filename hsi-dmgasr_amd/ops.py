@@ -50,6 +50,8 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     meta = dict(ksize=kh, cin=cin, cout=cout, bn=bn, cpad=cpad, proj_cin=proj_cin, prec=prec, tap_major=False)
     # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
     # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
+    if prec == _lib.BF16 and proj_weight is not None and kh == 3 and not out_nchw and bn == 128:
+        lay["w_v2"] = PackedConv._lanes(lay["w"], cpad)         # read by the split-K kernel only (conv_sk.hip: projection chunks)
     if prec == _lib.BF16 and proj_weight is None and (not out_nchw or (kh == 3 and bn == 32)):
         wv = lay["w"]
         meta["tap_major"] = kh == 3 and cin == 8
@@ -142,8 +144,11 @@ class PackedConv:
 
 # ------------------------------------------------------------------------------------------- kernels
 def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=None, res_scale=1.0,
-           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=False):
+           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=False, sk_only=False):
     """out = res_scale * act(conv(T(cat(x0, x1))) [+ proj(cat(proj_x0, proj_x1))] + bias + film) + res.
+
+    sk_only: launch only if the dispatch takes its split-K form (few pixel tiles, long contraction), else return None - how a
+    ResnetBlock offers its fused-projection descriptor, which no other bf16 kernel of the throughput mode accepts.
 
     stats=True: the kernel also writes per-(image, tile part, channel) sums of `out`; they ride on the returned
     tensor as ``out._hsidm_stats = (slab [B, nsplit, C, 2], nsplit)`` and feed gn_scale_shift / ca_vector."""
@@ -188,6 +193,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
     d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, (UPS_FOLDED if folded else int(bool(ups))), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
+    nb = 0
     if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and stride == 1 and not ups and pw.bn == 128 and pw.cin >= 200:
         # few pixel tiles x a long contraction (the 8x8 / 16x16 levels at small batches): the split-K form needs scratch
         # (set before the statistics query: the slab's split count depends on the kernel the dispatch picks)
@@ -195,6 +201,8 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         if nb > 0:
             ws = _sk_workspace(int(nb), x0.device)
             d.workspace, d.workspace_bytes = _lib.ptr(ws), ws.numel()
+    if sk_only and nb <= 0:
+        return None
     if stats and not pw.out_nchw:
         nsplit = _lib.lib().hsidm_conv_stats_nsplit(C.byref(d))
         if nsplit <= 0:

@@ -166,12 +166,12 @@ class Block(_HipModule):
             proj_weight=None if proj is None else proj.weight, proj_bias=None if proj is None else proj.bias,
             out_nchw=out_nchw))
 
-    def _run(self, x0, precision, x1=None, film=None, res=None, proj=None, proj_x0=None, proj_x1=None, out_nchw=False):
+    def _run(self, x0, precision, x1=None, film=None, res=None, proj=None, proj_x0=None, proj_x1=None, out_nchw=False, sk_only=False):
         _need_eval(self, self._dropout)
         gn = self.block[0]
         ab = ops.gn_scale_shift(x0, x1, gn.weight, gn.bias, gn.num_groups, precision, gn.eps)
         return ops.conv2d(x0, self._packed(precision, out_nchw, proj), x1=x1, gn_ab=ab, transform=ops.XF_AFFINE_SILU,
-                          film=film, res=res, proj_x0=proj_x0, proj_x1=proj_x1, stats=not out_nchw)
+                          film=film, res=res, proj_x0=proj_x0, proj_x1=proj_x1, stats=not out_nchw, sk_only=sk_only)
 
     def forward(self, x):
         self._check_input(x)
@@ -202,6 +202,13 @@ class ResnetBlock(_HipModule):
                 # block2's epilogue as the residual.  (Measured and dropped, round 2: running it on a second stream beside block1's
                 # convolution - a parallel branch of the captured step - at batches that leave workgroup slots free: the fork / join
                 # costs more than the overlap returns, 2.98 vs 2.83 ms per step at 5 latents, 5.03 vs 4.93 at 40, in-box A/B.)
+                # Few pixel tiles and a long contraction (one or two CAVE images per GPU on the 32x32 ... 8x8 levels): block2 runs in
+                # its split-K form, where the projection is a few more one-tap chunks of the same launch.
+                B, H, W, _ = h.shape
+                if B * H * W <= 4096 and h.shape[3] % 128 == 0 and h.shape[3] >= 256:
+                    out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, sk_only=True)
+                    if out is not None:
+                        return out
                 rc = self.res_conv
                 pk = self._cache.get(("proj", precision), [rc.weight, rc.bias], lambda: ops.PackedConv(rc.weight, rc.bias, precision))
                 r = ops.conv2d(x0, pk, x1=x1)

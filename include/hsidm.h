@@ -115,7 +115,10 @@ typedef struct hsidm_conv_desc {
     int32_t bn;               /* cout slice the weights were packed for: 32, 64 or 128             */
     void*   workspace;        /* optional scratch of hsidm_conv_workspace_bytes(d) bytes: enables the split-K form
                                  (csrc/conv_sk.hip) for launches with few pixel tiles and a long contraction -
-                                 the 8x8 / 16x16 levels at small batches; NULL: the persistent kernels only    */
+                                 the 8x8 / 16x16 levels at small batches; NULL: the persistent kernels only.
+                                 With nphase == 2 and w_v2 (its steps: 9 per chunk of phase 0, then 1 per chunk of
+                                 phase 1) the split form is the only w_v2 kernel that applies: ask
+                                 hsidm_conv_workspace_bytes first, 0 = launch the projection separately         */
     int64_t workspace_bytes;
 } hsidm_conv_desc;
 

@@ -528,6 +528,54 @@ def test_split_k_convolution_matches_the_persistent_kernel(dev, case):
     check("conv_sk_vs_torch%s" % (case,), "bf16", outs[1], want, tol=6e-3)
 
 
+SKP_CASES = [  # B, H, W, C (block2's width), P0, P1 (the projection's concat input)
+    (5, 8, 8, 512, 512, 512),       # ups[0]-like block at one CAVE image: 8 + 16 chunks
+    (5, 16, 16, 512, 512, 256),     # 768-channel concat, 16x16 level
+    (2, 32, 32, 256, 200, 0),       # ragged projection chunk (200 channels), 32x32 level
+]
+
+
+@pytest.mark.parametrize("case", SKP_CASES)
+def test_split_k_convolution_with_fused_projection(dev, case):
+    """ResnetBlock tail (reference unet.py:105-111) in one launch: block2's GroupNorm + SiLU + 3x3 conv plus res_conv's 1x1 projection of
+    the block input as extra one-tap chunks of the split-K kernel, against the two-launch form (projection on the GEMM kernel, entering
+    as the residual) and against torch."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Cc, P0, P1 = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
+    bias = torch.randn(Cc, generator=g)
+    wp = torch.randn(Cc, P0 + P1, 1, 1, generator=g) / (P0 + P1) ** 0.5
+    bp = torch.randn(Cc, generator=g)
+    fused = ops.PackedConv(w.to(dev), bias.to(dev), "bf16", proj_weight=wp.to(dev), proj_bias=bp.to(dev))
+    assert fused.w_v2 is not None and fused.proj_cin == (P0 + P1 + 7) // 8 * 8
+    pk2, pkp = ops.PackedConv(w.to(dev), bias.to(dev), "bf16"), ops.PackedConv(wp.to(dev), bp.to(dev), "bf16")
+    hh = torch.randn(B, H, W, Cc, generator=g).to(dev, torch.bfloat16)
+    x0 = torch.randn(B, H, W, P0, generator=g).to(dev, torch.bfloat16)
+    x1 = torch.randn(B, H, W, P1, generator=g).to(dev, torch.bfloat16) if P1 else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, Cc, generator=g), 0.1 * torch.randn(B, Cc, generator=g)], 2).contiguous()
+    tab = ops.gn_table(ab.to(dev))
+    recs = []
+    ops.set_conv_probe(recs)
+    y = ops.conv2d(hh, fused, gn_ab=tab, transform=ops.XF_AFFINE_SILU, proj_x0=x0, proj_x1=x1, stats=True, sk_only=True)
+    ops.set_conv_probe(None)
+    assert y is not None and recs[-1]["kernel"].startswith("conv_sk"), recs
+    torch.cuda.synchronize()
+    assert_stats(y._hsidm_stats[0], y, 0)
+    r = ops.conv2d(x0, pkp, x1=x1)
+    y2 = ops.conv2d(hh, pk2, gn_ab=tab, transform=ops.XF_AFFINE_SILU, res=r, stats=True)
+    check("conv_sk_proj_vs_two_launches%s" % (case,), "bf16", y, y2.float().cpu(), tol=5e-3)
+    a = torch.nn.functional.silu(hh.float().cpu() * ab[:, None, None, :, 0] + ab[:, None, None, :, 1]).to(torch.bfloat16).float()
+    xin = (torch.cat([x0, x1], dim=3) if P1 else x0).float().cpu()
+    want = torch.nn.functional.conv2d(a.permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), bias, padding=1)
+    want = want + torch.nn.functional.conv2d(xin.permute(0, 3, 1, 2), wp.to(torch.bfloat16).float(), bp)
+    check("conv_sk_proj_vs_torch%s" % (case,), "bf16", y, want.permute(0, 2, 3, 1), tol=6e-3)
+    # a batch that fills the chip: the descriptor is refused (the caller launches the projection on its own)
+    big = ops.conv2d(hh.repeat(16, 1, 1, 1), fused, gn_ab=ops.gn_table(ab.repeat(16, 1, 1).to(dev)), transform=ops.XF_AFFINE_SILU,
+                     proj_x0=x0.repeat(16, 1, 1, 1), proj_x1=None if x1 is None else x1.repeat(16, 1, 1, 1), sk_only=True)
+    assert big is None
+
+
 def test_final_block_conv_on_the_256_pixel_kernel(dev, monkeypatch):
     """The UNet's last conv (GroupNorm + SiLU + 3x3, 64 -> 3, fp32 NCHW out; reference unet.py:231,262) on conv_v3<WN = 1, NCHW>
     against the generic kernel (HSIDM_NO_V3=1) and against torch fp32."""
