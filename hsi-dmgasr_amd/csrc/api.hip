@@ -23,7 +23,8 @@ void conv_v2_set_stamps(unsigned long long* p);
 int conv_sk_parts(int B, int H, int W, int Cout, int nchunks);
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
                 const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
-                int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, float* workspace, hipStream_t s);
+                int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, int stride, float* workspace,
+                hipStream_t s);
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
                   const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
                   int nch, int im_H, int im_W, hipStream_t s);
@@ -55,9 +56,11 @@ enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 // takes it (the persistent kernels are single-phase), so the caller asks hsidm_conv_workspace_bytes first.
 static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     const int xf = d->ph[0].transform;
-    if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->ksize != 3 || d->stride != 1 || d->ups ||
+    if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->ksize != 3 || d->ups ||
         (xf != HSIDM_XF_NONE && xf != HSIDM_XF_AFFINE_SILU) || d->bn != 128 || d->Cout % 128 || (Hout & 7) || (Wout & 7) ||
         d->act != HSIDM_ACT_NONE || debug_get(DBG_NO_SPLIT_K)) return 0;
+    // stride 2 (Downsample): the parity-plane weights, even input maps, no transform, no projection
+    if (d->stride == 2 && (xf != HSIDM_XF_NONE || d->nphase != 1 || (d->Hin & 1) || (d->Win & 1))) return 0;
     const int nchunks = (d->ph[0].C0 + d->ph[0].C1 + 63) / 64;
     if (nchunks < 4) return 0;
     const int TW = Wout >= 16 ? 16 : 8;
@@ -273,7 +276,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
                            reinterpret_cast<const bf16*>(d->res), d->res_scale, reinterpret_cast<bf16*>(d->out),
                            reinterpret_cast<float2*>(d->stats), d->B, Hout, Wout, d->Cout, cout_pad, p.ph[0].nchunks,
                            reinterpret_cast<const bf16*>(p.ph[1].src0), reinterpret_cast<const bf16*>(p.ph[1].src1), p.ph[1].C0, p.ph[1].C1,
-                           reinterpret_cast<float*>(d->workspace), s);
+                           d->stride, reinterpret_cast<float*>(d->workspace), s);
     }
     if (use_v2) {
         ConvV2Params v;

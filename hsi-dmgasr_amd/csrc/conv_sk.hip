@@ -27,18 +27,24 @@ struct ConvSkParams {
     // each, untransformed; their weight steps follow the 9 * nchunks steps of the 3x3 kernel
     const bf16* psrc0; const bf16* psrc1;
     int PC0, PC1, pchunks;
-    int B, H, W, Cout, Cout_pad;
+    int B, H, W, Hin, Win, Cout, Cout_pad;          // H, W: output map; Hin, Win: input map (= H, W unless stride 2)
     int tiles_x, tiles_y;
     int silu;
 };
 
-namespace sk {
-constexpr int TH = 8, TW = 8, HR = TH + 2, HC = TW + 2, HPIX = HR * HC, PSTR = 72, VPP = 8;
-constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;            // 800 vectors, 4 per thread (the last round partial)
-}  // namespace sk
+// S = 1: 10 x 10 halo of an 8 x 8 output tile.  S = 2 (Downsample, reference unet.py:68-74: 3x3, stride 2, pad 1): 17 x 17 input
+// pixels, output (r, c) reads input (2r + ky, 2c + kx) of the tile; the weights are the parity-plane layout the persistent kernel
+// uses for these layers (include/hsidm.h: stride = 2 with w_v2), addressed by the plane / window tap of each 3x3 tap.
+template <int S>
+struct SkGeo {
+    static constexpr int TH = 8, TW = 8, HR = S * TH + 3 - S, HC = S * TW + 3 - S, HPIX = HR * HC, PSTR = 72, VPP = 8;
+    static constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;   // S = 1: 800 vectors, 4 per thread; S = 2: 2312, 10 per thread
+};
 
+template <int S>
 __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
-    using namespace sk;
+    using G = SkGeo<S>;
+    constexpr int TH = G::TH, TW = G::TW, HC = G::HC, HPIX = G::HPIX, PSTR = G::PSTR, MAXHV = G::MAXHV;
     __shared__ __attribute__((aligned(16))) bf16 halo[HPIX * PSTR];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
     // A fragment base of the two 32-pixel MFMA tiles (tile rows 4 mt .. 4 mt + 3): lane = (row lr / 8, column lr % 8), k half lh
     int abase[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) abase[mt] = ((4 * mt + (lr >> 3)) * HC + (lr & 7)) * PSTR + 8 * lh;
+    for (int mt = 0; mt < 2; ++mt) abase[mt] = (S * (4 * mt + (lr >> 3)) * HC + S * (lr & 7)) * PSTR + 8 * lh;
 
     f32x16 acc[2];
 #pragma unroll
@@ -75,9 +81,15 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
         bf16x8 wr[9][4];
         if (!proj) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < 9; ++tap) {
+                // S = 2: 3x3 tap (dy, dx) lives in plane (dy != 1, dx != 1) at window tap (dy == 1 ? 1 : dy / 2, dx likewise);
+                // step = (plane * nchunks + chunk) * 4 + window tap
+                const int dy = tap / 3, dx = tap % 3;
+                const int plane = 2 * (dy != 1) + (dx != 1), wt = 2 * (dy == 1 ? 1 : dy / 2) + (dx == 1 ? 1 : dx / 2);
+                const bf16* wt_p = S == 1 ? wc + (size_t)tap * wstep : wlane + ((size_t)(plane * p.nchunks + lc) * 4 + wt) * wstep;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const bf16x8*>(wc + (size_t)tap * wstep + kk * 64 * 8);
+                for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const bf16x8*>(wt_p + kk * 64 * 8);
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *reinterpret_cast<const bf16x8*>(wc + kk * 64 * 8);
@@ -107,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
         for (int i = 0; i < MAXHV; ++i) {
             const int hp = min((tid >> 3) + i * 32, HPIX - 1);
             const int hy = hp / HC, hx = hp - hy * HC;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            okv[i] = cok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            raw[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b * p.H + cy) * p.W + cx) * cs + cl);
+            const int iy = S * ty0 + hy - 1, ix = S * tx0 + hx - 1;
+            okv[i] = cok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
+            raw[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b * p.Hin + cy) * p.Win + cx) * cs + cl);
         }
         __syncthreads();                                         // the previous chunk's readers are done
 #pragma unroll
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
                 }
             }
         } else {
-            const int toff = (HC + 1) * PSTR;
+            const int toff = (HC + 1) * PSTR;                   // (projections only come with S = 1)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -263,19 +275,21 @@ int conv_sk_parts(int B, int H, int W, int Cout, int nchunks) {
 
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
                 const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
-                int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, float* workspace, hipStream_t s) {
+                int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, int stride, float* workspace,
+                hipStream_t s) {
     ConvSkParams p;
     p.src0 = src0; p.src1 = src1; p.gn_ab = gn_ab; p.w = w; p.partial = workspace;
     p.C0 = C0; p.C1 = C1; p.nchunks = nchunks;
     p.psrc0 = psrc0; p.psrc1 = psrc1; p.PC0 = PC0; p.PC1 = PC1; p.pchunks = (PC0 + PC1 + 63) / 64;
-    p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.Cout_pad = Cout_pad;
+    p.B = B; p.H = H; p.W = W; p.Hin = stride * H; p.Win = stride * W; p.Cout = Cout; p.Cout_pad = Cout_pad;
     p.tiles_x = W / 8; p.tiles_y = H / 8;
     p.silu = silu;
     const int tiles = B * p.tiles_x * p.tiles_y, slices = Cout / 128;
     const int allchunks = nchunks + p.pchunks;
     p.cpp = sk_cpp(tiles, slices, allchunks);
     const int parts = (allchunks + p.cpp - 1) / p.cpp;
-    hipLaunchKernelGGL(conv_sk_kernel, dim3(tiles, slices, parts), dim3(256), 0, s, p);
+    if (stride == 2) hipLaunchKernelGGL(conv_sk_kernel<2>, dim3(tiles, slices, parts), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_sk_kernel<1>, dim3(tiles, slices, parts), dim3(256), 0, s, p);
     hipLaunchKernelGGL(conv_sk_finish_kernel, dim3(H * W / 64, B, Cout / 32), dim3(256), 0, s, (const float*)workspace, parts, bias, film,
                        film_stride, res, res_scale, out, stats, B, H * W, Cout);
     return (int)hipGetLastError();

@@ -194,7 +194,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, (UPS_FOLDED if folded else int(bool(ups))), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
     nb = 0
-    if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and stride == 1 and not ups and pw.bn == 128 and pw.cin >= 200:
+    if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and not ups and pw.bn == 128 and pw.cin >= 200:
         # few pixel tiles x a long contraction (the 8x8 / 16x16 levels at small batches): the split-K form needs scratch
         # (set before the statistics query: the slab's split count depends on the kernel the dispatch picks)
         nb = _lib.lib().hsidm_conv_workspace_bytes(C.byref(d))

@@ -205,7 +205,7 @@ class ResnetBlock(_HipModule):
                 # Few pixel tiles and a long contraction (one or two CAVE images per GPU on the 32x32 ... 8x8 levels): block2 runs in
                 # its split-K form, where the projection is a few more one-tap chunks of the same launch.
                 B, H, W, _ = h.shape
-                if B * H * W <= 4096 and h.shape[3] % 128 == 0 and h.shape[3] >= 256:
+                if B * H * W <= 16384 and h.shape[3] % 128 == 0 and h.shape[3] >= 256:
                     out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, sk_only=True)
                     if out is not None:
                         return out

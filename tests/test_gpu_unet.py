@@ -687,6 +687,36 @@ def test_stride2_conv_over_parity_planes_matches_v1_and_torch(dev, case):
     check("dn4_vs_torch%s" % (case,), "bf16", outs[1], ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("case", [(5, 16, 16, 512, 512), (5, 32, 32, 256, 256), (3, 16, 32, 328, 128)])
+def test_split_k_stride2_convolution(dev, case):
+    """Downsample conv (3x3, stride 2, pad 1) at one CAVE image per GPU: the split-K kernel's stride-2 form (17x17 input halo, the
+    parity-plane weights addressed per 3x3 tap) against the persistent plane-wise kernel (debug switch NO_SPLIT_K) and torch."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pk = ops.PackedConv(w.to(dev), bias.to(dev), "bf16", fold_dn=True)
+    x = torch.randn(B, H, W, Ci, generator=g).to(dev, torch.bfloat16)
+    res = torch.randn(B, H // 2, W // 2, Co, generator=g).to(dev, torch.bfloat16)       # the training step's input gradient adds one
+    outs, labels = [], []
+    for no_sk in (1, 0):
+        recs = []
+        with _lib.debug_switch("NO_SPLIT_K", no_sk):
+            ops.set_conv_probe(recs)
+            y = ops.conv2d(x, pk, stride=2, res=res, stats=True)
+            ops.set_conv_probe(None)
+            torch.cuda.synchronize()
+        assert_stats(y._hsidm_stats[0], y, no_sk)
+        outs.append(y.float().cpu())
+        labels.append(recs[-1]["kernel"])
+    assert labels[0].startswith("conv_v2") and labels[1].startswith("conv_sk"), labels
+    ref = torch.nn.functional.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), bias, stride=2, padding=1)
+    ref = ref.permute(0, 2, 3, 1) + res.float().cpu()
+    check("conv_sk_s2_vs_v2%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
+    check("conv_sk_s2_vs_torch%s" % (case,), "bf16", outs[1], ref, tol=6e-3)
+
+
 @pytest.mark.parametrize("case", [(3, 24, 16, 6, 64), (3, 16, 24, 6, 64), (2, 16, 8, 8, 128), (1, 16, 16, 6, 32), (2, 32, 32, 5, 64), (3, 8, 8, 8, 64)])
 def test_eight_channel_conv_as_tap_major_gemm(dev, case):
     """3x3 convs with <= 8 input channels (the UNet stem) run as a K = 72 GEMM (conv1x1_g, im2col on the fly); shapes the
