@@ -69,7 +69,10 @@ static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     // kernel passes that once it has ~80 work items (8x8 level at 40 latents: 55 us vs 61 us), and falls to 37-170 TFLOP/s below
     // 40 (8x8 / 16x16 levels at 5 latents: 81 -> 37 us, 72 -> 43 us)
     // (two-image 8x8 tiles keep the persistent kernel efficient down to fewer items than one-image 8x16 tiles do)
-    if (items * (TW == 8 ? 8 : 4) > conv_v2_slots()) return 0;
+    // (stride 2 on 8x8 output maps: the persistent plane-wise kernel walks 16 window taps per chunk in sequence - 69 us at 40 latents
+    // against 41 us split, profiles/r02_small_batch/sk_mult.txt; SK_MULT: threshold experiments)
+    const int mult = debug_get(DBG_SK_MULT) > 0 ? debug_get(DBG_SK_MULT) : (TW == 8 ? (d->stride == 2 ? 4 : 8) : 4);
+    if (items * mult > conv_v2_slots()) return 0;
     const int pchunks = d->nphase == 2 ? (d->ph[1].C0 + d->ph[1].C1 + 63) / 64 : 0;
     return conv_sk_parts(d->B, Hout, Wout, d->Cout, nchunks + pchunks);
 }
@@ -87,12 +90,12 @@ struct DebugTable {
         const char* e = getenv("HSIDM_1X1");
         v[hsidm::DBG_1X1_V1] = (e && e[0] == 'v') ? 1 : 0;
         v[hsidm::DBG_V2_ABL] = env_int("HSIDM_V2_ABL", 0);
-        v[hsidm::DBG_NO_FUSED_PROJ] = getenv("HSIDM_NO_FUSED_PROJ") ? 1 : 0;
+        v[hsidm::DBG_SK_MULT] = env_int("HSIDM_SK_MULT", 0);
         v[hsidm::DBG_NO_SPLIT_K] = getenv("HSIDM_NO_SPLIT_K") ? 1 : 0;
     }
 };
 DebugTable g_debug;          // constructed when the library is loaded
-const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "NO_FUSED_PROJ", "NO_SPLIT_K"};
+const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K"};
 }  // namespace
 int hsidm::debug_get(int key) { return g_debug.v[key].load(std::memory_order_relaxed); }
 
@@ -183,7 +186,19 @@ static int v2_slice(const hsidm_conv_desc* d, int Hout, int Wout, int tile_kind,
         d->ph[0].transform != HSIDM_XF_AFFINE_SILU || d->Cout % 256) return d->bn;
     const int TW = tile_kind == 0 ? 16 : 8;
     const long long tiles = (long long)((d->B + (tile_kind == 1)) / (tile_kind == 1 ? 2 : 1)) * ((Wout + TW - 1) / TW) * ((Hout + 7) / 8);
-    return tiles * (d->Cout / 256) >= conv_v2_slots() / 4 ? 256 : d->bn;       // at least half of the CUs get an item
+    const long long items256 = tiles * (d->Cout / 256);
+    const int cus = conv_v2_slots() / 2;
+    if (items256 < cus / 2) return d->bn;                                      // at least half of the CUs get an item
+    if (on == 2) return 256;                                                   // (A/B: the rule without the makespan comparison)
+    if (items256 <= cus) return 256;                                           // one round either way: the form with less staging
+    // More than one round of 256-cout items: the last, partly filled round costs a whole item.  128-cout items fill the tail
+    // better - two are resident per CU, each 1.07 item-times when it shares the CU and ~0.6 when it has the CU to itself
+    // (measured: +7 % for the 128-cout form at full occupancy, conv_bench at batch 40) - so compare the two makespans, in units
+    // of one 256-cout item (40 latents, 32x32 level: 320 items = 2 rounds against 1.07 + 0.6; 240 latents: 8 against 8.1).
+    const double t256 = (double)((items256 + cus - 1) / cus);
+    const long long items128 = 2 * items256, full = items128 / (2 * cus), rem = items128 % (2 * cus);
+    const double t128 = 1.07 * (double)full + (rem == 0 ? 0.0 : (rem <= cus ? 0.6 : 1.07));
+    return t256 <= t128 ? 256 : d->bn;
 }
 
 extern "C" int64_t hsidm_conv_workspace_bytes(const hsidm_conv_desc* d) {
