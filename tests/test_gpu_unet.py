@@ -346,10 +346,12 @@ def test_strided_ddim_sampler_matches_oracle(dev, steps, eta):
     assert gd.super_resolution(cond, continous=False).shape == (3, 16, 16)
 
 
-@pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96)])
+@pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96), (136, 16, 16, 128),
+                                   (260, 8, 8, 64), (3, 16, 16, 64)])
 def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
-    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (N = 64 / 256, C % 64 == 0), the panel
-    kernel it replaces (other shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same bf16 inputs."""
+    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (N = 64 / 256, C % 64 == 0; 136 / 260 images: more
+    workgroups than CUs), the panel kernel it replaces (other shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same bf16
+    inputs."""
     from hsi_dmgasr_amd import ops
     B, H, W, C = shape
     g = torch.Generator().manual_seed(sum(shape))
