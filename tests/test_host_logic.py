@@ -252,3 +252,29 @@ def test_bench_strong_scaling_shards_cover_all_patches():
         assert spans[0][0] == 0 and spans[-1][1] == 64
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_bench_launches_itself_for_several_gpus(monkeypatch):
+    """`python bench.py --gpus 4` from a plain shell (no WORLD_SIZE): torch.distributed.run as a CHILD process, one rank per GPU, rendezvous
+    on 127.0.0.1, the caller's flags passed through - and nothing touches torch.cuda in the parent (the box refuses an exec after that)."""
+    import importlib.util
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched in the parent")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "3", "--total-patches", "64"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the child's return code is the parent's
+    (cmd, env), = calls
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-8:] == ["--gpus", "4", "--steps", "20", "--warmup", "3", "--total-patches", "64"] and cmd[-9].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
