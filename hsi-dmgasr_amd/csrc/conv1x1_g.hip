@@ -24,6 +24,18 @@
 #include "conv_v2.h"
 #include "../../include/hsidm.h"
 
+// Diagnostic builds (-DG1_ABL=n, tools/g1_ablate.sh): 1 no activation loads, 2 no weight loads, 3 no MFMAs, 4 no A-fragment LDS
+// reads, 5 no barriers, 6 no output stores, 7 no epilogue, 8 no statistics (results are wrong; timing only).  The product build has
+// G1_ABL = 0 and none of this code.  What it showed at batch 240 (profiles/r02_small_batch/g1_ablate.txt): no single piece of the K
+// loop is worth more than 5 % (the MFMAs: 93 -> 89 us on the 1024 -> 512 projection) except the activation loads (-21 %), and the
+// epilogue as a whole is 20-40 % of a launch (qkv 128 -> 76 us without it; its stores alone 7-14 %): per item ~6.5 us against
+// 1.15 us per 64-channel chunk.  Tried on that evidence and dropped: the tile transposed by swapping the MFMA operands, stored
+// straight from the accumulators (8 bytes per lane: slower, 167 vs 147 us on qkv) or through a patch written with two
+// ds_write_b128 per lane and tile instead of sixteen ds_write_b16 (no change: the b16 writes are not what the epilogue costs).
+#ifndef G1_ABL
+#define G1_ABL 0
+#endif
+
 namespace hsidm {
 
 struct C1gParams {
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     bf16x8 fring[8];
     int wnext = 0;
     auto f_issue = [&](bf16x8& dst, int kk) __attribute__((always_inline)) {
-        dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)wnext * wstep_stride + kk * 64 * 8);
+        if (G1_ABL != 2) dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)wnext * wstep_stride + kk * 64 * 8);
         if (kk == 3) wnext = (wnext + 1 == p.nch) ? 0 : wnext + 1;
     };
 
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             for (int i = 0; i < 4; ++i) {
                 int m = m0 + i * 32 + px_l;
                 m = m < p.M ? m : p.M - 1;
-                hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
+                if (G1_ABL != 1) hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
             }
         }
         if (++st_chunk == p.nch) { st_chunk = 0; st_item += G; st_m0 += m0_step; }
@@ -207,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 bf16x8 a[3][MR];
                 auto a_fetch = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + u * 16);
+                    for (int mr = 0; mr < MR; ++mr)
+                        if (G1_ABL != 4) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + u * 16);
                 };
                 a_fetch(0);
                 a_fetch(1);
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr)
                             acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], fring[0], zero, 0, 0, 0);
-                    } else {
+                    } else if (G1_ABL != 3) {
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr)
                             acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3][mr], fring[u % 8], acc[mr], 0, 0, 0);
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                     if (kk == 1) { commit(PAR ^ 1, 0, PAR ^ 1); commit(PAR ^ 1, 1, PAR ^ 1); }
                     if (kk == 2) { commit(PAR ^ 1, 2, PAR ^ 1); commit(PAR ^ 1, 3, PAR ^ 1); }
                 }
-                lds_barrier();
+                if (G1_ABL != 5) lds_barrier();
             };
             body(SlotTag<0>{});
             body(SlotTag<1>{});
@@ -288,11 +301,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                             o[k] = (bf16)f[k];
                         }
                     }
-                    *reinterpret_cast<bf16x8*>(p.out + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
+                    if (G1_ABL != 6) *reinterpret_cast<bf16x8*>(p.out + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
                 }
-                if (p.stats) {
+                if (p.stats && G1_ABL != 8) {
                     // halving butterfly over the 16 lanes that hold the same 8 couts (see conv_v2.h)
                     const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
                     float a8[8], a4[4], a2[2];
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 }
             }
         };
-        if (p.res) run(SlotTag<1>{}); else run(SlotTag<0>{});
+        if (G1_ABL != 7) { if (p.res) run(SlotTag<1>{}); else run(SlotTag<0>{}); }
         lds_barrier();                                                  // the patch is the next odd chunk's buffer
     }
 }
