@@ -362,6 +362,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode object")
     ap.add_argument("--no-gae", action="store_true", help="skip the group-autoencoder object")
+    ap.add_argument("--no-small", action="store_true", help="skip the small-batch object (40 and 5 latents per GPU)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step object (BASELINE configs[4])")
     ap.add_argument("--workload", default="sample", choices=["sample", "train"],
                     help="sample: the headline metric (reverse-diffusion steps); train: BASELINE configs[4], one joint-train step "
@@ -474,6 +475,27 @@ def main():
             del run32
         torch.cuda.empty_cache()
         log('fp32 mode done')
+    small = None
+    if rank == 0 and world == 1 and not args.no_small and args.precision == "bf16" and batch > 8 * GROUPS:
+        # the same step at the per-GPU share of BASELINE configs[3] on 8 GPUs (8 patches = 40 latents) and at one CAVE image (the
+        # reference's own use: 5 latents): what strong scaling and single-image latency are made of
+        small = {}
+        with torch.no_grad():
+            for pp in (8, 1):
+                b = pp * GROUPS
+                r = gd.make_run(cond[:b].contiguous(), wrap=True)
+                for _ in range(3):
+                    r.step()
+                torch.cuda.synchronize()
+                n = max(50, min(300, args.steps))
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    r.step()
+                torch.cuda.synchronize()
+                d = time.perf_counter() - t0
+                small["%d_latents" % b] = dict(value=n * b / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n)
+                del r
+        log('small batches done')
     gae_rec = None
     if rank == 0 and not args.no_gae:
         with torch.no_grad():
@@ -504,7 +526,7 @@ def main():
                        "patches_per_gpu": patches, "total_patches": total_patches, "groups_per_patch": GROUPS,
                        "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": allgather_ms,
-            "roofline": roof, "fp32_mode": fp32, "gae": gae_rec, "train_step": train_rec, "cpu_baseline": cpu,
+            "roofline": roof, "fp32_mode": fp32, "small_batches": small, "gae": gae_rec, "train_step": train_rec, "cpu_baseline": cpu,
         }
         flush_c_stdio()
         print(json.dumps(line), flush=True)
