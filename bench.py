@@ -531,6 +531,7 @@ def main():
         flush_c_stdio()
         print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()                     # rank 0's extra measurements are done: every rank leaves the group together
         dist.destroy_process_group()
 
 
