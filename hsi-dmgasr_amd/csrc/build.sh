@@ -14,8 +14,10 @@ OBJ="${HSIDM_OBJ:-$OBJ}"
 mkdir -p "$OBJ"
 JOBS="${JOBS:-6}"
 pids=()
+objs=()
 for src in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${src%.hip}").o"
+  objs+=("$o")            # link exactly the objects of the sources present (a stale object of a removed file would still link)
   if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ -n "$(find "$HERE" -maxdepth 1 \( -name '*.h' -o -name '*.inc' \) -newer "$o")" ] || [ "$HERE/../../include/hsidm.h" -nt "$o" ]; then
     ( $HIPCC $FLAGS -c "$src" -o "$o" ) &
     pids+=($!)
@@ -25,5 +27,5 @@ done
 fail=0
 for p in "${pids[@]}"; do wait "$p" || fail=1; done
 [ $fail -eq 0 ] || { echo "hsidm build: compile failed" >&2; exit 1; }
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
 echo "built $OUT"
