@@ -246,3 +246,33 @@ def test_repacking_follows_in_place_reinitialisation(dev):
     torch.cuda.synchronize()
     assert not torch.equal(a, b)
     assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_every_object():
+    """`python bench.py` end to end at a reduced size (12 patches = 60 latents, 6 timed steps) as the driver runs it: ONE JSON object
+    on the last line of stdout with the contract's keys, the roofline of the dominant kernel, both precision modes, the small-batch,
+    group-autoencoder and training-step objects and the CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--patches", "12", "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16"
+    assert d["config"]["batch_per_gpu"] == 60 and "workload" in d["config"]
+    assert abs(d["value"] - 6 * 60 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["hbm_view"]["fused_unit"]["frac"] < rf["hbm_view"]["frac"]
+    assert d["fp32_mode"]["value"] > 0 and d["fp32_mode"]["roofline"]["mfma_passes_per_product"] == 3
+    assert set(d["small_batches"]) == {"40_latents", "5_latents"} and all(v["value"] > 0 for v in d["small_batches"].values())
+    assert d["gae"]["bf16"]["encode_ms"] > 0 and d["train_step"]["bf16"]["graph_ms_per_step"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]
