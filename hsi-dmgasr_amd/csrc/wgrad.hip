@@ -21,7 +21,8 @@ namespace hsidm {
 struct WgradParams {
     const void* a0; const void* a1; const void* dy;
     float* ws;
-    float* bias_ws;                    // [nsplit][Cout_pad] partial sums of dy over the pixels (the bias gradient), or null
+    float* bias_ws;                    // partial sums of dy over the pixels (the bias gradient), or null:
+    int bias_images;                   //   0: [nsplit][Cout_pad];  B: per image, [nsplit][B][Cout_pad] (FiLM's gradient needs them apart)
     int C0, C1, Cin, Cout;             // tensor channel counts (multiples of 8)
     int B, Hin, Win, Hout, Wout;
     int tiles_x, tiles_y, ksteps, nsplit;
@@ -73,6 +74,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     f32x16 accb;
 #pragma unroll
     for (int j = 0; j < 16; ++j) accb[j] = 0.f;
+
+    // per-image sums: a split is a run of pixel tiles in image order, so its tile of sums is written out and restarted whenever the
+    // image changes; the images a split never sees get zeros (every entry of the workspace is written exactly once)
+    const int nimg = p.bias_images;
+    auto bias_flush = [&](int b) __attribute__((always_inline)) {
+        if ((lane & 31) == 0) {
+            float* dst = p.bias_ws + ((size_t)(nimg ? split * nimg + b : split)) * p.Cout_pad + co0 + 32 * wm;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dst[(j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)] = accb[j];
+        }
+    };
+    int cur_b = s_begin / tpi;
+    const int first_b = cur_b;
 
     u32x4 rd[C::NV_D], ra[C::NV_A];
     auto issue = [&](int step) __attribute__((always_inline)) {
@@ -130,6 +144,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         commit();
         __syncthreads();
         if (step + 1 < s_end) issue(step + 1);
+        if (do_bias && nimg) {
+            const int b_step = step / tpi;
+            if (b_step != cur_b) {                           // workgroup-uniform
+                bias_flush(cur_b);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) accb[j] = 0.f;
+                cur_b = b_step;
+            }
+        }
         if constexpr (!C::F32) {
             // k index of an MFMA k-group (16 pixels): k = 8h + j  <->  pixel (row kg, x = 8h + j) for TW = 16,
             //                                                        pixel (row 2kg + h, x = j) for TW = 8
@@ -192,10 +215,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             dst[(size_t)m * p.Cin_pad + n] = acc[t][j];
         }
     }
-    if (do_bias && (lane & 31) == 0) {                       // every column of the ones-tile holds the same sums: column 0 leaves
+    if (do_bias) {                                           // every column of the ones-tile holds the same sums: column 0 leaves
+        if (s_begin < s_end || !nimg) bias_flush(nimg ? cur_b : 0);
+        if (nimg) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            p.bias_ws[(size_t)split * p.Cout_pad + co0 + 32 * wm + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)] = accb[j];
+            for (int j = 0; j < 16; ++j) accb[j] = 0.f;
+            for (int b = 0; b < nimg; ++b)
+                if (s_begin >= s_end || b < first_b || b > cur_b) bias_flush(b);
+        }
     }
 }
 
@@ -337,7 +364,7 @@ static int wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wou
     const int per = (pl.ksteps + ns - 1) / ns;
     pl.nsplit = (pl.ksteps + per - 1) / per;                          // no empty split
     pl.bias_off = (size_t)pl.nsplit * per_split;                      // [nsplit][Cout_pad] bias partials behind the weight partials
-    pl.ws_bytes = pl.bias_off + (size_t)pl.nsplit * pl.Cout_pad * sizeof(float);
+    pl.ws_bytes = pl.bias_off + (size_t)pl.nsplit * B * pl.Cout_pad * sizeof(float);      // room for the per-image form
     return HSIDM_OK;
 }
 
@@ -396,10 +423,11 @@ extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0
     if (rc != HSIDM_OK) return rc;
     if (!a0 || (C1 > 0 && !a1) || !dy || !workspace || Cout_w <= 0 || Cout_w > Cout || Cin_w <= 0 || Cin_w > C0 + C1) return HSIDM_E_BADARG;
     if ((size_t)workspace_bytes < pl.ws_bytes) return HSIDM_E_BADARG;
-    if (with_bias && dw && !db) return HSIDM_E_BADARG;
+    if (with_bias < 0 || with_bias > 2 || (with_bias && dw && !db)) return HSIDM_E_BADARG;
     WgradParams p;
     p.a0 = a0; p.a1 = C1 > 0 ? a1 : nullptr; p.dy = dy; p.ws = (float*)workspace;
     p.bias_ws = with_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.bias_off) : nullptr;
+    p.bias_images = with_bias == 2 ? B : 0;
     p.C0 = C0; p.C1 = C1; p.Cin = C0 + C1; p.Cout = Cout;
     p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ksteps = pl.ksteps; p.nsplit = pl.nsplit;
@@ -415,8 +443,11 @@ extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0
     const int ppb = reduce_ppb(pl.nsplit);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
                        pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw);
-    if (with_bias)                                  // the bias partials are a [nsplit][1 tap][Cout_pad][1] stack of the same kind
+    if (with_bias == 1)                             // the bias partials are a [nsplit][1 tap][Cout_pad][1] stack of the same kind
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout_w + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)p.bias_ws, pl.nsplit,
                            1, pl.Cout_pad, 1, Cout_w, 1, db);
+    if (with_bias == 2)                             // per image: [nsplit][1][B * Cout_pad][1] -> db [B][Cout_pad]
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((B * pl.Cout_pad + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)p.bias_ws,
+                           pl.nsplit, 1, B * pl.Cout_pad, 1, B * pl.Cout_pad, 1, db);
     return (int)hipGetLastError();
 }

@@ -71,10 +71,11 @@ def _workspace(nbytes, dev):
     return buf
 
 
-def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db=None):
+def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db=None, db_images=None):
     """dw [Cout_w, Cin_w, k, k] (fp32, contiguous view of the gradient buffer) = weight gradient of the convolution that
     maps a = cat(a0, a1) to the tensor whose gradient is dy.  db [Cout_w] (optional): the bias gradient, the per-channel sum of dy,
-    from the same launch.
+    from the same launch.  db_images [B, Cout_pad] (instead of db): the same sums per image (FiLM's gradient), Cout_pad = Cout rounded
+    up to 64 (bias_image_cols), padding columns zero.
 
     deferred: a DeferredReductions collector - the split-K partial tiles stay in a workspace of this layer's own and ONE launch sums
     all layers at the end (reduce_deferred)."""
@@ -88,17 +89,27 @@ def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db
     if nb < 0:
         _check(int(nb), "conv_wgrad_workspace_bytes")
     assert dw.is_contiguous() and dw.dtype == torch.float32
+    mode = 0
     if db is not None:
-        assert db.is_contiguous() and db.dtype == torch.float32 and db.numel() == cout_w
+        assert db_images is None and db.is_contiguous() and db.dtype == torch.float32 and db.numel() == cout_w
+        mode = 1
+    if db_images is not None:
+        assert db_images.is_contiguous() and db_images.dtype == torch.float32 and tuple(db_images.shape) == (B, bias_image_cols(Ct))
+        db, mode = db_images, 2
     if deferred is None:
         ws = _workspace(nb, a0.device)
         dwp, dbp = _lib.ptr(dw), _lib.ptr(db)
     else:
-        ws = deferred.workspace(dw, nb, geo, db)
+        ws = deferred.workspace(dw, nb, geo, db, mode)
         dwp, dbp = None, None
     _check(L.hsidm_conv_wgrad(_lib.prec_id(precision), _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(dy), B, Hin, Win, Ho, Wo, Ct, k,
-                              stride, int(bool(ups)), cout_w, cin_w, dwp, int(db is not None), dbp, _lib.ptr(ws), int(nb),
+                              stride, int(bool(ups)), cout_w, cin_w, dwp, mode, dbp, _lib.ptr(ws), int(nb),
                               _lib.stream_ptr()), "conv_wgrad")
+
+
+def bias_image_cols(cout):
+    """Columns of conv_wgrad's per-image bias sums: the gradient tensor's channel count rounded up to the kernel's 64-cout tile."""
+    return (cout + 63) // 64 * 64
 
 
 class DeferredReductions:
@@ -108,10 +119,10 @@ class DeferredReductions:
         self.dev = device
         self.ws, self.items, self.table, self.blocks = {}, [], None, 0
 
-    def workspace(self, dw, nbytes, geo, db=None):
+    def workspace(self, dw, nbytes, geo, db=None, mode=0):
         key = dw.data_ptr()
         hit = self.ws.get(key)
-        dbp = None if db is None else db.data_ptr()
+        dbp = None if db is None else (db.data_ptr(), mode)
         if hit is None or hit[0].numel() < nbytes or hit[1] != geo or hit[4] != dbp:
             plan = (C.c_int32 * 5)()
             _check(_lib.lib().hsidm_conv_wgrad_plan(*geo, plan), "conv_wgrad_plan")
@@ -134,13 +145,15 @@ class DeferredReductions:
                 it.Cout_w, it.Cin_w, it.block0 = dw.shape[0], dw.shape[1], blk
                 blk += (dw.shape[0] * dw.shape[1] + ppb - 1) // ppb
                 i += 1
-                if dbp is not None:                     # the bias partials: a [nsplit][1][Cout_pad][1] stack behind the weight partials
+                if dbp is not None:                     # the bias partials: a [nsplit][1][rows][1] stack behind the weight partials
                     nsplit, NT, cout_pad, cin_pad, _ = plan
+                    rows_pad = cout_pad * (geo[2] if dbp[1] == 2 else 1)      # per image: [nsplit][B][Cout_pad]
+                    rows = rows_pad if dbp[1] == 2 else dw.shape[0]
                     it = arr[i]
-                    it.ws, it.dw = buf.data_ptr() + 4 * nsplit * NT * cout_pad * cin_pad, dbp
-                    it.nsplit, it.NT, it.Cout_pad, it.Cin_pad = nsplit, 1, cout_pad, 1
-                    it.Cout_w, it.Cin_w, it.block0 = dw.shape[0], 1, blk
-                    blk += (dw.shape[0] + ppb - 1) // ppb
+                    it.ws, it.dw = buf.data_ptr() + 4 * nsplit * NT * cout_pad * cin_pad, dbp[0]
+                    it.nsplit, it.NT, it.Cout_pad, it.Cin_pad = nsplit, 1, rows_pad, 1
+                    it.Cout_w, it.Cin_w, it.block0 = rows, 1, blk
+                    blk += (rows + ppb - 1) // ppb
                     i += 1
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.table = host.to(self.dev)

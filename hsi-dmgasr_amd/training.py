@@ -45,6 +45,7 @@ class Trainer:
         self.step_count = 0            # optimiser steps taken (Adam's bias correction)
         self._iter = 0                 # training forward passes started (dropout mask key)
         self.reducer, self._reduced, self._low_cache = None, False, {}
+        self._film_bufs, self._b1_idx = {}, None
         self._shape_seen, self._tracking = None, False
         self._defer_obj, self._defer = None, None
         self._g, self._g_active, self._g_calls = None, False, 0      # captured step (optimize_parameters): state, capturing/replaying, calls
@@ -232,12 +233,13 @@ class Trainer:
         y = ops.conv2d(a, self.pk(blk.block[3]), film=film, res=res, stats=not out_nchw)
         return y, (x0, x1, ab, a, lid, p_drop)
 
-    def _block_bwd(self, blk, ctx, dy, add=None, bias=True):
+    def _block_bwd(self, blk, ctx, dy, add=None, bias=True, db_images=None):
         """dy: gradient at the block's conv output.  bias: the conv's bias gradient (the channel sums of dy) comes out of the weight
-        gradient launch; False when the caller needs the per-image sums too and runs channel_sums.  -> (dx0, dx1)"""
+        gradient launch; False when the caller takes the per-image sums (db_images, or channel_sums).  -> (dx0, dx1)"""
         x0, x1, ab, a, lid, p_drop = ctx
         gn, conv, p = blk.block[0], blk.block[3], self.precision
-        T.conv_wgrad(a, None, dy, self.G(conv.weight), p, deferred=self._defer, db=self.G(conv.bias) if bias else None)
+        T.conv_wgrad(a, None, dy, self.G(conv.weight), p, deferred=self._defer, db=self.G(conv.bias) if bias else None,
+                     db_images=db_images)
         da = ops.conv2d(dy, self.dpk(conv))
         return T.gn_act_bwd(da, x0, x1, ab, gn.weight, gn.num_groups, True, p, self.G(gn.weight), self.G(gn.bias), p_drop,
                             self._drop_key(), lid, add=add)
@@ -258,14 +260,26 @@ class Trainer:
         conv1, conv2 = rb.block1.block[3], rb.block2.block[3]
         proj = isinstance(rb.res_conv, nn.Conv2d)
         dh1, _ = self._block_bwd(rb.block2, c2, d_out)
-        # FiLM needs the per-image sums of dh1 as well: block1's bias gradient stays with channel_sums
-        dfilm = T.channel_sums(dh1, p, out_c=self.G(conv1.bias), want_bc=True)
+        # FiLM's gradient is the per-image channel sum of dh1, block1's bias gradient their total.  With the deferred reductions
+        # (one GPU) both come out of block1's weight-gradient launch: per-image sums into a buffer of this block's own, the total
+        # copied from the FiLM projection's bias gradient - the same number - at the end of the pass; with a gradient reducer the
+        # bias gradient must be final when the layer is, so the sums are taken here by the streaming reduction.
+        film_buf = None
+        if self._defer is not None:
+            key = (id(rb), dh1.shape[0])
+            film_buf = self._film_bufs.get(key)
+            if film_buf is None:
+                film_buf = torch.zeros((dh1.shape[0], T.bias_image_cols(dh1.shape[3])), dtype=torch.float32, device=self.dev)
+                self._film_bufs[key] = film_buf
+            dfilm = film_buf[:, :conv1.bias.shape[0]]
+        else:
+            dfilm = T.channel_sums(dh1, p, out_c=self.G(conv1.bias), want_bc=True)
         if proj:                                                      # (both biases see the same gradient sum)
             T.conv_wgrad(x0, x1, d_out, self.G(rb.res_conv.weight), p, deferred=self._defer, db=self.G(rb.res_conv.bias))
             add = ops.conv2d(d_out, self.dpk(rb.res_conv), res=skip_add)
         else:
             add = d_out if skip_add is None else T.add(d_out, skip_add, p)
-        dx0, dx1 = self._block_bwd(rb.block1, c1, dh1, add=add, bias=False)
+        dx0, dx1 = self._block_bwd(rb.block1, c1, dh1, add=add, bias=False, db_images=film_buf)
         return dx0, dx1, dfilm
 
     def _attn_fwd(self, at, x):
@@ -397,14 +411,28 @@ class Trainer:
         assert not skip_grads
         mlp = net._mlp()
         l1, l2 = net.noise_level_mlp[1], net.noise_level_mlp[3]
+        if self._defer is not None:
+            self._defer.reduce()                            # every weight / bias gradient, and the per-image sums FiLM needs
         T.noise_film_bwd(tp["gamma"], tp["t_emb"], torch.cat(dfilms, dim=1).contiguous(), mlp, self._wf,
                          (self.G(l1.weight), self.G(l1.bias), self.G(l2.weight), self.G(l2.bias), self._dwf, self._dbf))
-        if self._defer is not None:
-            self._defer.reduce()
+        if self._defer is not None:                         # block1's bias gradients = the FiLM projections' bias gradients
+            self.grad.index_copy_(0, self._conv1_bias_index(), self._dbf.clone())
         self._tape = None
         if red is not None:
             red.finish()
             self._reduced = True
+
+    def _conv1_bias_index(self):
+        """Flat offsets of every ResnetBlock's block1 conv bias, in the order of the FiLM bias vector (= the order of the blocks)."""
+        if self._b1_idx is None:
+            idx = []
+            for u in self.net._res_units():
+                b = u.res_block.block1.block[3].bias
+                o = self._off[id(b)]
+                idx.append(torch.arange(o, o + b.numel(), dtype=torch.int64))
+            self._b1_idx = torch.cat(idx).to(self.dev)
+            assert self._b1_idx.numel() == self._dbf.numel()
+        return self._b1_idx
 
     def _low(self, module):
         """Lowest flat offset of a module's parameters: after its backward everything from there up is final."""

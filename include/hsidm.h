@@ -298,8 +298,10 @@ int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, const void* src
  *   dy NHWC [B][Hout][Wout][Cout]; ksize 3 (pad 1) or 1; stride 1 | 2; ups: a is read through the nearest x2 upsample
  *   (unet.py:64-65).  Cout_w <= Cout and Cin_w <= C0 + C1 drop the zero-padding channels of the NHWC tensors.
  * Implicit GEMM over the pixel axis on MFMA (csrc/wgrad.hip), split K with a fixed summation order (deterministic).
- * with_bias: also the bias gradient db[co] = sum_{b,y,x} dy[b][y][x][co] (Cout_w values), from one more accumulator tile against an
- *   all-ones operand in the same launch; its partial sums [nsplit][Cout_pad] sit behind the weight partials in the workspace.
+ * with_bias = 1: also the bias gradient db[co] = sum_{b,y,x} dy[b][y][x][co] (Cout_w values), from one more accumulator tile against
+ *   an all-ones operand in the same launch; its partial sums [nsplit][Cout_pad] sit behind the weight partials in the workspace.
+ * with_bias = 2: the same sums per image, db [B][Cout_pad] (padding columns zero) - FeatureWiseAffine's gradient (unet.py:42-50) is
+ *   the per-image sum of the block's conv gradient; partial sums [nsplit][B][Cout_pad].
  * workspace: hsidm_conv_wgrad_workspace_bytes(...) bytes (<= 64 MiB). */
 int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize,
                                          int stride, int ups);
@@ -307,7 +309,8 @@ int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, c
                      int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
                      int with_bias, float* db, void* workspace, int64_t workspace_bytes, void* stream);
 /* Deferred form: dw == NULL leaves the partial tiles in `workspace` ([nsplit][taps][Cout_pad][Cin_pad] fp32, then with_bias's
- * [nsplit][Cout_pad] - as an item: taps 1, Cin_pad 1, Cin_w 1, ws = workspace + nsplit*taps*Cout_pad*Cin_pad floats; the four sizes from
+ * [nsplit][Cout_pad] ([nsplit][B][Cout_pad] per image: Cout_pad' = Cout_w' = B*Cout_pad) - as an item: taps 1, Cin_pad 1, Cin_w 1,
+ * ws = workspace + nsplit*taps*Cout_pad*Cin_pad floats; the sizes from
  * hsidm_conv_wgrad_plan) and ONE hsidm_wgrad_reduce_all launch sums every layer's splits later - a training step on one GPU has 94
  * of these reductions, each 10-20 us of latency on its own.  items: device array sorted by block0, block0 = prefix sum of
  * ceil(Cout_w * Cin_w / ppb) over the items, ppb = plan5[4] (pairs per workgroup: 64 with many splits, 256 with few; a bias item uses

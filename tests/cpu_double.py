@@ -157,9 +157,12 @@ def gn_act_bwd(da, x0, x1, gn_ab, gamma, groups, silu, precision, dgamma, dbeta,
     return gx[..., :C0].contiguous(), (None if x1 is None else gx[..., C0:].contiguous())
 
 
-def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db=None):
+def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db=None, db_images=None):
     if db is not None:
         db.copy_(dy.float().sum(dim=(0, 1, 2))[:db.numel()])
+    if db_images is not None:
+        db_images.zero_()
+        db_images[:, :dy.shape[3]] = dy.float().sum(dim=(1, 2))
     x = nchw(cat(a0, a1))
     if ups:
         x = F.interpolate(x, scale_factor=2, mode="nearest")
