@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
 
 class WgradItem(C.Structure):
     _fields_ = [("ws", _vp), ("dw", _vp), ("nsplit", _i32), ("NT", _i32), ("Cout_pad", _i32), ("Cin_pad", _i32), ("Cout_w", _i32),
-                ("Cin_w", _i32), ("block0", _i32), ("reserved", _i32)]
+                ("Cin_w", _i32), ("block0", _i32), ("layout", _i32)]
 
 
 # name -> argtypes, exactly the prototypes of include/hsidm.h
@@ -79,7 +79,7 @@ SIGNATURES = {
                          _vp, _vp, _vp, _vp],
     "hsidm_conv_wgrad_workspace_bytes": [_i32] * 11,
     "hsidm_conv_wgrad": [_i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
-                         _vp, _vp, _i64, _vp],
+                         _i32, _vp, _vp, _i64, _vp],
     "hsidm_conv_wgrad_plan": [_i32] * 11 + [_vp],
     "hsidm_wgrad_reduce_all": [_vp, _i32, _i32, _vp],
     "hsidm_add": [_i32, _vp, _vp, _vp, _i64, _vp],

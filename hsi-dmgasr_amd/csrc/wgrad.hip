@@ -236,8 +236,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // the PyTorch layout (coalesced writes).
 __host__ __device__ inline int reduce_ppb(int nsplit) { return nsplit <= 8 ? 256 : 64; }
 
+// layout 0: dw [cout][cin][tap] (PyTorch's contiguous weight), element (pair, t) at pair * NT + t; layout 1: dw [cout][tap][cin] (the
+// same tensor in channels-last memory order, the form the training step keeps its 3x3 weights in: the re-pack then gathers
+// contiguous runs), element at (co * NT + t) * Cin_w + ci.
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
-                                                   int Cout_w, int Cin_w, float* __restrict__ dw, int blk, float* sm) {
+                                                   int Cout_w, int Cin_w, float* __restrict__ dw, int blk, float* sm, int layout) {
     const int64_t npairs = (int64_t)Cout_w * Cin_w;
     const size_t plane = (size_t)Cout_pad * Cin_pad;
     const int ppb = reduce_ppb(nsplit);
@@ -270,10 +273,21 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ ws,
         for (int t = 0; t < 9; ++t) sm[threadIdx.x * 9 + t] = acc[t];
         __syncthreads();
         const int64_t base = (int64_t)blk * 256 * NT, total = npairs * NT;
-        for (int e = threadIdx.x; e < 256 * NT; e += 256) {
-            if (base + e < total) {
-                const int pr = e / NT, t = e - pr * NT;
-                dw[base + e] = sm[pr * 9 + t];
+        if (layout == 0) {
+            for (int e = threadIdx.x; e < 256 * NT; e += 256) {
+                if (base + e < total) {
+                    const int pr = e / NT, t = e - pr * NT;
+                    dw[base + e] = sm[pr * 9 + t];
+                }
+            }
+        } else {
+            for (int e = threadIdx.x; e < 256 * NT; e += 256) {      // e = t * 256 + pair: consecutive threads, consecutive ci
+                const int t = e >> 8, pr = e & 255;
+                const int64_t ip = (int64_t)blk * 256 + pr;
+                if (ip < npairs) {
+                    const int co = (int)(ip / Cin_w), ci = (int)(ip % Cin_w);
+                    dw[((int64_t)co * NT + t) * Cin_w + ci] = sm[pr * 9 + t];
+                }
             }
         }
         return;
@@ -295,17 +309,23 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ ws,
     __syncthreads();
     const int64_t base = (int64_t)blk * 64 * NT, total = npairs * NT;
     for (int e = threadIdx.x; e < 64 * NT; e += 256) {
-        if (base + e < total) {
-            const int pr = e / NT, t = e - pr * NT;
-            dw[base + e] = ((sm[pr * 10 + t] + sm[(64 + pr) * 10 + t]) + sm[(128 + pr) * 10 + t]) + sm[(192 + pr) * 10 + t];
+        int pr, t;
+        int64_t idx;
+        if (layout == 0) { pr = e / NT; t = e - pr * NT; idx = base + e; }
+        else {
+            t = e >> 6; pr = e & 63;
+            const int64_t ip = (int64_t)blk * 64 + pr;
+            idx = ip < npairs ? ((ip / Cin_w) * NT + t) * Cin_w + ip % Cin_w : -1;
         }
+        if (layout == 0 ? base + e < total : idx >= 0)
+            dw[idx] = ((sm[pr * 10 + t] + sm[(64 + pr) * 10 + t]) + sm[(128 + pr) * 10 + t]) + sm[(192 + pr) * 10 + t];
     }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int NT, int Cout_pad, int Cin_pad,
-                                                           int Cout_w, int Cin_w, float* __restrict__ dw) {
+                                                           int Cout_w, int Cin_w, float* __restrict__ dw, int layout) {
     __shared__ float sm[4 * 64 * 10];
-    wgrad_reduce_block(ws, nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, dw, blockIdx.x, sm);
+    wgrad_reduce_block(ws, nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, dw, blockIdx.x, sm, layout);
 }
 
 // every layer's reduction in ONE launch (the training step on one GPU defers them to the end of the backward pass: 94 launches
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const hsidm_wgrad
         }
     }
     const hsidm_wgrad_item it = items[lo];
-    wgrad_reduce_block(it.ws, it.nsplit, it.NT, it.Cout_pad, it.Cin_pad, it.Cout_w, it.Cin_w, it.dw, (int)blockIdx.x - it.block0, sm);
+    wgrad_reduce_block(it.ws, it.nsplit, it.NT, it.Cout_pad, it.Cin_pad, it.Cout_w, it.Cin_w, it.dw, (int)blockIdx.x - it.block0, sm, it.layout);
 }
 
 struct WgPlan { int TW, TH, tiles_x, tiles_y, ksteps, nsplit, cin_tiles, cout_tiles, Cin_pad, Cout_pad, NT, mode; size_t ws_bytes, bias_off; };
@@ -417,13 +437,13 @@ extern "C" int hsidm_wgrad_reduce_all(const hsidm_wgrad_item* items_dev, int n_i
 
 extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
                                 int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
-                                int with_bias, float* db, void* workspace, int64_t workspace_bytes, void* stream) {
+                                int dw_layout, int with_bias, float* db, void* workspace, int64_t workspace_bytes, void* stream) {
     WgPlan pl;
     const int rc = wgrad_plan(C0, C1, B, Hin, Win, Hout, Wout, Cout, ksize, stride, ups, pl);
     if (rc != HSIDM_OK) return rc;
     if (!a0 || (C1 > 0 && !a1) || !dy || !workspace || Cout_w <= 0 || Cout_w > Cout || Cin_w <= 0 || Cin_w > C0 + C1) return HSIDM_E_BADARG;
     if ((size_t)workspace_bytes < pl.ws_bytes) return HSIDM_E_BADARG;
-    if (with_bias < 0 || with_bias > 2 || (with_bias && dw && !db)) return HSIDM_E_BADARG;
+    if (with_bias < 0 || with_bias > 2 || (with_bias && dw && !db) || dw_layout < 0 || dw_layout > 1) return HSIDM_E_BADARG;
     WgradParams p;
     p.a0 = a0; p.a1 = C1 > 0 ? a1 : nullptr; p.dy = dy; p.ws = (float*)workspace;
     p.bias_ws = with_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.bias_off) : nullptr;
@@ -442,12 +462,12 @@ extern "C" int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0
     const int64_t n = (int64_t)Cout_w * Cin_w;
     const int ppb = reduce_ppb(pl.nsplit);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)workspace, pl.nsplit, pl.NT,
-                       pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw);
+                       pl.Cout_pad, pl.Cin_pad, Cout_w, Cin_w, dw, dw_layout);
     if (with_bias == 1)                             // the bias partials are a [nsplit][1 tap][Cout_pad][1] stack of the same kind
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout_w + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)p.bias_ws, pl.nsplit,
-                           1, pl.Cout_pad, 1, Cout_w, 1, db);
+                           1, pl.Cout_pad, 1, Cout_w, 1, db, 0);
     if (with_bias == 2)                             // per image: [nsplit][1][B * Cout_pad][1] -> db [B][Cout_pad]
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((B * pl.Cout_pad + ppb - 1) / ppb)), dim3(256), 0, s, (const float*)p.bias_ws,
-                           pl.nsplit, 1, B * pl.Cout_pad, 1, B * pl.Cout_pad, 1, db);
+                           pl.nsplit, 1, B * pl.Cout_pad, 1, B * pl.Cout_pad, 1, db, 0);
     return (int)hipGetLastError();
 }

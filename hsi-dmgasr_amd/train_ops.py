@@ -88,7 +88,8 @@ def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db
     nb = L.hsidm_conv_wgrad_workspace_bytes(*geo)
     if nb < 0:
         _check(int(nb), "conv_wgrad_workspace_bytes")
-    assert dw.is_contiguous() and dw.dtype == torch.float32
+    assert dw.dtype == torch.float32
+    layout = dw_layout(dw)
     mode = 0
     if db is not None:
         assert db_images is None and db.is_contiguous() and db.dtype == torch.float32 and db.numel() == cout_w
@@ -98,13 +99,24 @@ def conv_wgrad(a0, a1, dy, dw, precision, stride=1, ups=False, deferred=None, db
         db, mode = db_images, 2
     if deferred is None:
         ws = _workspace(nb, a0.device)
-        dwp, dbp = _lib.ptr(dw), _lib.ptr(db)
+        assert dw.is_cuda
+        dwp, dbp = (dw.data_ptr() if layout else _lib.ptr(dw)), _lib.ptr(db)      # (channels-last view: dense, checked by dw_layout)
     else:
         ws = deferred.workspace(dw, nb, geo, db, mode)
         dwp, dbp = None, None
     _check(L.hsidm_conv_wgrad(_lib.prec_id(precision), _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(dy), B, Hin, Win, Ho, Wo, Ct, k,
-                              stride, int(bool(ups)), cout_w, cin_w, dwp, mode, dbp, _lib.ptr(ws), int(nb),
+                              stride, int(bool(ups)), cout_w, cin_w, dwp, layout, mode, dbp, _lib.ptr(ws), int(nb),
                               _lib.stream_ptr()), "conv_wgrad")
+
+
+def dw_layout(dw):
+    """0: the weight gradient view is PyTorch-contiguous [Cout, Cin, k, k]; 1: channels-last memory order [Cout, k, k, Cin] (what
+    training.Trainer keeps its 3x3 weights and their gradients in)."""
+    if dw.is_contiguous():
+        return 0
+    co, ci, kh, kw = dw.shape
+    assert dw.stride() == (ci * kh * kw, 1, kw * ci, ci), "weight gradient must be contiguous or channels-last"
+    return 1
 
 
 def bias_image_cols(cout):
@@ -142,7 +154,7 @@ class DeferredReductions:
                 it = arr[i]
                 it.ws, it.dw = buf.data_ptr(), dw.data_ptr()
                 it.nsplit, it.NT, it.Cout_pad, it.Cin_pad, ppb = plan
-                it.Cout_w, it.Cin_w, it.block0 = dw.shape[0], dw.shape[1], blk
+                it.Cout_w, it.Cin_w, it.block0, it.layout = dw.shape[0], dw.shape[1], blk, dw_layout(dw)
                 blk += (dw.shape[0] * dw.shape[1] + ppb - 1) // ppb
                 i += 1
                 if dbp is not None:                     # the bias partials: a [nsplit][1][rows][1] stack behind the weight partials

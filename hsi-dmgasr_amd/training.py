@@ -89,9 +89,18 @@ class Trainer:
         with torch.no_grad():
             for p in order:
                 o, n = offs[id(p)], p.numel()
+                self._off[id(p)] = o
+                if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+                    # 3x3 weights live in channels-last memory order [cout][ky][kx][cin] (same tensor, other strides): the packed
+                    # layouts take 8 consecutive input channels of one tap per vector, so the re-pack gathers contiguous runs
+                    # instead of elements 36 bytes apart (805 -> ~430 us per step, tools/gather_bench.py)
+                    co, ci, kh, kw = p.shape
+                    self.flat[o:o + n].view(co, kh, kw, ci).copy_(p.detach().float().permute(0, 2, 3, 1))
+                    p.data = self.flat[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+                    self._gview[id(p)] = self.grad[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+                    continue
                 self.flat[o:o + n].copy_(p.detach().reshape(-1).float())
                 p.data = self.flat[o:o + n].view(p.shape)
-                self._off[id(p)] = o
                 self._gview[id(p)] = self.grad[o:o + n].view(p.shape)
         F = sum(l.weight.shape[0] for l in lins)
         dim = lins[0].weight.shape[1]
@@ -142,7 +151,11 @@ class Trainer:
         for conv, out_nchw, fold_dn, need_dg in self._convs():
             w = conv.weight
             base = self._off[id(w)]
-            iw = (torch.arange(w.numel(), dtype=torch.float64, device=self.dev) + (base + 1)).view(w.shape)
+            iw = torch.arange(w.numel(), dtype=torch.float64, device=self.dev) + (base + 1)
+            if w.shape[2] * w.shape[3] > 1:              # memory order of a 3x3 weight: [cout][ky][kx][cin] (_flatten)
+                iw = iw.view(w.shape[0], w.shape[2], w.shape[3], w.shape[1]).permute(0, 3, 1, 2)
+            else:
+                iw = iw.view(w.shape)
             roles = [("fwd", iw, out_nchw, fold_dn)]
             if need_dg:
                 roles.append(("dgrad", iw.transpose(0, 1).flip(2, 3).contiguous(), False, False))

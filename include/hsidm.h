@@ -298,6 +298,8 @@ int hsidm_gn_act_bwd(int prec, const void* da, const void* src0, const void* src
  *   dy NHWC [B][Hout][Wout][Cout]; ksize 3 (pad 1) or 1; stride 1 | 2; ups: a is read through the nearest x2 upsample
  *   (unet.py:64-65).  Cout_w <= Cout and Cin_w <= C0 + C1 drop the zero-padding channels of the NHWC tensors.
  * Implicit GEMM over the pixel axis on MFMA (csrc/wgrad.hip), split K with a fixed summation order (deterministic).
+ * dw_layout: 0 = dw [Cout_w][Cin_w][k][k] (PyTorch's contiguous layout), 1 = [Cout_w][k][k][Cin_w] (the same tensor in channels-last
+ *   memory order: what the training step keeps its weights in, so that the re-pack gathers contiguous runs).
  * with_bias = 1: also the bias gradient db[co] = sum_{b,y,x} dy[b][y][x][co] (Cout_w values), from one more accumulator tile against
  *   an all-ones operand in the same launch; its partial sums [nsplit][Cout_pad] sit behind the weight partials in the workspace.
  * with_bias = 2: the same sums per image, db [B][Cout_pad] (padding columns zero) - FeatureWiseAffine's gradient (unet.py:42-50) is
@@ -307,7 +309,7 @@ int64_t hsidm_conv_wgrad_workspace_bytes(int C0, int C1, int B, int Hin, int Win
                                          int stride, int ups);
 int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, const void* dy, int B, int Hin, int Win,
                      int Hout, int Wout, int Cout, int ksize, int stride, int ups, int Cout_w, int Cin_w, float* dw,
-                     int with_bias, float* db, void* workspace, int64_t workspace_bytes, void* stream);
+                     int dw_layout, int with_bias, float* db, void* workspace, int64_t workspace_bytes, void* stream);
 /* Deferred form: dw == NULL leaves the partial tiles in `workspace` ([nsplit][taps][Cout_pad][Cin_pad] fp32, then with_bias's
  * [nsplit][Cout_pad] ([nsplit][B][Cout_pad] per image: Cout_pad' = Cout_w' = B*Cout_pad) - as an item: taps 1, Cin_pad 1, Cin_w 1,
  * ws = workspace + nsplit*taps*Cout_pad*Cin_pad floats; the sizes from
@@ -318,7 +320,7 @@ int hsidm_conv_wgrad(int prec, const void* a0, const void* a1, int C0, int C1, c
 typedef struct hsidm_wgrad_item {
     const float* ws;
     float*       dw;
-    int32_t nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, block0, reserved;
+    int32_t nsplit, NT, Cout_pad, Cin_pad, Cout_w, Cin_w, block0, layout;    /* layout: dw_layout of hsidm_conv_wgrad */
 } hsidm_wgrad_item;
 int hsidm_conv_wgrad_plan(int C0, int C1, int B, int Hin, int Win, int Hout, int Wout, int Cout, int ksize, int stride, int ups,
                           int32_t* plan5);

@@ -123,6 +123,12 @@ def test_conv_weight_gradient(dev, prec, case):
     T.conv_wgrad(a0, a1, dy, dw2, prec, stride=stride, ups=ups, db=db2)
     dw3 = torch.empty_like(dw)
     T.conv_wgrad(a0, a1, dy, dw3, prec, stride=stride, ups=ups)     # without the bias tile: the weight gradient is the same
+    if k == 3:      # the same gradient written in channels-last memory order [cout][ky][kx][cin] (the training step's weight layout)
+        dwc = torch.full((cout_w, k, k, cin_w), float("nan"), device=dev).permute(0, 3, 1, 2)
+        assert T.dw_layout(dwc) == 1
+        T.conv_wgrad(a0, a1, dy, dwc, prec, stride=stride, ups=ups)
+        torch.cuda.synchronize()
+        assert torch.equal(dwc, dw)
     # per-image sums (FiLM's gradient) from the same accumulator tile, flushed at image boundaries; padding columns are zero
     dw4, dbi = torch.empty_like(dw), torch.full((B, T.bias_image_cols(Ct)), float("nan"), device=dev)
     T.conv_wgrad(a0, a1, dy, dw4, prec, stride=stride, ups=ups, db_images=dbi)
@@ -390,8 +396,9 @@ def test_captured_training_step_replays_correctly(dev):
         c0, c1 = (1e-3 / (1 - 0.9 ** step)), 1 / math.sqrt(1 - 0.999 ** step)
         for name, p in tr.net.named_parameters():
             o = tr._off[id(p)]
-            want = before[name].to(dev).reshape(-1) - c0 * (m1[o:o + p.numel()] / (v1[o:o + p.numel()].sqrt() * c1 + 1e-8))
-            assert float((p.detach().reshape(-1) - want).abs().max()) < 1e-6, name
+            view = lambda buf: torch.as_strided(buf, p.shape, p.stride(), o)        # (3x3 weights: channels-last in the flat buffers)
+            want = before[name].to(dev) - c0 * (view(m1) / (view(v1).sqrt() * c1 + 1e-8))
+            assert float((p.detach() - want).abs().max()) < 1e-6, name
     assert keys[0] != keys[1] and tr.step_count == 4 and tr._iter == 4
     log_err("captured_train_step_losses", "fp32", losses[-1], {"losses": losses})
 
