@@ -46,6 +46,12 @@ GN_CASES = [  # B, H, W, C0, C1, groups, silu, p_drop
     (2, 8, 8, 128, 64, 32, True, 0.0),       # 6 channels per group: vectors of 8 straddle groups
     (2, 4, 4, 64, 0, 32, False, 0.0),        # the attention's GroupNorm (affine only)
     (1, 32, 32, 32, 0, 8, True, 0.35),
+    # the deep levels' shapes at the training batch: whole 8-channel vectors per group
+    (4, 16, 16, 512, 0, 32, True, 0.2),      # 16 channels per group (the 16x16 level at the training batch), dropout
+    (2, 8, 8, 512, 256, 32, True, 0.0),      # 24 per group over a concat: 3 vectors per pixel, 85 pixel rows of threads
+    (3, 16, 16, 256, 0, 32, False, 0.0),     # 8 per group, affine only
+    (4, 8, 16, 512, 512, 32, True, 0.1),     # 32 per group, the seam between two groups
+    (5, 32, 32, 256, 0, 32, True, 0.0),      # 40 960 elements per workgroup, odd batch
 ]
 
 
