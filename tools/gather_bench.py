@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""hsidm_gather_pack (the training step's re-pack) at the shipped UNet's size with a contiguous index map and with a map that takes 8
+elements 36 bytes apart per vector (a [cout][cin][3][3] weight gathered along cin): the reason the trainer keeps its 3x3 weights in
+channels-last memory order.  Run on the GPU box from the repo root:  python tools/gather_bench.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from hsi_dmgasr_amd import train_ops as T

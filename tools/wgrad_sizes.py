@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Split-K plan of every weight-gradient launch of one training step of the shipped UNet (B = 4): partial-sum bytes, splits, tiles.
+Run on the GPU box from the repo root:  python tools/wgrad_sizes.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from hsi_dmgasr_amd.init import init_weights_orthogonal
