@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const ActT* __restrict_
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict__ part0, int nsplit0, int C0,
                                                           const float2* __restrict__ part1, int nsplit1, int C1,
                                                           int HW, int groups, int gpb, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
+                                                          const float* __restrict__ beta, float eps, double inv_n,
                                                           float2* __restrict__ ab) {
     __shared__ float scr[512];
     __shared__ float cs[256], cq[256], gm[256], gr[256];
@@ -106,12 +106,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
     if (t < gpb) {
         double sa = 0.0, sd = 0.0;
         for (int k = 0; k < cpg; ++k) { sa += cs[t * cpg + k]; sd += cq[t * cpg + k]; }
-        const double n = (double)cpg * HW;
-        const double mean = sa / n;
-        double var = sd / n - mean * mean;
+        // mean and E[x^2] - mean^2 in double (the subtraction cancels); the reciprocal square root in fp32 with one Newton step
+        // (~1e-7 relative) instead of a double division and a double square root - software sequences of a few hundred
+        // instructions each on the critical path of a launch that lasts 5 us
+        const double mean = sa * inv_n;
+        double var = sd * inv_n - mean * mean;
         var = var > 0.0 ? var : 0.0;
+        const float vf = (float)var + eps;
+        float r = __builtin_amdgcn_rsqf(vf);
+        r = r * (1.5f - 0.5f * vf * r * r);
         gm[t] = (float)mean;
-        gr[t] = (float)(1.0 / sqrt(var + (double)eps));
+        gr[t] = r;
         // fourth part of the table: (mean, rstd) per (image, group), read by the backward pass (hsidm_gn_act_bwd)
         float2* mr = reinterpret_cast<float2*>(reinterpret_cast<float*>(ab) + (size_t)4 * gridDim.y * C);
         mr[(size_t)b * groups + blockIdx.x * gpb + t] = make_float2(gm[t], gr[t]);
@@ -248,7 +253,7 @@ extern "C" int hsidm_gn_finalize(const float* part0, int nsplit0, int C0, const 
     while (groups % (gpb * 2) == 0 && groups / (gpb * 2) >= 8 && gpb * 2 * cpg <= 256) gpb *= 2;
     if (groups / gpb > 8 && gpb * cpg < 8) { while (groups % (gpb * 2) == 0 && gpb * 2 * cpg <= 8) gpb *= 2; }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups / gpb, B), dim3(256), 0, (hipStream_t)stream, (const float2*)part0, nsplit0,
-                       C0, (const float2*)part1, nsplit1, C1, HW, groups, gpb, gamma, beta, eps, (float2*)gn_ab);
+                       C0, (const float2*)part1, nsplit1, C1, HW, groups, gpb, gamma, beta, eps, 1.0 / ((double)cpg * HW), (float2*)gn_ab);
     return (int)hipGetLastError();
 }
 
