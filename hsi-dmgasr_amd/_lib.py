@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSIDM_LIB: diagnostic override (A/B builds, in-kernel stamp builds); the product library is libhsidm.so next to this file
 LIB_PATH = os.environ.get("HSIDM_LIB") or os.path.join(_HERE, "libhsidm.so")
 
-BF16, F32X3 = 0, 1
+BF16, F32X3, F16 = 0, 1, 2
 XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 
@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("film", _vp), ("film_stride", _i32), ("res", _vp), ("res_scale", _f32), ("out", _vp),
                 ("stats", _vp), ("B", _i32), ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32),
                 ("Cout", _i32), ("ksize", _i32), ("stride", _i32), ("ups", _i32), ("act", _i32),
-                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32), ("workspace", _vp), ("workspace_bytes", _i64)]
+                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32), ("workspace", _vp), ("workspace_bytes", _i64), ("w_v2_lo", _vp)]
 
 
 class WgradItem(C.Structure):
@@ -162,8 +162,10 @@ def prec_id(precision):
         return BF16
     if precision in ("fp32", "f32x3"):
         return F32X3
-    raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (precision,))
+    if precision in ("fp16", "fp16x1", "fp16x2"):
+        return F16
+    raise ValueError("precision must be 'bf16', 'fp16' or 'fp32', got %r" % (precision,))
 
 
 def act_dtype(precision):
-    return torch.bfloat16 if prec_id(precision) == BF16 else torch.float32
+    return {BF16: torch.bfloat16, F16: torch.float16, F32X3: torch.float32}[prec_id(precision)]

@@ -14,19 +14,25 @@ HSIDM_DECL(conv_run_f32x3_k3s1)
 HSIDM_DECL(conv_run_f32x3_k3s2)
 HSIDM_DECL(conv_run_f32x3_k1s1)
 HSIDM_DECL(conv_run_f32x3_k3s1nchw)
+HSIDM_DECL(conv_run_f16_k3s1)
+HSIDM_DECL(conv_run_f16_k3s2)
+HSIDM_DECL(conv_run_f16_k1s1)
+HSIDM_DECL(conv_run_f16_k3s1nchw)
 #undef HSIDM_DECL
-int conv_v2_run(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
+int conv_v2_run_bf16(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
+int conv_v2_run_f16(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
+int conv_v2_run_f16w(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 int conv_v2_slots();
-int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s);
+int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, hipStream_t s);
 void conv_v2_set_stamps(unsigned long long* p);
 int conv_sk_parts(int B, int H, int W, int Cout, int nchunks);
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
                 const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
                 int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, int stride, float* workspace,
-                hipStream_t s);
-int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
-                  const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
+                int elem, hipStream_t s);
+int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w, const bf16* w_lo,
+                  int elem, const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
                   int nch, int im_H, int im_W, hipStream_t s);
 }  // namespace hsidm
 
@@ -46,7 +52,10 @@ extern "C" const char* hsidm_error_string(int code) {
     }
 }
 
-extern "C" int hsidm_conv_bk(int prec) { return prec == HSIDM_BF16 ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
+extern "C" int hsidm_conv_bk(int prec) { return (prec == HSIDM_BF16 || prec == HSIDM_F16) ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
+
+// the 16-bit throughput modes share every kernel (templates over the element type, common.h: Elem)
+static inline bool is16(int prec) { return prec == HSIDM_BF16 || prec == HSIDM_F16; }
 
 enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 
@@ -56,7 +65,7 @@ enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 // takes it (the persistent kernels are single-phase), so the caller asks hsidm_conv_workspace_bytes first.
 static int sk_parts(const hsidm_conv_desc* d, int Hout, int Wout) {
     const int xf = d->ph[0].transform;
-    if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->ksize != 3 || d->ups ||
+    if (!is16(d->prec) || !d->w_v2 || d->w_v2_lo || d->out_nchw || d->ksize != 3 || d->ups ||
         (xf != HSIDM_XF_NONE && xf != HSIDM_XF_AFFINE_SILU) || d->bn != 128 || d->Cout % 128 || (Hout & 7) || (Wout & 7) ||
         d->act != HSIDM_ACT_NONE || debug_get(DBG_NO_SPLIT_K)) return 0;
     // stride 2 (Downsample): the parity-plane weights, even input maps, no transform, no projection
@@ -113,7 +122,8 @@ static bool force_v1_1x1() { return debug_get(DBG_1X1_V1) == 1; }
 
 static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
     if (!d) return HSIDM_E_BADARG;
-    if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3) return HSIDM_E_BADARG;
+    if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3 && d->prec != HSIDM_F16) return HSIDM_E_BADARG;
+    if (d->w_v2_lo && (d->prec != HSIDM_F16 || !d->w_v2)) return HSIDM_E_BADARG;
     if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
     if (d->ksize != 3 && d->ksize != 1) return HSIDM_E_BADARG;
     if (d->stride != 1 && d->stride != 2) return HSIDM_E_BADARG;
@@ -135,19 +145,19 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     const int xf = d->ph[0].transform;
     path = PATH_V1;
     if (up4) {
-        if (d->prec != HSIDM_BF16 || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || xf != HSIDM_XF_NONE ||
+        if (!is16(d->prec) || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || xf != HSIDM_XF_NONE ||
             d->bn != 128) return HSIDM_E_UNSUPPORTED;
     }
     // stride 2 with w_v2: the four input-parity planes on the conv_v2 schedule (w_v2 = [plane][chunk][2x2 taps] layout)
-    if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 2) {
+    if (is16(d->prec) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 2) {
         if (d->ksize != 3 || xf != HSIDM_XF_NONE || (d->bn != 64 && d->bn != 128) || (d->Hin & 1) || (d->Win & 1)) return HSIDM_E_UNSUPPORTED;
         path = PATH_V2;
     }
     // fp32 NCHW output (the UNet's final Block, 64 -> 3): one padded 32-cout slice on the 256-pixel kernel (conv_v3.hip, WN = 1)
-    if (d->prec == HSIDM_BF16 && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
+    if (is16(d->prec) && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
         xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 32 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
         !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
-    if (d->prec == HSIDM_BF16 && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
+    if (is16(d->prec) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
         // 8x8 maps: two-image tiles halve the work items; when those would leave half of the co-resident workgroup slots
         // empty, one-image 64-pixel tiles keep two workgroups on every CU at the same staging cost per pixel
@@ -182,7 +192,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
 // Only when that still occupies half of the CUs: the items are half as many and the slots are one per CU.  HSIDM_V2_BN256=0 disables it.
 static int v2_slice(const hsidm_conv_desc* d, int Hout, int Wout, int tile_kind, int path) {
     const int on = debug_get(DBG_V2_BN256);
-    if (!on || path != PATH_V2 || tile_kind == 2 || d->bn != 128 || d->stride != 1 || d->ups ||
+    if (!on || path != PATH_V2 || tile_kind == 2 || d->bn != 128 || d->stride != 1 || d->ups || d->w_v2_lo ||
         d->ph[0].transform != HSIDM_XF_AFFINE_SILU || d->Cout % 256) return d->bn;
     const int TW = tile_kind == 0 ? 16 : 8;
     const long long tiles = (long long)((d->B + (tile_kind == 1)) / (tile_kind == 1 ? 2 : 1)) * ((Wout + TW - 1) / TW) * ((Hout + 7) / 8);
@@ -250,6 +260,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     const bool use_v2 = path == PATH_V2 || path == PATH_V3;
     if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
     if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
+    const int elem = d->prec == HSIDM_F16 ? 1 : 0;
     const int bk = hsidm_conv_bk(d->prec);
     ConvParams p;
     p.nphase = d->nphase;
@@ -278,7 +289,8 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     if (path == PATH_G1) {
         const hsidm_conv_phase& s0 = d->ph[0];
         return conv1x1_g_run(d->bn, s0.transform, reinterpret_cast<const bf16*>(s0.src0), reinterpret_cast<const bf16*>(s0.C1 > 0 ? s0.src1 : nullptr),
-                             s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), d->bias, reinterpret_cast<const bf16*>(d->res),
+                             s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), reinterpret_cast<const bf16*>(d->w_v2_lo), elem,
+                             d->bias, reinterpret_cast<const bf16*>(d->res),
                              d->res_scale, reinterpret_cast<bf16*>(d->out), reinterpret_cast<float2*>(d->stats), d->B * Hout * Wout,
                              Hout * Wout, d->Cout, d->ksize == 3 ? 2 : (s0.C0 + s0.C1 + 127) / 128 * 2, d->ksize == 3 ? Hout : 0,
                              d->ksize == 3 ? Wout : 0, s);
@@ -291,7 +303,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
                            reinterpret_cast<const bf16*>(d->res), d->res_scale, reinterpret_cast<bf16*>(d->out),
                            reinterpret_cast<float2*>(d->stats), d->B, Hout, Wout, d->Cout, cout_pad, p.ph[0].nchunks,
                            reinterpret_cast<const bf16*>(p.ph[1].src0), reinterpret_cast<const bf16*>(p.ph[1].src1), p.ph[1].C0, p.ph[1].C1,
-                           d->stride, reinterpret_cast<float*>(d->workspace), s);
+                           d->stride, reinterpret_cast<float*>(d->workspace), elem, s);
     }
     if (use_v2) {
         ConvV2Params v;
@@ -300,6 +312,12 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.gn_ab = reinterpret_cast<const f32x4*>(p.ph[0].gn_ab);
         v.C0 = p.ph[0].C0; v.C1 = p.ph[0].C1; v.nchunks = p.ph[0].nchunks;
         v.w = reinterpret_cast<const bf16*>(d->w_v2);
+        v.w_lo = reinterpret_cast<const bf16*>(d->w_v2_lo);
+        const int np = d->w_v2_lo ? 2 : 1;
+        auto v2_run = [&](int tk, int bn_, int xf_) {
+            if (!elem) return conv_v2_run_bf16(tk, bn_, xf_, v, s);
+            return np == 2 ? conv_v2_run_f16w(tk, bn_, xf_, v, s) : conv_v2_run_f16(tk, bn_, xf_, v, s);
+        };
         v.bias = d->bias; v.film = d->film; v.film_stride = d->film_stride;
         v.res = reinterpret_cast<const bf16*>(d->res); v.res_scale = d->res_scale;
         v.out = reinterpret_cast<bf16*>(d->out); v.stats = reinterpret_cast<float2*>(d->stats);
@@ -307,13 +325,13 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
         if (path == PATH_V3) {
             v.steps_per_item = steps;
-            return conv_v3_run(v, d->out_nchw, s);
+            return conv_v3_run(v, d->out_nchw, elem, np, s);
         }
         const bool dn4 = d->stride == 2;
         if (dn4) v.nchunks = 4 * p.ph[0].nchunks;
         v.steps_per_item = dn4 ? v.nchunks * 4 : (up4 ? p.ph[0].nchunks * 4 : steps);
-        if (!dn4 && !up4 && v2_slice(d, Hout, Wout, tile_kind, path) == 256) return conv_v2_run(tile_kind, 256, d->ph[0].transform, v, s);
-        return conv_v2_run(tile_kind, d->bn, dn4 ? -2 : (up4 ? -1 : d->ph[0].transform), v, s);
+        if (!dn4 && !up4 && v2_slice(d, Hout, Wout, tile_kind, path) == 256) return v2_run(tile_kind, 256, d->ph[0].transform);
+        return v2_run(tile_kind, d->bn, dn4 ? -2 : (up4 ? -1 : d->ph[0].transform));
     }
     p.w_hi = reinterpret_cast<const bf16*>(d->w_hi);
     p.w_lo = reinterpret_cast<const bf16*>(d->w_lo);
@@ -325,6 +343,13 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     p.stats = reinterpret_cast<float2*>(d->stats);
     p.tiles_x = tiles_x;
     p.tiles_y = tiles_y;
+    if (d->prec == HSIDM_F16) {                  // the generic kernel's fp16 form always multiplies by hi + lo weights
+        if (!d->w_lo) return HSIDM_E_BADARG;
+        if (d->out_nchw) return conv_run_f16_k3s1nchw(tile_kind, d->bn, p, s);
+        if (d->ksize == 1) return conv_run_f16_k1s1(tile_kind, d->bn, p, s);
+        if (d->stride == 2) return conv_run_f16_k3s2(tile_kind, d->bn, p, s);
+        return conv_run_f16_k3s1(tile_kind, d->bn, p, s);
+    }
     const bool bf = d->prec == HSIDM_BF16;
     if (d->out_nchw) return bf ? conv_run_bf16_k3s1nchw(tile_kind, d->bn, p, s) : conv_run_f32x3_k3s1nchw(tile_kind, d->bn, p, s);
     if (d->ksize == 1) return bf ? conv_run_bf16_k1s1(tile_kind, d->bn, p, s) : conv_run_f32x3_k1s1(tile_kind, d->bn, p, s);

@@ -18,29 +18,32 @@
 
 namespace hsidm {
 
-template <bool SPLIT> struct Frag { bf16x8 hi; bf16x8 lo; };
+// Op: the 16-bit MFMA operand type (bf16 | fp16); SPLIT (fp32 storage): operands as Op hi + lo, three MFMAs per product
+template <typename Op, bool SPLIT> struct Frag { typename Elem<Op>::x8 hi; typename Elem<Op>::x8 lo; };
 
-template <bool SPLIT>
-__device__ __forceinline__ void make_frag(const float (&v)[8], Frag<SPLIT>& f) {
+template <typename Op, bool SPLIT>
+__device__ __forceinline__ void make_frag(const float (&v)[8], Frag<Op, SPLIT>& f) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        f.hi[k] = (bf16)v[k];
-        if (SPLIT) f.lo[k] = (bf16)(v[k] - (float)f.hi[k]);
+        f.hi[k] = (Op)v[k];
+        if (SPLIT) f.lo[k] = (Op)(v[k] - (float)f.hi[k]);
     }
 }
 
-template <bool SPLIT>
-__device__ __forceinline__ void mma(f32x16& acc, const Frag<SPLIT>& a, const Frag<SPLIT>& b) {
+template <typename Op, bool SPLIT>
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<Op, SPLIT>& a, const Frag<Op, SPLIT>& b) {
     if (SPLIT) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+        acc = Elem<Op>::mfma(a.lo, b.hi, acc);
+        acc = Elem<Op>::mfma(a.hi, b.lo, acc);
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+    acc = Elem<Op>::mfma(a.hi, b.hi, acc);
 }
 
-template <typename ActT, bool SPLIT>
+template <typename ActT, bool SPLIT, typename Op = bf16>
 __global__ __launch_bounds__(256) void attention_kernel(const ActT* __restrict__ qkv, ActT* __restrict__ out,
                                                         int N, int C, float scale) {
+    using bf16 = Op;                                 // (the body below names its operand type bf16)
+    using bf16x8 = typename Elem<Op>::x8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int QS = C + 8;                       // bf16 elements per Q row (+16 B pad)
     const int NP = (N + 31) & ~31;              // keys padded to the MFMA tile
@@ -70,8 +73,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const ActT* __restrict__
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = 0.f;
         }
-        Frag<SPLIT> f;
-        make_frag<SPLIT>(v, f);
+        Frag<Op, SPLIT> f;
+        make_frag<Op, SPLIT>(v, f);
         *reinterpret_cast<bf16x8*>(q_hi + r * QS + cvi * 8) = f.hi;
         if (SPLIT) *reinterpret_cast<bf16x8*>(q_lo + r * QS + cvi * 8) = f.lo;
     }
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const ActT* __restrict__
         const bool kok = key < N;
         const ActT* krow = base + (size_t)(kok ? key : 0) * row3 + C + 8 * lh;
         for (int c16 = 0; c16 < C; c16 += 16) {
-            Frag<SPLIT> a, bb;
+            Frag<Op, SPLIT> a, bb;
             a.hi = *reinterpret_cast<const bf16x8*>(q_hi + lr * QS + c16 + 8 * lh);
             if (SPLIT) a.lo = *reinterpret_cast<const bf16x8*>(q_lo + lr * QS + c16 + 8 * lh);
             float v[8];
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const ActT* __restrict__
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = 0.f;
             }
-            make_frag<SPLIT>(v, bb);
-            mma<SPLIT>(acc, a, bb);
+            make_frag<Op, SPLIT>(v, bb);
+            mma<Op, SPLIT>(acc, a, bb);
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -167,11 +170,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const ActT* __restrict__
                     const float* prow = S + lr * SS + kt * 32 + kk * 16 + 8 * lh;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) pv[k] = prow[k];
-                    Frag<SPLIT> a, bb;
-                    make_frag<SPLIT>(pv, a);
+                    Frag<Op, SPLIT> a, bb;
+                    make_frag<Op, SPLIT>(pv, a);
                     bb.hi = *reinterpret_cast<const bf16x8*>(vt_hi + lr * VS + kk * 16 + 8 * lh);
                     if (SPLIT) bb.lo = *reinterpret_cast<const bf16x8*>(vt_lo + lr * VS + kk * 16 + 8 * lh);
-                    mma<SPLIT>(acc, a, bb);
+                    mma<Op, SPLIT>(acc, a, bb);
                 }
             }
         }
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const ActT* __restrict__
     }
 }
 
-template <typename ActT, bool SPLIT>
+template <typename ActT, bool SPLIT, typename Op = bf16>
 static int launch_attention(const void* qkv, void* out, int B, int N, int C, hipStream_t s) {
     const int QS = C + 8, NP = (N + 31) & ~31, SS = NP + 4;
     const size_t q_bytes = (size_t)(SPLIT ? 2 : 1) * 32 * QS * 2;
@@ -194,9 +197,9 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
     const size_t lds = reg0 + (size_t)32 * SS * 4;
     if (lds > 160 * 1024) return HSIDM_E_UNSUPPORTED;
     static PerDeviceOnce once;                  // raise the dynamic-LDS cap once per device (not a stream operation)
-    if (int rc = raise_lds_cap(once, &attention_kernel<ActT, SPLIT>, 160 * 1024)) return rc;
+    if (int rc = raise_lds_cap(once, &attention_kernel<ActT, SPLIT, Op>, 160 * 1024)) return rc;
     dim3 grid((N + 31) / 32, B);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_kernel<ActT, SPLIT>), grid, dim3(256), lds, s, (const ActT*)qkv, (ActT*)out, N, C,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_kernel<ActT, SPLIT, Op>), grid, dim3(256), lds, s, (const ActT*)qkv, (ActT*)out, N, C,
                        1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
@@ -221,8 +224,11 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
 #endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <int NKT, int NW>
-__global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attention_v2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int C, float scale) {
+template <int NKT, int NW, typename E>
+__global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attention_v2_kernel(const E* __restrict__ qkv, E* __restrict__ out, int C, float scale) {
+    using bf16 = E;                                  // (the body below names its element type bf16; E = bf16 | fp16)
+    using bf16x8 = typename Elem<E>::x8;
+    using bf16x4 = typename Elem<E>::x4;
     constexpr int N = 32 * NKT, T = 64 * NW, NV = N * 8 / T;
     // bf16 per key row: 144 B (ds_read_b128 fragments) / 160 B (transposed reads: the four key rows a 16-lane group touches start
     // 40 banks apart - banks 0, 40, 16, 56, eight each: conflict-free like the 192-byte pitch, and two 256-key buffers are exactly
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attentio
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * KRS + kk * 16);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], sc[kt], 0, 0, 0);
+                sc[kt] = Elem<E>::mfma(a, qf[kk], sc[kt]);
             }
         if (more) {
             commit((chunk + 1) & 1, KRS);
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attentio
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 8 * VRS));
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[c2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[kt][st], o[c2], 0, 0, 0);
+                    o[c2] = Elem<E>::mfma(__builtin_bit_cast(bf16x8, both), pf[kt][st], o[c2]);
                 }
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attentio
             for (int jg = 0; jg < 4; ++jg) {
                 bf16x4 w4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w4[e] = (bf16)o[c2][4 * jg + e];
+                for (int e = 0; e < 4; ++e) w4[e] = (bf16)Elem<E>::sat(o[c2][4 * jg + e]);
                 *reinterpret_cast<bf16x4*>(orow + chunk * 64 + c2 * 32 + 8 * jg) = w4;
             }
         if (more) commit((chunk + 1) & 1, VRS);
@@ -357,13 +363,13 @@ __global__ __launch_bounds__(64 * NW, HSIDM_ATT_VRS == 80 ? 2 : 1) void attentio
     }
 }
 
-template <int NKT, int NW>
+template <int NKT, int NW, typename E>
 static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 32 * NKT * HSIDM_ATT_VRS * 2;
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &attention_v2_kernel<NKT, NW>, lds)) return rc;
+    if (int rc = raise_lds_cap(once, &attention_v2_kernel<NKT, NW, E>, lds)) return rc;
     dim3 grid(NKT / NW, B);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW>), grid, dim3(64 * NW), lds, s, (const bf16*)qkv, (bf16*)out, C,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW, E>), grid, dim3(64 * NW), lds, s, (const E*)qkv, (E*)out, C,
                        1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
@@ -374,9 +380,14 @@ extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int 
     if (!qkv || !out || B <= 0 || N <= 0 || C <= 0 || (C & 31)) return HSIDM_E_BADARG;
     if (N > 1024) return HSIDM_E_UNSUPPORTED;
     if (prec == HSIDM_BF16 && (C & 63) == 0 && !hsidm::debug_get(hsidm::DBG_ATTENTION_V1)) {     // (diagnostic A/B switch)
-        if (N == 256) return hsidm::launch_attention_v2<8, 4>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 64) return hsidm::launch_attention_v2<2, 2>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256) return hsidm::launch_attention_v2<8, 4, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 64) return hsidm::launch_attention_v2<2, 2, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
     }
+    if (prec == HSIDM_F16 && (C & 63) == 0 && !hsidm::debug_get(hsidm::DBG_ATTENTION_V1)) {
+        if (N == 256) return hsidm::launch_attention_v2<8, 4, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 64) return hsidm::launch_attention_v2<2, 2, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
+    }
+    if (prec == HSIDM_F16) return hsidm::launch_attention<hsidm::f16, false, hsidm::f16>(qkv, out, B, N, C, (hipStream_t)stream);
     if (prec == HSIDM_BF16) return hsidm::launch_attention<hsidm::bf16, false>(qkv, out, B, N, C, (hipStream_t)stream);
     if (prec == HSIDM_F32X3) return hsidm::launch_attention<float, true>(qkv, out, B, N, C, (hipStream_t)stream);
     return HSIDM_E_BADARG;

@@ -9,6 +9,12 @@ namespace hsidm {
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -19,6 +25,34 @@ constexpr int kWave = 64;
 // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving) on gfx950
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+
+// ---- the 16-bit element type of a throughput mode --------------------------------------------------
+// bf16 (8-bit significand) or fp16 (11-bit significand, |x| <= 65504): same MFMA rate, same storage, same layouts; every
+// 16-bit kernel is a template over it.  lo / hi: the two elements of a packed 32-bit word as fp32 (for fp16 the conversion
+// folds into the consumer: v_fma_mix_f32 reads fp16 halves directly); sat: the clamp applied to values on their way to an
+// fp16 STORE (an overflow would otherwise become inf and poison the rest of the chain); operands staged behind
+// GroupNorm + SiLU are bounded and skip it.
+template <typename E> struct Elem;
+template <> struct Elem<bf16> {
+    using x8 = bf16x8; using x4 = bf16x4; using x2 = bf16x2;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+    static __device__ __forceinline__ float sat(float v) { return v; }
+};
+template <> struct Elem<f16> {
+    using x8 = f16x8; using x4 = f16x4; using x2 = f16x2;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
+    static __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+};
+// two fp32 -> one packed pair (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even), saturated for fp16
+template <typename E>
+__device__ __forceinline__ typename Elem<E>::x2 cvt_pair(float a, float b) {
+    const f32x2v v = {Elem<E>::sat(a), Elem<E>::sat(b)};
+    return __builtin_convertvector(v, typename Elem<E>::x2);
+}
 
 // 8 consecutive activations as fp32, from either storage type
 template <typename T> struct Vec8;
@@ -33,6 +67,19 @@ template <> struct Vec8<bf16> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] = (bf16)v[i];
         *reinterpret_cast<bf16x8*>(p) = r;
+    }
+};
+template <> struct Vec8<f16> {
+    static __device__ __forceinline__ void load(const f16* p, float (&v)[8]) {
+        f16x8 r = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+    }
+    static __device__ __forceinline__ void store(f16* p, const float (&v)[8]) {
+        f16x8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (f16)Elem<f16>::sat(v[i]);
+        *reinterpret_cast<f16x8*>(p) = r;
     }
 };
 template <> struct Vec8<float> {
@@ -54,9 +101,11 @@ template <> struct Vec8<float> {
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 x) { return (float)x; }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float x) { return (f16)Elem<f16>::sat(x); }
 
 // v_exp_f32 + v_rcp_f32 (~1e-6 relative), 5 VALU instead of an IEEE division
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

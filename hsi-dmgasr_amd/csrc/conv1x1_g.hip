@@ -44,6 +44,7 @@ struct C1gParams {
     int C0, C1;
     const f32x4* gn_ab;     // [B][Ctot/2] = (scale, shift) of two channels, or null
     const bf16* w;          // [chunk][Cout_pad/32][kk 4][lane 64][8]
+    const bf16* w_lo;       // NP = 2: low halves of the weights, same layout (conv_v2.h, V2Cfg); else null
     const float* bias;
     const bf16* res;
     float res_scale;
@@ -54,13 +55,16 @@ struct C1gParams {
     int n_slices, m_tiles, total_items;
 };
 
-template <int BN, int XF, int IM = 0>
+template <int BN, int XF, int IM = 0, typename E = bf16, int NP = 1>
 __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
+    using EL = Elem<E>;
+    using x8 = typename EL::x8;
+    using x2 = typename EL::x2;
     constexpr int WN = BN / 32, WM = 4 / WN, MR = 128 / WM / 32;
     constexpr int PSTR = 72, TILE = 128 * PSTR;
     constexpr int SCR_STR = 40;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* xt = reinterpret_cast<bf16*>(smem_raw);               // [2][TILE] (+ 2 KiB: the epilogue patch overruns buffer 1)
+    E* xt = reinterpret_cast<E*>(smem_raw);                     // [2][TILE] (+ 2 KiB: the epilogue patch overruns buffer 1)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,12 +81,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 
     // ---- weight stream -------------------------------------------------------------------------------------------
     const int nsw = p.Cout_pad >> 5;
-    const bf16* wlane = p.w + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    const E* wlane = reinterpret_cast<const E*>(p.w) + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
-    bf16x8 fring[8];
+    x8 fring[8], fring_lo[NP == 2 ? 8 : 1];
     int wnext = 0;
-    auto f_issue = [&](bf16x8& dst, int kk) __attribute__((always_inline)) {
-        if (G1_ABL != 2) dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)wnext * wstep_stride + kk * 64 * 8);
+    auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
+        if (G1_ABL != 2) {
+            fring[slot] = *reinterpret_cast<const x8*>(wlane + (size_t)wnext * wstep_stride + kk * 64 * 8);
+            if (NP == 2) fring_lo[NP == 2 ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + (size_t)wnext * wstep_stride + kk * 64 * 8);
+        }
         if (kk == 3) wnext = (wnext + 1 == p.nch) ? 0 : wnext + 1;
     };
 
@@ -106,10 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         const int m0 = st_m0;
         const int c = st_chunk * 64 + cv * 8;
         const int cc = c < ctot ? c : 0;                        // zero-weight padding: any finite data will do
-        const bf16* src;
+        const E* src;
         int cs;
-        if (cc < p.C0) { src = p.src0 + cc; cs = p.C0; }
-        else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
+        if (cc < p.C0) { src = reinterpret_cast<const E*>(p.src0) + cc; cs = p.C0; }
+        else           { src = reinterpret_cast<const E*>(p.src1) + (cc - p.C0); cs = p.C1; }
         set_m0[S] = m0;
         set_cc[S] = cc;
         if (IM) {
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 const bool ok = tap < 9 && yy >= 0 && yy < p.im_H && xx >= 0 && xx < p.im_W;
                 zero |= ok ? 0u : (1u << i);
                 const int ms = ok ? m + dy * p.im_W + dx : m;
-                hreg[S][i] = *reinterpret_cast<const u32x4*>(p.src0 + (size_t)ms * 8);
+                hreg[S][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.src0) + (size_t)ms * 8);
             }
             set_zero[S] = zero;
         } else {
@@ -174,15 +182,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             float v[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[2 * k] = __uint_as_float(raw[k] << 16);
-                v[2 * k + 1] = __uint_as_float(raw[k] & 0xffff0000u);
+                v[2 * k] = EL::lo(raw[k]);
+                v[2 * k + 1] = EL::hi(raw[k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], h2_lo(abh[i >> 1][k]), h2_hi(abh[i >> 1][k]));
-            bf16x8 o;
+            x8 o;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
-            *reinterpret_cast<bf16x8*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = o;
+            for (int k = 0; k < 8; ++k) o[k] = (E)EL::sat(v[k]);       // (GroupNorm affine without an activation: not bounded)
+            *reinterpret_cast<x8*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = o;
         } else {
             *reinterpret_cast<u32x4*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = raw;
         }
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 
     // prologue: chunks 0 and 1 requested, six weight fragments in flight, chunk 0 committed
 #pragma unroll
-    for (int f = 0; f < 6; ++f) f_issue(fring[f], f % 4);
+    for (int f = 0; f < 6; ++f) f_issue(f, f % 4);
     issue(0);
     issue(1);
     params_fetch(0);
@@ -213,14 +221,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             // chunk after that into set PAR (whose previous content was committed one body ago)
             auto body = [&](auto par_tag) __attribute__((always_inline)) {
                 constexpr int PAR = decltype(par_tag)::value;
-                const bf16* hb = xt + PAR * TILE;
+                const E* hb = xt + PAR * TILE;
                 params_fetch(PAR ^ 1);                          // before the data requests: a later wait for the parameters then
                 issue(PAR);                                     // leaves those (and the weight ring) in flight
-                bf16x8 a[3][MR];
+                x8 a[3][MR];
                 auto a_fetch = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        if (G1_ABL != 4) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + u * 16);
+                        if (G1_ABL != 4) a[u % 3][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + u * 16);
                 };
                 a_fetch(0);
                 a_fetch(1);
@@ -228,16 +236,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = PAR * 4 + kk;                 // position in the two-chunk trip: the weight ring's period
                     if (kk + 2 < 4) a_fetch(kk + 2);
-                    f_issue(fring[(u + 6) % 8], (u + 6) % 4);
+                    f_issue((u + 6) % 8, (u + 6) % 4);
                     if (u == 0 && chunk == 0) {                // first k-slice of the item: C = 0 as the MFMA's inline constant
                         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], fring[0], zero, 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[0][mr], fring[0], zero);
                     } else if (G1_ABL != 3) {
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3][mr], fring[u % 8], acc[mr], 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[kk % 3][mr], fring[u % 8], acc[mr]);
+                    }
+                    if (NP == 2 && G1_ABL != 3) {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[kk % 3][mr], fring_lo[NP == 2 ? u % 8 : 0], acc[mr]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk == 1) { commit(PAR ^ 1, 0, PAR ^ 1); commit(PAR ^ 1, 1, PAR ^ 1); }
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         // ---- epilogue: buffer 1 is free (the last chunk of an item has odd parity), buffer 0 holds the next item's chunk 0
         const int m0 = cur_m0;
         cur_m0 += m0_step;
-        bf16* scr = xt + TILE + wave * (64 * SCR_STR);
+        E* scr = xt + TILE + wave * (64 * SCR_STR);
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
@@ -266,11 +276,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 if (mp >= p.M) break;
                 const size_t obase = (size_t)mp * p.Cout + n0 + wn * 32;
                 const unsigned lane_el = (unsigned)(pl0 * p.Cout + cq * 8);
-                bf16x8 rv[RES ? 4 : 1];
+                x8 rv[RES ? 4 : 1];
                 if (RES) {
 #pragma unroll
                     for (int v4 = 0; v4 < 4; ++v4)
-                        if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + obase + (size_t)16 * v4 * p.Cout + lane_el);
+                        if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + obase + (size_t)16 * v4 * p.Cout + lane_el);
                 }
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 #pragma unroll
                     for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
                         const int row = (j & 3) + 8 * (j >> 2);
-                        const bf16x2 pr = cvt_pair(acc[g + m2][j] + bias, acc[g + m2][j + 1] + bias);
+                        const x2 pr = cvt_pair<E>(acc[g + m2][j] + bias, acc[g + m2][j + 1] + bias);
                         scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
                         scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                     }
@@ -289,19 +299,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
                     if (v4 >= 2 * nm) break;
-                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                    const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
                     float f[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
-                    bf16x8 o = raw;
+                    x8 o = raw;
                     if (RES) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
-                            o[k] = (bf16)f[k];
+                            o[k] = (E)EL::sat(f[k]);
                         }
                     }
-                    if (G1_ABL != 6) *reinterpret_cast<bf16x8*>(p.out + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
+                    if (G1_ABL != 6) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
                 }
@@ -329,11 +339,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 }
 
 
-template <int BN, int XF, int IM = 0>
+template <int BN, int XF, int IM, typename E, int NP>
 static int run_g1(C1gParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 128 * 72 * 2 + 2048;
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM>, lds)) return rc;
+    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP>, lds)) return rc;
     const int g1_slots = 2 * device_cus();
     p.n_slices = p.Cout_pad / BN;
     p.m_tiles = (p.M + 127) / 128;
@@ -343,14 +353,27 @@ static int run_g1(C1gParams& p, hipStream_t s) {
     const int slots = g1_slots;
     int G = (p.total_items < slots ? p.total_items : slots) / lcm * lcm;
     if (G == 0) G = p.total_items;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM>), dim3(G), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM, E, NP>), dim3(G), dim3(256), lds, s, p);
     return (int)hipGetLastError();
+}
+
+template <typename E, int NP>
+static int dispatch_g1(int bn, int xf, int im, C1gParams& p, hipStream_t s) {
+    if (im) {
+        if (bn == 128) return run_g1<128, XF_NONE, 1, E, NP>(p, s);
+        if (bn == 64) return run_g1<64, XF_NONE, 1, E, NP>(p, s);
+        return HSIDM_E_UNSUPPORTED;
+    }
+    if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE, 0, E, NP>(p, s) : run_g1<128, XF_AFFINE, 0, E, NP>(p, s);
+    if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE, 0, E, NP>(p, s) : run_g1<64, XF_AFFINE, 0, E, NP>(p, s);
+    return HSIDM_E_UNSUPPORTED;
 }
 
 // bn: 64 or 128 (Cout % bn == 0); xf: XF_NONE or XF_AFFINE; HW % 64 == 0; nch even.
 // im_W > 0: 3x3 conv of an 8-channel input as a tap-major GEMM (C0 = 8, C1 = 0, xf = XF_NONE, nch = 2).
-int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w,
-                  const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
+// elem: 0 bf16, 1 fp16 (the bf16-typed pointers are then fp16 data); w_lo != null (fp16 only): second pass on the weights' low halves
+int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w, const bf16* w_lo,
+                  int elem, const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
                   int nch, int im_H, int im_W, hipStream_t s) {
     C1gParams p;
     p.im_H = im_H; p.im_W = im_W;
@@ -359,15 +382,10 @@ int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, in
     }
     p.src0 = src0; p.src1 = src1; p.C0 = C0; p.C1 = C1;
     p.gn_ab = reinterpret_cast<const f32x4*>(gn_ab);
-    p.w = w; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
+    p.w = w; p.w_lo = w_lo; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
     p.M = M; p.HW = HW; p.Cout = Cout; p.Cout_pad = Cout; p.nch = nch;
-    if (im_W > 0) {
-        if (bn == 128) return run_g1<128, XF_NONE, 1>(p, s);
-        if (bn == 64) return run_g1<64, XF_NONE, 1>(p, s);
-        return HSIDM_E_UNSUPPORTED;
-    }
-    if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE>(p, s) : run_g1<128, XF_AFFINE>(p, s);
-    if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE>(p, s) : run_g1<64, XF_AFFINE>(p, s);
+    if (elem == 0) return w_lo ? HSIDM_E_UNSUPPORTED : dispatch_g1<bf16, 1>(bn, xf, im_W > 0, p, s);
+    if (elem == 1) return w_lo ? dispatch_g1<f16, 2>(bn, xf, im_W > 0, p, s) : dispatch_g1<f16, 1>(bn, xf, im_W > 0, p, s);
     return HSIDM_E_UNSUPPORTED;
 }
 

@@ -20,6 +20,9 @@
 //   ActT = float, SPLIT = true : fp32 storage; each operand is split into bf16 hi + bf16 lo and
 //                                hi*hi + hi*lo + lo*hi is accumulated in fp32 ("fp32x3",
 //                                ~2^-17 relative per product; used for the fp32 parity gate)
+//   ActT = f16, Op = f16, WLO   : fp16 storage and operands; the weights as fp16 hi + lo (two MFMAs per product): what the
+//                                shapes the persistent kernels refuse run on in the fp16 mode ("fp16"; always with the low
+//                                halves - this kernel is not what a benchmark step runs on)
 #pragma once
 #include "common.h"
 
@@ -56,10 +59,13 @@ struct ConvParams {
     float2* stats;         // optional [B][tiles_per_img*SUBS][Cout] (sum, sumsq) slab, each entry written once, or null
 };
 
-template <typename ActT, bool SPLIT_, int BN_, int BK_, int TH_, int TW_, int NI_, int KS_, int S_, bool OUT_NCHW_>
+template <typename ActT, bool SPLIT_, int BN_, int BK_, int TH_, int TW_, int NI_, int KS_, int S_, bool OUT_NCHW_, typename Op_ = bf16,
+          bool WLO_ = false>
 struct ConvCfg {
     using Act = ActT;
-    static constexpr bool SPLIT = SPLIT_;
+    using Op = Op_;                                      // 16-bit MFMA operand type
+    static constexpr bool SPLIT = SPLIT_;                // activations AND weights as hi + lo (three MFMAs per product)
+    static constexpr bool WLO = WLO_ || SPLIT_;          // weights as hi + lo
     static constexpr bool OUT_NCHW = OUT_NCHW_;
     static constexpr int BN = BN_, BK = BK_, TH = TH_, TW = TW_, NI = NI_, KS = KS_, S = S_;
     static constexpr int BM = TH * TW * NI;
@@ -78,22 +84,27 @@ struct ConvCfg {
     static constexpr int MAXHV = (HVEC + 255) / 256;
     static constexpr int WVEC = BN * VPP;
     static constexpr int MAXWV = (WVEC + 255) / 256;
-    static constexpr int NPART = SPLIT ? 2 : 1;
+    static constexpr int NPART = SPLIT ? 2 : 1, WPART = WLO ? 2 : 1;
     static constexpr int HALO_ELEMS = NI * HPIX * PSTR;
     static constexpr int WT_ELEMS = BN * WSTR;
-    static constexpr size_t LDS_BYTES = (size_t)(NPART * HALO_ELEMS + 2 * NPART * WT_ELEMS) * 2;
+    static constexpr size_t LDS_BYTES = (size_t)(NPART * HALO_ELEMS + 2 * WPART * WT_ELEMS) * 2;
     // statistics slab: entries per (image, spatial tile) = one per wave row that covers that image
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
 
 template <typename ActT> struct RawVec;     // 8 activations as loaded from memory
 template <> struct RawVec<bf16> { u32x4 a; };
+template <> struct RawVec<f16> { u32x4 a; };
 template <> struct RawVec<float> { u32x4 a, b; };
 
 template <typename ActT>
 __device__ __forceinline__ void raw_load(RawVec<ActT>& r, const ActT* p);
 template <>
 __device__ __forceinline__ void raw_load<bf16>(RawVec<bf16>& r, const bf16* p) {
+    r.a = *reinterpret_cast<const u32x4*>(p);
+}
+template <>
+__device__ __forceinline__ void raw_load<f16>(RawVec<f16>& r, const f16* p) {
     r.a = *reinterpret_cast<const u32x4*>(p);
 }
 template <>
@@ -106,6 +117,8 @@ __device__ __forceinline__ void raw_zero(RawVec<ActT>& r);
 template <>
 __device__ __forceinline__ void raw_zero<bf16>(RawVec<bf16>& r) { r.a = u32x4{0, 0, 0, 0}; }
 template <>
+__device__ __forceinline__ void raw_zero<f16>(RawVec<f16>& r) { r.a = u32x4{0, 0, 0, 0}; }
+template <>
 __device__ __forceinline__ void raw_zero<float>(RawVec<float>& r) { r.a = u32x4{0, 0, 0, 0}; r.b = r.a; }
 
 __device__ __forceinline__ void raw_unpack(const RawVec<bf16>& r, float (&v)[8]) {
@@ -113,6 +126,13 @@ __device__ __forceinline__ void raw_unpack(const RawVec<bf16>& r, float (&v)[8])
     for (int i = 0; i < 4; ++i) {
         v[2 * i] = __uint_as_float(r.a[i] << 16);
         v[2 * i + 1] = __uint_as_float(r.a[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void raw_unpack(const RawVec<f16>& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = Elem<f16>::lo(r.a[i]);
+        v[2 * i + 1] = Elem<f16>::hi(r.a[i]);
     }
 }
 __device__ __forceinline__ void raw_unpack(const RawVec<float>& r, float (&v)[8]) {
@@ -126,13 +146,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BN = C::BN, BK = C::BK, TH = C::TH, TW = C::TW, NI = C::NI, KS = C::KS, S = C::S;
     constexpr int MR = C::MR, NR = C::NR, PSTR = C::PSTR, WSTR = C::WSTR, VPP = C::VPP;
     constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS;
-    constexpr bool SPLIT = C::SPLIT;
+    constexpr bool SPLIT = C::SPLIT, WLO = C::WLO;
+    using Op = typename C::Op;
+    using bf16 = Op;                                 // (the body below names its operand type bf16; Op = bf16 | fp16)
+    using bf16x8 = typename Elem<Op>::x8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* halo_hi = reinterpret_cast<bf16*>(smem_raw);
     bf16* halo_lo = halo_hi + (SPLIT ? C::HALO_ELEMS : 0);
     bf16* wt_hi = halo_hi + C::NPART * C::HALO_ELEMS;            // [2][WT_ELEMS]
-    bf16* wt_lo = wt_hi + (SPLIT ? 2 * C::WT_ELEMS : 0);         // [2][WT_ELEMS]
+    bf16* wt_lo = wt_hi + (WLO ? 2 * C::WT_ELEMS : 0);           // [2][WT_ELEMS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     RawVec<ActT> hreg[C::MAXHV];
     unsigned hvalid = 0;
-    u32x4 wreg_hi[C::MAXWV], wreg_lo[SPLIT ? C::MAXWV : 1];
+    u32x4 wreg_hi[C::MAXWV], wreg_lo[WLO ? C::MAXWV : 1];
 
     // ---- staging helpers ---------------------------------------------------------------------------
     auto halo_issue = [&](const ConvPhase& ph, int chunk) {
@@ -278,8 +301,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (C::WVEC % 256 == 0 || v < C::WVEC) {
                 const int n = v / VPP;
                 const size_t off = ((size_t)step * p.Cout_pad + n0 + n) * BK + (v % VPP) * 8;
-                wreg_hi[i] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
-                if (SPLIT) wreg_lo[i] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+                wreg_hi[i] = *reinterpret_cast<const u32x4*>(p.w_hi + off);      // (2-byte elements of either operand type)
+                if (WLO) wreg_lo[i] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
             }
         }
     };
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (C::WVEC % 256 == 0 || v < C::WVEC) {
                 const int o = buf * C::WT_ELEMS + (v / VPP) * WSTR + (v % VPP) * 8;
                 *reinterpret_cast<u32x4*>(wt_hi + o) = wreg_hi[i];
-                if (SPLIT) *reinterpret_cast<u32x4*>(wt_lo + o) = wreg_lo[i];
+                if (WLO) *reinterpret_cast<u32x4*>(wt_lo + o) = wreg_lo[i];
             }
         }
     };
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const bf16* wl = wt_lo + buf * C::WT_ELEMS;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 ah[MR], al[SPLIT ? MR : 1], bh[NR], bl[SPLIT ? NR : 1];
+            bf16x8 ah[MR], al[SPLIT ? MR : 1], bh[NR], bl[WLO ? NR : 1];
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
                 ah[mr] = *reinterpret_cast<const bf16x8*>(halo_hi + abase[mr] + aoff + kk * 16);
@@ -308,17 +331,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 bh[nr] = *reinterpret_cast<const bf16x8*>(wh + bbase[nr] + kk * 16);
-                if (SPLIT) bl[nr] = *reinterpret_cast<const bf16x8*>(wl + bbase[nr] + kk * 16);
+                if (WLO) bl[nr] = *reinterpret_cast<const bf16x8*>(wl + bbase[nr] + kk * 16);
             }
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    if (SPLIT) {   // small terms first
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mr], bh[nr], acc[mr][nr], 0, 0, 0);
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
-                    }
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+                    // small terms first
+                    if (SPLIT) acc[mr][nr] = Elem<Op>::mfma(al[SPLIT ? mr : 0], bh[nr], acc[mr][nr]);
+                    if (WLO) acc[mr][nr] = Elem<Op>::mfma(ah[mr], bl[WLO ? nr : 0], acc[mr][nr]);
+                    acc[mr][nr] = Elem<Op>::mfma(ah[mr], bh[nr], acc[mr][nr]);
                 }
         }
     };

@@ -41,11 +41,13 @@ struct SkGeo {
     static constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;   // S = 1: 800 vectors, 4 per thread; S = 2: 2312, 10 per thread
 };
 
-template <int S>
+template <int S, typename E>
 __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
     using G = SkGeo<S>;
+    using EL = Elem<E>;
+    using x8 = typename EL::x8;
     constexpr int TH = G::TH, TW = G::TW, HC = G::HC, HPIX = G::HPIX, PSTR = G::PSTR, MAXHV = G::MAXHV;
-    __shared__ __attribute__((aligned(16))) bf16 halo[HPIX * PSTR];
+    __shared__ __attribute__((aligned(16))) E halo[HPIX * PSTR];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
 
     // weight fragments of this wave's 32 couts: [step][Cout_pad/32][kk][lane][8]
     const int nsw = p.Cout_pad >> 5;
-    const bf16* wlane = p.w + ((size_t)(slice * 4 + wave) * 4 * 64 + lane) * 8;
+    const E* wlane = reinterpret_cast<const E*>(p.w) + ((size_t)(slice * 4 + wave) * 4 * 64 + lane) * 8;
     const size_t wstep = (size_t)nsw * 4 * 64 * 8;
 
     // A fragment base of the two 32-pixel MFMA tiles (tile rows 4 mt .. 4 mt + 3): lane = (row lr / 8, column lr % 8), k half lh
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
         // behind the staging of the halo tile (a one-tap-ahead ring was latency-bound: 8 MFMAs per tap against ~0.7 us per fetch)
         const bool proj = chunk >= p.nchunks;                    // workgroup-uniform
         const int lc = proj ? chunk - p.nchunks : chunk;         // chunk within its phase
-        const bf16* wc = wlane + (size_t)(proj ? p.nchunks * 9 + lc : lc * 9) * wstep;
-        bf16x8 wr[9][4];
+        const E* wc = wlane + (size_t)(proj ? p.nchunks * 9 + lc : lc * 9) * wstep;
+        x8 wr[9][4];
         if (!proj) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -86,23 +88,23 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
                 // step = (plane * nchunks + chunk) * 4 + window tap
                 const int dy = tap / 3, dx = tap % 3;
                 const int plane = 2 * (dy != 1) + (dx != 1), wt = 2 * (dy == 1 ? 1 : dy / 2) + (dx == 1 ? 1 : dx / 2);
-                const bf16* wt_p = S == 1 ? wc + (size_t)tap * wstep : wlane + ((size_t)(plane * p.nchunks + lc) * 4 + wt) * wstep;
+                const E* wt_p = S == 1 ? wc + (size_t)tap * wstep : wlane + ((size_t)(plane * p.nchunks + lc) * 4 + wt) * wstep;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const bf16x8*>(wt_p + kk * 64 * 8);
+                for (int kk = 0; kk < 4; ++kk) wr[tap][kk] = *reinterpret_cast<const x8*>(wt_p + kk * 64 * 8);
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *reinterpret_cast<const bf16x8*>(wc + kk * 64 * 8);
+            for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *reinterpret_cast<const x8*>(wc + kk * 64 * 8);
         }
         // ---- stage the 10 x 10 halo of this chunk's 64 channels (GroupNorm + SiLU on the way; zero padding AFTER the activation) ----
         const int ctot = proj ? p.PC0 + p.PC1 : p.C0 + p.C1;
         const int c = lc * 64 + cv * 8;
         const bool cok = c < ctot;
         const int cc = cok ? c : 0;
-        const bf16* src;
+        const E* src;
         int cs, cl;
-        if (!proj) { if (cc < p.C0) { src = p.src0; cs = p.C0; cl = cc; } else { src = p.src1; cs = p.C1; cl = cc - p.C0; } }
-        else       { if (cc < p.PC0) { src = p.psrc0; cs = p.PC0; cl = cc; } else { src = p.psrc1; cs = p.PC1; cl = cc - p.PC0; } }
+        if (!proj) { if (cc < p.C0) { src = reinterpret_cast<const E*>(p.src0); cs = p.C0; cl = cc; } else { src = reinterpret_cast<const E*>(p.src1); cs = p.C1; cl = cc - p.C0; } }
+        else       { if (cc < p.PC0) { src = reinterpret_cast<const E*>(p.psrc0); cs = p.PC0; cl = cc; } else { src = reinterpret_cast<const E*>(p.psrc1); cs = p.PC1; cl = cc - p.PC0; } }
         const float2* gn = proj ? nullptr : p.gn_ab;
         float sc[8], sh[8];
         if (gn) {
@@ -132,12 +134,12 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
             if (gn) {
                 float v[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(o4[k] << 16); v[2 * k + 1] = __uint_as_float(o4[k] & 0xffff0000u); }
-                bf16x8 o;
+                for (int k = 0; k < 4; ++k) { v[2 * k] = EL::lo(o4[k]); v[2 * k + 1] = EL::hi(o4[k]); }
+                x8 o;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float u = fmaf(v[k], sc[k], sh[k]);
-                    o[k] = (bf16)(p.silu ? silu_fast(u) : u);
+                    o[k] = (E)EL::sat(p.silu ? silu_fast(u) : u);
                 }
                 o4 = __builtin_bit_cast(u32x4, o);
             }
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + abase[mt] + toff + kk * 16);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[tap][kk], acc[mt], 0, 0, 0);
+                        const x8 a = *reinterpret_cast<const x8*>(halo + abase[mt] + toff + kk * 16);
+                        acc[mt] = EL::mfma(a, wr[tap][kk], acc[mt]);
                     }
                 }
             }
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + abase[mt] + toff + kk * 16);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[0][kk], acc[mt], 0, 0, 0);
+                    const x8 a = *reinterpret_cast<const x8*>(halo + abase[mt] + toff + kk * 16);
+                    acc[mt] = EL::mfma(a, wr[0][kk], acc[mt]);
                 }
             }
         }
@@ -189,10 +191,12 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const ConvSkParams p) {
 
 // out = res_scale * (sum of the parts + bias + FiLM) + res, rounded to bf16; statistics slab [B][HW/64][Cout] of what was stored.
 // grid (HW / 64, B, Cout / 32): a workgroup owns 64 pixels x 32 channels; thread = (channel vector of 8, pixel).
+template <typename E>
 __global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ bias,
-                                                             const float* __restrict__ film, int film_stride, const bf16* __restrict__ res,
-                                                             float res_scale, bf16* __restrict__ out, float2* __restrict__ stats, int B, int HW,
+                                                             const float* __restrict__ film, int film_stride, const E* __restrict__ res,
+                                                             float res_scale, E* __restrict__ out, float2* __restrict__ stats, int B, int HW,
                                                              int Cout) {
+    using x8 = typename Elem<E>::x8;
     __shared__ float red[64][32][2];
     const int grp = blockIdx.x, b = blockIdx.y, cg = blockIdx.z;
     const int t = threadIdx.x, cvi = t & 3, prow = t >> 2;
@@ -232,18 +236,18 @@ __global__ __launch_bounds__(256) void conv_sk_finish_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = res_scale * (v[k] + add[k]);
         if (res) {
-            const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + off);
+            const x8 r = *reinterpret_cast<const x8*>(res + off);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += (float)r[k];
         }
-        bf16x8 o;
+        x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            o[k] = (bf16)v[k];
+            o[k] = (E)Elem<E>::sat(v[k]);
             s1[k] += v[k];
             s2[k] = fmaf(v[k], v[k], s2[k]);
         }
-        *reinterpret_cast<bf16x8*>(out + off) = o;
+        *reinterpret_cast<x8*>(out + off) = o;
     }
     if (stats) {
 #pragma unroll
@@ -276,7 +280,7 @@ int conv_sk_parts(int B, int H, int W, int Cout, int nchunks) {
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
                 const float* film, int film_stride, const bf16* res, float res_scale, bf16* out, float2* stats, int B, int H, int W,
                 int Cout, int Cout_pad, int nchunks, const bf16* psrc0, const bf16* psrc1, int PC0, int PC1, int stride, float* workspace,
-                hipStream_t s) {
+                int elem, hipStream_t s) {
     ConvSkParams p;
     p.src0 = src0; p.src1 = src1; p.gn_ab = gn_ab; p.w = w; p.partial = workspace;
     p.C0 = C0; p.C1 = C1; p.nchunks = nchunks;
@@ -288,10 +292,18 @@ int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2
     const int allchunks = nchunks + p.pchunks;
     p.cpp = sk_cpp(tiles, slices, allchunks);
     const int parts = (allchunks + p.cpp - 1) / p.cpp;
-    if (stride == 2) hipLaunchKernelGGL(conv_sk_kernel<2>, dim3(tiles, slices, parts), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv_sk_kernel<1>, dim3(tiles, slices, parts), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(conv_sk_finish_kernel, dim3(H * W / 64, B, Cout / 32), dim3(256), 0, s, (const float*)workspace, parts, bias, film,
-                       film_stride, res, res_scale, out, stats, B, H * W, Cout);
+    const dim3 g(tiles, slices, parts), gf(H * W / 64, B, Cout / 32);
+    if (elem == 0) {
+        if (stride == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_sk_kernel<2, bf16>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_sk_kernel<1, bf16>), g, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_sk_finish_kernel<bf16>), gf, dim3(256), 0, s, (const float*)workspace, parts, bias, film,
+                           film_stride, res, res_scale, out, stats, B, H * W, Cout);
+    } else {
+        if (stride == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_sk_kernel<2, f16>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_sk_kernel<1, f16>), g, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_sk_finish_kernel<f16>), gf, dim3(256), 0, s, (const float*)workspace, parts, bias, film,
+                           film_stride, reinterpret_cast<const f16*>(res), res_scale, reinterpret_cast<f16*>(out), stats, B, H * W, Cout);
+    }
     return (int)hipGetLastError();
 }
 

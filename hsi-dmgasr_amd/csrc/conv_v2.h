@@ -34,6 +34,7 @@ struct ConvV2Params {
     const f32x4* gn_ab;     // [B][Ctot/2] = (scale, shift) pairs of two channels, or null
     int C0, C1, nchunks;
     const bf16* w;          // packed [step][Cout_pad/32][kk 4][lane 64][8], step = chunk*9 + tap
+    const bf16* w_lo;       // NP = 2 kernels: the low halves of the weights (w + w_lo ~ 22 significant bits), same layout; else null
     const float* bias;
     const float* film;
     int film_stride;
@@ -64,8 +65,17 @@ struct ConvV2Params {
 // columns).  The K loop walks the four (row parity, column parity) planes of the input; a staged halo pixel (iy, ix) of
 // plane (ry, rx) is in[2*iy + ry][2*ix + rx] and every plane contributes the window {iy-1, iy} x {ix-1, ix} with zero
 // weights where the plane has no tap (16/9 of the minimal MFMAs, on convs that are 1 % of the step's FLOPs).
-template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4>
+// E_: element type of activations, weights and MFMA operands (bf16 | fp16: common.h, Elem).
+// NP_ = 2: every MFMA is issued twice, on the high and on the low half of the weight (w_lo): the weights then carry ~22
+// significant bits at the price of twice the matrix instructions - affordable on the layers that are bound by the staging
+// transform, not by the matrix pipe (the 64- and 128-cout layers of the two high-resolution levels), where it removes the one
+// SYSTEMATIC error of a 16-bit mode (the same weight rounding in every step of the chain).  The weight ring
+// is then fragment-granular (6 pairs, five k-slices ahead) instead of three K steps deep: the same registers.
+template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4, typename E_ = bf16, int NP_ = 1>
 struct V2Cfg {
+    using E = E_;
+    static constexpr int NP = NP_;
+    static_assert(NP_ == 1 || NP_ == 2, "weight passes");
     static constexpr int BN = BN_, TH = TH_, TW = TW_, NI = NI_, XF = XF_;
     // NW = 8: 512 threads, one workgroup per CU, 256 couts per item - the eight waves share one staged (transformed) halo tile,
     // so the GroupNorm+SiLU transform is paid once per 256 couts instead of once per 128
@@ -73,6 +83,9 @@ struct V2Cfg {
     static constexpr bool UP4 = SP_ == 1, DN4 = SP_ == 2;
     static constexpr bool FR = SP_ != 0;                        // 4-tap chunks, fragment-granular weight ring
     static constexpr int NT = FR ? 4 : 9;                       // taps per channel chunk
+    static constexpr bool FRG = FR || NP_ == 2;                 // weights through the fragment ring (else the 3-step ring)
+    // ring slots / lookahead in k-slices; the slot count divides the k-slices of a chunk (16 | 36) so that every index is static
+    static constexpr int FS = FR ? (NP_ == 2 ? 4 : 8) : 6, FL = FR ? (NP_ == 2 ? 3 : 6) : 5;
     static constexpr int BM = TH * TW * NI, BK = 64;           // 128 pixels; 64 for the one-image 8x8 tile (maps of 8x8 pixels
                                                                 // at batches too small to fill the GPU with two-image tiles)
     static_assert(BM == 128 || (BM == 64 && BN_ == 128), "tile");
@@ -154,12 +167,6 @@ __device__ __forceinline__ float silu_fast(float y) {
 constexpr float kLn2 = 0.693147181f;
 // two fp32 -> one packed bf16 pair (v_cvt_pk_bf16_f32); storing the halves separately uses ds_write_b16 / ds_write_b16_d16_hi,
 // i.e. one conversion per two epilogue values instead of one each
-typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16x2 cvt_pair(float a, float b) {
-    const f32x2v v = {a, b};
-    return __builtin_convertvector(v, bf16x2);
-}
 __device__ __forceinline__ float silu_log2e(float u) {
     return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
 }
@@ -188,9 +195,15 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     constexpr int MAXHV = C::MAXHV, NT = C::NT, NH = C::NH;
     constexpr bool UP4 = C::UP4, DN4 = C::DN4, FR = C::FR;
     constexpr int NTHR = C::NTHR;
+    constexpr int NP = C::NP, FS = C::FS, FL = C::FL;
+    constexpr bool FRG = C::FRG;
+    using E = typename C::E;
+    using EL = Elem<E>;
+    using x8 = typename EL::x8;
+    using x2 = typename EL::x2;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* halo = reinterpret_cast<bf16*>(smem_raw);          // [2][HALO_ELEMS]
+    E* halo = reinterpret_cast<E*>(smem_raw);                // [2][HALO_ELEMS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -208,9 +221,11 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 
     // ---- weight stream: one contiguous 1 KiB per (step, 32-cout slice, kk) --------------------------------
     const int nsw = p.Cout_pad >> 5;
-    const bf16* wlane = p.w + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    const size_t wlane_off = ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    const E* wlane = reinterpret_cast<const E*>(p.w) + wlane_off;
+    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + wlane_off;
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
-    bf16x8 ring[3][4];
+    x8 ring[FRG ? 1 : 3][4];
     // item -> (pixel tile, output parity).  UP4 with up_m > 0: the four parities of one input tile are consecutive work
     // of ONE XCD (blocks b, b+8, b+16, b+24), so its L2 fetches the tile once.
     // (divisions by run-time values are ~20 scalar instructions each and an item needs some twenty of them: shifts whenever the
@@ -240,19 +255,23 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     int w_base = 0, w_base_nx = 0;                              // UP4: first weight step of the parity of the item the ring fetches for /
                                                                 // of the item after it (set at every item start: no division in f_issue)
     if (UP4) { int par; item_tile(item, par); w_base = par * p.steps_per_item; }
-    auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
-        const bf16* src = wlane + (size_t)wnext * wstep_stride;
+    auto b_issue = [&](x8 (&dst)[4]) __attribute__((always_inline)) {
+        const E* src = wlane + (size_t)wnext * wstep_stride;
         if (!(HSIDM_ABL(8))) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
+            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + kk * 64 * 8);
         }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
     // UP4: 16 fragments per chunk do not keep a 3-step ring in phase (4 taps), so the ring holds single fragments:
-    // 8 slots, fetched six sub-steps (24 MFMAs) ahead
-    bf16x8 fring[FR ? 8 : 1];
-    auto f_issue = [&](bf16x8& dst, int kk) __attribute__((always_inline)) {
-        if (!(HSIDM_ABL(8))) dst = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(w_base + wnext) * wstep_stride + kk * 64 * 8);
+    // 8 slots, fetched six sub-steps (24 MFMAs) ahead.  NP = 2: (high, low) fragment pairs, FS slots, FL sub-steps ahead.
+    x8 fring[FRG ? FS : 1], fring_lo[(FRG && NP == 2) ? FS : 1];
+    auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
+        if (!(HSIDM_ABL(8))) {
+            const size_t off = (size_t)(w_base + wnext) * wstep_stride + kk * 64 * 8;
+            fring[FRG ? slot : 0] = *reinterpret_cast<const x8*>(wlane + off);
+            if (NP == 2) fring_lo[NP == 2 ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + off);
+        }
         if (kk == 3) {
             if (wnext + 1 == p.steps_per_item) {
                 wnext = 0;
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 #pragma unroll
         for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
     };
-    const bf16* st_src = p.src0;
+    const E* st_src = reinterpret_cast<const E*>(p.src0);
     auto halo_begin = [&](int chunk) __attribute__((always_inline)) {
         // channel slice of the chunk being staged (+ its GroupNorm parameters).  Loads are UNCONDITIONAL (clamped
         // addresses): a predicated load would be merged with its zero alternative right away and that use would
@@ -339,8 +358,8 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         }
         st_cok = c < ctot;
         const int cc = st_cok ? c : 0;
-        if (cc < p.C0) { st_src = p.src0; st_cs = p.C0; st_cl = cc; }
-        else           { st_src = p.src1; st_cs = p.C1; st_cl = cc - p.C0; }
+        if (cc < p.C0) { st_src = reinterpret_cast<const E*>(p.src0); st_cs = p.C0; st_cl = cc; }
+        else           { st_src = reinterpret_cast<const E*>(p.src1); st_cs = p.C1; st_cl = cc - p.C0; }
         st_c = cc;
         if (C::XF != XF_NONE && NI == 1) gn_params(st_b0, cc);
     };
@@ -364,8 +383,8 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         }
         {
             const unsigned w = hreg[i % NH][part];
-            cm_v[2 * part] = __uint_as_float(w << 16);
-            cm_v[2 * part + 1] = __uint_as_float(w & 0xffff0000u);
+            cm_v[2 * part] = EL::lo(w);
+            cm_v[2 * part + 1] = EL::hi(w);
             if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
 #pragma unroll
                 for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_log2e(fmaf(cm_v[k], h2_lo(abh[k]), h2_hi(abh[k])));
@@ -373,9 +392,9 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         }
         if (part == 3) {
             const bool live = st_cok && hv_pix[i] >= 0;         // zero padding stays zero (pad AFTER activation)
-            bf16x8 o;
+            x8 o;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (bf16)cm_v[k];
+            for (int k = 0; k < 8; ++k) o[k] = (E)cm_v[k];
             u32x4 ou = __builtin_bit_cast(u32x4, o);            // zero padding / dead channels: select on the packed words
 #pragma unroll
             for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
@@ -412,12 +431,12 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     };
 
     // prologue: first two weight steps, first halo tile (synchronously)
-    if (!FR) {
+    if (!FRG) {
         b_issue(ring[0]);
         b_issue(ring[1]);
     } else {
 #pragma unroll
-        for (int f = 0; f < 6; ++f) f_issue(fring[f], f % 4);
+        for (int f = 0; f < FL; ++f) f_issue(f, f % 4);
     }
     describe(item);
     halo_begin(0);
@@ -473,21 +492,24 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         const int par_off = UP4 ? py * RP + px * PSTR : 0;            // this parity's 2x2 window inside the 3x3 halo
         HSIDM_SETPRIO(1);
         for (int chunk = 0; chunk < nch; ++chunk) {
-            const bf16* hb = halo + cur * C::HALO_ELEMS + par_off;
+            const E* hb = halo + cur * C::HALO_ELEMS + par_off;
             // A fragments: 3-deep register ring over the 4*NT (tap, k-slice) sub-steps of the chunk, fetched two
             // sub-steps ahead (measured: with one sub-step of lookahead every k-slice waited ~300 cycles on LDS)
-            bf16x8 a[3][MR];
+            // (NP = 2: a sub-step carries twice the MFMAs, so ONE sub-step of lookahead covers the same LDS latency and the ring is
+            // two deep - 16 registers that the low-half weight fragments need)
+            constexpr int AD = NP == 2 ? 2 : 3;
+            x8 a[AD][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
                 const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + kq * 16;
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(hb + abase[mr] + off);
+                for (int mr = 0; mr < MR; ++mr) a[u % AD][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + off);
             };
             a_fetch(0);
-            a_fetch(1);
+            if (AD == 3) a_fetch(1);
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) {
-                if (!FR) b_issue(ring[(tap + 2) % 3]);         // weights two K steps ahead
+                if (!FRG) b_issue(ring[(tap + 2) % 3]);        // weights two K steps ahead
                 if (st_valid && tap == 0) {                    // staging of the next chunk, one vector per tap
                     if (st_chunk == 0) describe(st_item);
                     halo_begin(st_chunk);
@@ -505,8 +527,8 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = tap * 4 + kk;
-                    if (u + 2 < 4 * NT) a_fetch(u + 2);
-                    if (FR) f_issue(fring[(u + 6) % 8], (u + 6) % 4);    // weights six fragments ahead
+                    if (u + AD - 1 < 4 * NT) a_fetch(u + AD - 1);
+                    if (FRG) f_issue((u + FL) % FS, (u + FL) % 4);       // weights FL fragments ahead
                     if (!(HSIDM_ABL(16))) {
                         if (!FR) {                             // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, k-slices 2-3)
                             if (tap >= 3 && tap - 3 < MAXHV) halo_commit_part(tap - 3, cur ^ 1, kk);
@@ -518,18 +540,27 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                         // first k-slice of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item
                         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], FR ? fring[0] : ring[0][0], zero, 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[0][mr], FRG ? fring[0] : ring[0][0], zero);
                     } else {
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], FR ? fring[u % 8] : ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], FRG ? fring[FRG ? u % FS : 0] : ring[FRG ? 0 : tap % 3][kk], acc[mr]);
+                    }
+                    if (NP == 2) {                             // second pass on the weights' low halves (MR MFMAs after the tile's first)
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], fring_lo[NP == 2 ? u % FS : 0], acc[mr]);
                     }
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // 1 LDS read (A fragment, two sub-steps ahead)
-                        __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 6 : 2, 0);   // a slice of the staging VALU
+                        __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? (NP == 2 ? 3 : 6) : (NP == 2 ? 1 : 2), 0);   // a slice of the staging VALU
+                    }
+                    if (NP == 2) {
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 3 : 1, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);         // keep the two-sub-step LDS lookahead the source expresses
                 }
@@ -569,7 +600,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             constexpr int LTW = (TW == 16) ? 4 : 3;
             constexpr int SCR_STR = 40;                                       // bf16 per pixel row: 32 couts + 16 B pad
             constexpr int NV = 2 * MR;                                        // 16-B vectors per lane and item
-            bf16* scr = (C::NW == 8 ? reinterpret_cast<bf16*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2 + C::POS_BYTES) : halo + (cur ^ 1) * C::HALO_ELEMS) +
+            E* scr = (C::NW == 8 ? reinterpret_cast<E*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2 + C::POS_BYTES) : halo + (cur ^ 1) * C::HALO_ELEMS) +
                         wave * (64 * SCR_STR);
             // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU).  The lane
             // constants are rebuilt from the hardware lane id at the top of every pass: kept across the passes they were
@@ -584,7 +615,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
                 constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
                 constexpr bool RES = decltype(res_tag)::value != 0;
-                bf16x8 rv[RES ? 4 : 1];                                        // residual vectors of the current pass
+                x8 rv[RES ? 4 : 1];                                            // residual vectors of the current pass
                 float vs1[8], vs2[8];
 #pragma unroll
                 for (int g = 0; g < MR; g += 2) {
@@ -600,7 +631,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                     if (RES) {                                                 // requested first: the latency hides behind the transposition
 #pragma unroll
                         for (int v4 = 0; v4 < 4; ++v4)
-                            if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(g, v4) + lane_el);
+                            if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + vec_base(g, v4) + lane_el);
                     }
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
@@ -618,7 +649,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                                 // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
                                 if (!RES) { s1[NI == 1 ? 0 : img] += v[e]; s2[NI == 1 ? 0 : img] = fmaf(v[e], v[e], s2[NI == 1 ? 0 : img]); }
                             }
-                            const bf16x2 pr = cvt_pair(v[0], v[1]);
+                            const x2 pr = cvt_pair<E>(v[0], v[1]);
                             scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
                             scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                         }
@@ -631,19 +662,19 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 #pragma unroll
                     for (int v4 = 0; v4 < 4; ++v4) {
                         if (v4 >= 2 * nm) break;
-                        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                        const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
                         float f[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
-                        bf16x8 o = raw;
+                        x8 o = raw;
                         if (RES) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {
                                 f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
-                                o[k] = (bf16)f[k];
+                                o[k] = (E)EL::sat(f[k]);
                             }
                         }
-                        if (!HSIDM_ABL(1)) *reinterpret_cast<bf16x8*>(p.out + vec_base(g, v4) + lane_el) = o;
+                        if (!HSIDM_ABL(1)) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(g, v4) + lane_el) = o;
                         if (RES) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
@@ -698,9 +729,9 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                 if (!(nok && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
                 if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;
-                if (p.res) v = p.res_scale * v + (float)p.res[o];
-                const bf16 st = (bf16)v;
-                if (!(HSIDM_ABL(1))) p.out[o] = st;
+                if (p.res) v = p.res_scale * v + (float)reinterpret_cast<const E*>(p.res)[o];
+                const E st = (E)EL::sat(v);
+                if (!(HSIDM_ABL(1))) reinterpret_cast<E*>(p.out)[o] = st;
                 const float sv = (float)st;
                 s1[NI == 1 ? 0 : img] += sv;
                 s2[NI == 1 ? 0 : img] += sv * sv;

@@ -39,12 +39,20 @@ static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 // WN_ = 1, NCHW_: the UNet's final Block (GroupNorm + SiLU + conv 64 -> 3, reference unet.py:231,262): one 32-cout slice of which
 //   3 couts exist, waves = 4 pixel quarters, 2 MFMA tiles per wave, fp32 NCHW output straight from the accumulators (no FiLM,
 //   residual or statistics) - the last launch of a bf16 step that ran on the generic kernel (415 us at batch 240).
-template <int WN_, bool NCHW_>
+// E: element type (bf16 | fp16); NP = 2: a second MFMA pass on the weights' low halves (conv_v2.h, V2Cfg) - these layers run the
+// matrix pipe a third of the time, so the pass is nearly free and the weights of the level whose output IS the network's output
+// carry ~22 bits; the weight ring is then 6 (high, low) fragment pairs fetched five k-slices ahead (the same registers).
+template <int WN_, bool NCHW_, typename E = bf16, int NP = 1>
 __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using namespace v3;
+    using EL = Elem<E>;
+    using x8 = typename EL::x8;
+    using x2 = typename EL::x2;
+    constexpr bool FRG = NP == 2;
+    constexpr int FS = 6, FL = 5;
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* halo = reinterpret_cast<bf16*>(smem_raw);
+    E* halo = reinterpret_cast<E*>(smem_raw);
     int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)HALO_ELEMS * 2);
 
     const int tid = threadIdx.x;
@@ -66,15 +74,23 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 
     // ---- weight stream (conv_v2's order: [step = chunk*9 + tap][cout/32][kk][lane][8]) ----------------------------------
     const int nsw = p.Cout_pad >> 5;
-    const bf16* wlane = p.w + ((size_t)wn * 4 * 64 + lane) * 8;
+    const E* wlane = reinterpret_cast<const E*>(p.w) + ((size_t)wn * 4 * 64 + lane) * 8;
+    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + ((size_t)wn * 4 * 64 + lane) * 8;
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
-    bf16x8 ring[3][4];
+    x8 ring[FRG ? 1 : 3][4];
+    x8 fring[FRG ? FS : 1], fring_lo[FRG ? FS : 1];
     int wnext = 0;
-    auto b_issue = [&](bf16x8 (&dst)[4]) __attribute__((always_inline)) {
-        const bf16* src = wlane + (size_t)wnext * wstep_stride;
+    auto b_issue = [&](x8 (&dst)[4]) __attribute__((always_inline)) {
+        const E* src = wlane + (size_t)wnext * wstep_stride;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 64 * 8);
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + kk * 64 * 8);
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
+    };
+    auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
+        const size_t off = (size_t)wnext * wstep_stride + kk * 64 * 8;
+        fring[FRG ? slot : 0] = *reinterpret_cast<const x8*>(wlane + off);
+        fring_lo[FRG ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + off);
+        if (kk == 3) wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
 
     // ---- halo staging: vector i of this thread = halo pixel (tid/8 + 32 i), channels 8*(tid%8).. of the chunk ------------
@@ -118,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int c = chunk * BK + cv * 8;
         st_cok = c < ctot;
         const int cc = st_cok ? c : 0;
-        const bf16* src;
+        const E* src;
         int cs;
-        if (cc < p.C0) { src = p.src0 + cc; cs = p.C0; }
-        else           { src = p.src1 + (cc - p.C0); cs = p.C1; }
+        if (cc < p.C0) { src = reinterpret_cast<const E*>(p.src0) + cc; cs = p.C0; }
+        else           { src = reinterpret_cast<const E*>(p.src1) + (cc - p.C0); cs = p.C1; }
         {   // log2(e)-scaled fp16x2 part of the GroupNorm table (conv_v2.h: gn_params, silu_log2e)
             const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)3 * p.B * ctot + (size_t)st_b * ctot + cc);
             const u32x4 lo = t[0], hi = t[1];
@@ -147,14 +163,14 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             float v[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[2 * k] = __uint_as_float(hreg[i][k] << 16);
-                v[2 * k + 1] = __uint_as_float(hreg[i][k] & 0xffff0000u);
+                v[2 * k] = EL::lo(hreg[i][k]);
+                v[2 * k + 1] = EL::hi(hreg[i][k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = silu_log2e(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
-            bf16x8 o;
+            x8 o;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
+            for (int k = 0; k < 8; ++k) o[k] = (E)v[k];
             u32x4 ou = __builtin_bit_cast(u32x4, o);
             const bool live = st_cok && hv_pix[i] >= 0;         // zero padding stays zero (pad AFTER activation)
 #pragma unroll
@@ -177,8 +193,13 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     };
 
     // prologue: two weight steps in flight, raw vectors of (first item, chunk 0) requested
-    b_issue(ring[0]);
-    b_issue(ring[1]);
+    if (!FRG) {
+        b_issue(ring[0]);
+        b_issue(ring[1]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < FL; ++f) f_issue(f, f % 4);
+    }
     describe(item);
     issue_all(0);
     auto stage_advance = [&]() __attribute__((always_inline)) {
@@ -213,32 +234,36 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             lds_barrier();
             if (chunk == 0) HSIDM_STAMP(it, 3);
             HSIDM_SETPRIO(1);
-            bf16x8 a[3][MR];
+            constexpr int AD = NP == 2 ? 2 : 3;                 // (conv_v2.h: one sub-step of lookahead when it carries twice the MFMAs)
+            x8 a[AD][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
                 const int off = (tp / 3) * RP + (tp % 3) * PSTR + kq * 16;
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[u % 3][mr] = *reinterpret_cast<const bf16x8*>(halo + abase[mr] + off);
+                for (int mr = 0; mr < MR; ++mr) a[u % AD][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
             };
             a_fetch(0);
-            a_fetch(1);
+            if (AD == 3) a_fetch(1);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                b_issue(ring[(tap + 2) % 3]);
+                if (!FRG) b_issue(ring[(tap + 2) % 3]);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = tap * 4 + kk;
-                    if (u + 2 < 36) a_fetch(u + 2);
+                    if (u + AD - 1 < 36) a_fetch(u + AD - 1);
+                    if (FRG) f_issue((u + FL) % FS, (u + FL) % 4);
                     if (u == 0 && chunk == 0) {
                         // first k-slice of the item: C = 0 as the MFMA's inline constant instead of 64 v_mov per lane and item
                         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mr], ring[0][0], zero, 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[0][mr], FRG ? fring[0] : ring[0][0], zero);
                     } else {
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % 3][mr], ring[tap % 3][kk], acc[mr], 0, 0, 0);
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], FRG ? fring[FRG ? u % FS : 0] : ring[FRG ? 0 : tap % 3][kk], acc[mr]);
+                    }
+                    if (NP == 2) {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], fring_lo[FRG ? u % FS : 0], acc[mr]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             HSIDM_STAMP(it, 13);
             continue;                                                               // no transposition patch: no barrier
         }
-        bf16* scr = reinterpret_cast<bf16*>(smem_raw + PATCH_OFF) + wave * (32 * SCR_STR);
+        E* scr = reinterpret_cast<E*>(smem_raw + PATCH_OFF) + wave * (32 * SCR_STR);
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
@@ -287,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
             constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
             constexpr bool RES = decltype(res_tag)::value != 0;
-            bf16x8 rv[RES ? 2 : 1];
+            x8 rv[RES ? 2 : 1];
             float vs1[8], vs2[8];
             // Without a residual the statistics are taken from the fp32 values before they are rounded for the store: the lane
             // owns one cout there, so 2 VALU per value and one exchange between the lane halves replace the unpacking of the
@@ -305,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 };
                 if (RES) {
 #pragma unroll
-                    for (int v4 = 0; v4 < 2; ++v4) rv[v4] = *reinterpret_cast<const bf16x8*>(p.res + vec_base(v4) + lane_el);
+                    for (int v4 = 0; v4 < 2; ++v4) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + vec_base(v4) + lane_el);
                 }
 #pragma unroll
                     for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
@@ -317,25 +342,25 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                             if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                             if (!RES) { as1 += v[e]; as2 = fmaf(v[e], v[e], as2); }   // statistics in the accumulator layout (see below)
                         }
-                        const bf16x2 pr = cvt_pair(v[0], v[1]);
+                        const x2 pr = cvt_pair<E>(v[0], v[1]);
                         scr[row * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
                         scr[(row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
                     }
 #pragma unroll
                 for (int v4 = 0; v4 < 2; ++v4) {
-                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                    const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
                     float f[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
-                    bf16x8 o = raw;
+                    x8 o = raw;
                     if (RES) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
-                            o[k] = (bf16)f[k];
+                            o[k] = (E)EL::sat(f[k]);
                         }
                     }
-                    *reinterpret_cast<bf16x8*>(p.out + vec_base(v4) + lane_el) = o;
+                    *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(v4) + lane_el) = o;
                     if (RES) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
@@ -373,15 +398,16 @@ extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds
 
 // Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller); nchw = 0: Cout == 64, NHWC bf16 out;
 // nchw = 1: Cout <= 32 (one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
-template <int WN_, bool NCHW_>
+template <int WN_, bool NCHW_, typename E, int NP>
 static int launch_v3(ConvV2Params& p, int G, hipStream_t s) {
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_>, v3::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
+    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_, E, NP>, v3::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_, E, NP>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
-int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s) {
+// elem: 0 bf16, 1 fp16; np = 2 (fp16 only): p.w_lo holds the weights' low halves
+int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, hipStream_t s) {
     const int g3_slots = 2 * device_cus();
     p.tiles_x = p.Wout / v3::TW;
     p.tiles_y = p.Hout / v3::TH;
@@ -398,7 +424,10 @@ int conv_v3_run(ConvV2Params& p, int nchw, hipStream_t s) {
     p.stamps = g_stamps;
     int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;
     if (G == 0) G = p.total_items;
-    return nchw ? launch_v3<1, true>(p, G, s) : launch_v3<2, false>(p, G, s);
+    if (elem == 0 && np == 1) return nchw ? launch_v3<1, true, bf16, 1>(p, G, s) : launch_v3<2, false, bf16, 1>(p, G, s);
+    if (elem == 1 && np == 1) return nchw ? launch_v3<1, true, f16, 1>(p, G, s) : launch_v3<2, false, f16, 1>(p, G, s);
+    if (elem == 1 && np == 2) return nchw ? launch_v3<1, true, f16, 2>(p, G, s) : launch_v3<2, false, f16, 2>(p, G, s);
+    return HSIDM_E_UNSUPPORTED;
 }
 
 }  // namespace hsidm

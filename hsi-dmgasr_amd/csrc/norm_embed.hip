@@ -129,12 +129,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
         ab[(size_t)b * C + c] = make_float2(sc, sh);
         // second half of the table: the same pair as fp16x2, the form the bf16 conv kernels consume (no conversion, and no
         // wait on a parameter load, between requesting a chunk and staging it)
+        // The fp16 shift is formed with the ROUNDED scale: scale' * x + (beta - mean * scale') = scale' * (x - mean) + beta, so the
+        // scale's rounding error multiplies the deviation from the group mean, not the value itself (a map whose mean is ten
+        // standard deviations from zero would otherwise see ten times the error; it matters for the fp16 mode, whose operands
+        // are as precise as these pairs).
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 hh = {(_Float16)sc, (_Float16)sh};
+        const _Float16 sc_h = (_Float16)sc;
+        const h2 hh = {sc_h, (_Float16)(beta[c] - gm[g] * (float)sc_h)};
         reinterpret_cast<unsigned*>(ab + (size_t)gridDim.y * C)[(size_t)b * C + c] = __builtin_bit_cast(unsigned, hh);
         // third part: log2(e) * (scale, shift), for the kernels that follow the affine map with SiLU: u = log2(e) * y feeds
         // v_exp_f32 directly (y * sigmoid(y) = u / (1 + 2^-u) / log2(e)); they undo the factor on their fp32 accumulators
-        const h2 hs = {(_Float16)(sc * 1.44269504f), (_Float16)(sh * 1.44269504f)};
+        const _Float16 sl_h = (_Float16)(sc * 1.44269504f);
+        const h2 hs = {sl_h, (_Float16)(beta[c] * 1.44269504f - gm[g] * (float)sl_h)};
         reinterpret_cast<unsigned*>(ab + (size_t)gridDim.y * C)[(size_t)(gridDim.y + b) * C + c] = __builtin_bit_cast(unsigned, hs);
     }
 }
@@ -233,6 +239,8 @@ extern "C" int hsidm_gn_partial(int prec, const void* src0, const void* src1, in
     hipStream_t s = (hipStream_t)stream;
     if (prec == HSIDM_BF16)
         hipLaunchKernelGGL(gn_partial_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src0, (const bf16*)src1, C0, C1, HW, nsplit, (float2*)part);
+    else if (prec == HSIDM_F16)
+        hipLaunchKernelGGL(gn_partial_kernel<f16>, grid, dim3(256), 0, s, (const f16*)src0, (const f16*)src1, C0, C1, HW, nsplit, (float2*)part);
     else if (prec == HSIDM_F32X3)
         hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)src0, (const float*)src1, C0, C1, HW, nsplit, (float2*)part);
     else

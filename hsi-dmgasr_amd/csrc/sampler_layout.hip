@@ -269,6 +269,8 @@ extern "C" int hsidm_nchw_to_nhwc(int prec, const float* src0, const int64_t* of
     const float* s1 = C1 > 0 ? src1 : nullptr;
     if (prec == HSIDM_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, grid, dim3(256), 0, s, src0, off0, C0, s1, off1, C1, (bf16*)out, HW, Cpad);
+    else if (prec == HSIDM_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, grid, dim3(256), 0, s, src0, off0, C0, s1, off1, C1, (f16*)out, HW, Cpad);
     else if (prec == HSIDM_F32X3)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, s, src0, off0, C0, s1, off1, C1, (float*)out, HW, Cpad);
     else
@@ -282,6 +284,8 @@ extern "C" int hsidm_nhwc_to_nchw(int prec, const void* src, float* out, int B, 
     hipStream_t s = (hipStream_t)stream;
     if (prec == HSIDM_BF16)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, out, HW, C);
+    else if (prec == HSIDM_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, grid, dim3(256), 0, s, (const f16*)src, out, HW, C);
     else if (prec == HSIDM_F32X3)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)src, out, HW, C);
     else
@@ -297,6 +301,9 @@ extern "C" int hsidm_ca_apply(int prec, const void* r, const float* ca, const vo
     if (prec == HSIDM_BF16)
         hipLaunchKernelGGL(ca_apply_kernel<bf16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)r, ca, (const bf16*)skip,
                            (const bf16*)skip2, res_scale, (bf16*)out, HW, C, nvec);
+    else if (prec == HSIDM_F16)
+        hipLaunchKernelGGL(ca_apply_kernel<f16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)r, ca, (const f16*)skip,
+                           (const f16*)skip2, res_scale, (f16*)out, HW, C, nvec);
     else if (prec == HSIDM_F32X3)
         hipLaunchKernelGGL(ca_apply_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)r, ca, (const float*)skip,
                            (const float*)skip2, res_scale, (float*)out, HW, C, nvec);
@@ -311,6 +318,8 @@ extern "C" int hsidm_film_affine(int prec, const void* x, const float* gamma_bet
     hipStream_t s = (hipStream_t)stream;
     if (prec == HSIDM_BF16)
         hipLaunchKernelGGL(film_affine_kernel<bf16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)x, gamma_beta, (bf16*)out, HW, C, nvec);
+    else if (prec == HSIDM_F16)
+        hipLaunchKernelGGL(film_affine_kernel<f16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)x, gamma_beta, (f16*)out, HW, C, nvec);
     else if (prec == HSIDM_F32X3)
         hipLaunchKernelGGL(film_affine_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)x, gamma_beta, (float*)out, HW, C, nvec);
     else

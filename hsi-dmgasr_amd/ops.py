@@ -10,6 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, XF_AFFINE, XF_AFFINE_SILU, XF_NONE  # noqa: F401 (re-exported)
+from .precision import wide_weights
 
 
 # ------------------------------------------------------------------------------------------- packing
@@ -30,7 +31,8 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     PackedConv carries.  Called with the real fp32 weights (PackedConv) and with float64 index-valued tensors
     (training.PackMap: the layouts become gather maps into the flat parameter buffer)."""
     prec = _lib.prec_id(precision)
-    bk = 64 if prec == _lib.BF16 else 32
+    bk = 32 if prec == _lib.F32X3 else 64
+    b16 = prec != _lib.F32X3               # bf16 / fp16: the same layouts
     cout, cin, kh, kw = weight.shape
     assert kh == kw and kh in (1, 3)
     if cin % 8:     # NHWC tensors carry channels in 16-B vectors: pad the K axis with zero weights
@@ -50,9 +52,9 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     meta = dict(ksize=kh, cin=cin, cout=cout, bn=bn, cpad=cpad, proj_cin=proj_cin, prec=prec, tap_major=False)
     # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
     # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
-    if prec == _lib.BF16 and proj_weight is not None and kh == 3 and not out_nchw and bn == 128:
+    if b16 and proj_weight is not None and kh == 3 and not out_nchw and bn == 128:
         lay["w_v2"] = PackedConv._lanes(lay["w"], cpad)         # read by the split-K kernel only (conv_sk.hip: projection chunks)
-    if prec == _lib.BF16 and proj_weight is None and (not out_nchw or (kh == 3 and bn == 32)):
+    if b16 and proj_weight is None and (not out_nchw or (kh == 3 and bn == 32)):
         wv = lay["w"]
         meta["tap_major"] = kh == 3 and cin == 8
         if meta["tap_major"]:                    # stem-like convs: tap-major GEMM (conv1x1_g IM mode), k = 8*tap + c -> 128
@@ -105,12 +107,18 @@ class PackedConv:
         if proj_weight is not None and proj_bias is not None:
             b = proj_bias.detach().float().clone() if b is None else b + proj_bias.detach().float()
         w = lay["w"]
-        self.w_hi = w.to(torch.bfloat16).contiguous()
-        self.w_lo = (w - self.w_hi.float()).to(torch.bfloat16).contiguous() if self.prec == _lib.F32X3 else None
+        et = torch.float16 if self.prec == _lib.F16 else torch.bfloat16            # element type of the packed weights
+        self.w_hi = w.to(et).contiguous()
+        # low halves: fp32 mode (three MFMAs per product) and the generic kernel's fp16 form (always hi + lo weights)
+        self.w_lo = (w - self.w_hi.float()).to(et).contiguous() if self.prec != _lib.BF16 else None
         self.bias = None if b is None else b.to(dev).contiguous()
-        self.w_v2 = None if lay["w_v2"] is None else lay["w_v2"].to(torch.bfloat16).contiguous()
-        self.w_up4 = None if lay["w_up4"] is None else lay["w_up4"].to(torch.bfloat16).contiguous()
-        self.w_dn4 = None if lay["w_dn4"] is None else lay["w_dn4"].to(torch.bfloat16).contiguous()
+        # fp16 mode: does this layer multiply by hi + lo weights on the persistent kernels too (precision.wide_weights)?
+        self.wide = self.prec == _lib.F16 and wide_weights(precision, self.cout)
+        for name in ("w_v2", "w_up4", "w_dn4"):
+            t = lay[name]
+            hi = None if t is None else t.to(et).contiguous()
+            setattr(self, name, hi)
+            setattr(self, name + "_lo", (t - hi.float()).to(et).contiguous() if (hi is not None and self.wide) else None)
 
     def _set_meta(self, meta, precision, out_nchw):
         self.ksize, self.cin, self.cout, self.bn = meta["ksize"], meta["cin"], meta["cout"], meta["bn"]
@@ -123,6 +131,7 @@ class PackedConv:
         self = cls.__new__(cls)
         self._set_meta(meta, precision, out_nchw)
         self.w_hi, self.w_lo, self.w_v2, self.w_up4, self.w_dn4, self.bias = w_hi, w_lo, w_v2, None, w_dn4, bias
+        self.wide, self.w_v2_lo, self.w_up4_lo, self.w_dn4_lo = False, None, None, None
         return self
 
     @staticmethod
@@ -177,15 +186,17 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
         d.nphase = 2
     d.w_hi, d.w_lo, d.bias = _lib.ptr(pw.w_hi), _lib.ptr(pw.w_lo), _lib.ptr(pw.bias)
     d.w_v2 = _lib.ptr(pw.w_v2) if _use_v2 else None
+    w_v2_lo = pw.w_v2_lo
     if pw.tap_major and (ups or stride != 1 or transform != XF_NONE or act != ACT_NONE or film is not None or x1 is not None or
                          pw.cout % pw.bn or pw.bn < 64 or (Ho * Wo) % 64 or Ho * Wo < 128 or (Wo & (Wo - 1))):
         d.w_v2 = None                 # the tap-major layout is only read by the GEMM kernel (include/hsidm.h)
     folded = bool(ups) and _use_v2 and _fold_ups and pw.w_up4 is not None
     if folded:
-        d.w_v2 = _lib.ptr(pw.w_up4)
+        d.w_v2, w_v2_lo = _lib.ptr(pw.w_up4), pw.w_up4_lo
     planes = stride == 2 and _use_v2 and _fold_ups and pw.w_dn4 is not None and H % 2 == 0 and W % 2 == 0
     if stride == 2:
-        d.w_v2 = _lib.ptr(pw.w_dn4) if planes else None
+        d.w_v2, w_v2_lo = (_lib.ptr(pw.w_dn4), pw.w_dn4_lo) if planes else (None, None)
+    d.w_v2_lo = _lib.ptr(w_v2_lo) if d.w_v2 else None
     if film is not None:          # a column slice of the [B, F] FiLM table
         assert film.stride(1) == 1 and film.shape == (B, pw.cout)
         d.film, d.film_stride = film.data_ptr(), film.stride(0)

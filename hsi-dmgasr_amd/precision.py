@@ -3,17 +3,26 @@
   "bf16" : bf16 activations and MFMA operands, fp32 accumulation / statistics / softmax / sampler state
            (the throughput mode BASELINE.json's headline config names);
   "fp32" : fp32 activations; every matrix operand is split into bf16 hi + lo and hi*hi + hi*lo + lo*hi is
-           accumulated in fp32 on the same MFMA pipeline (~1e-5 relative; the fp32 parity gate).
+           accumulated in fp32 on the same MFMA pipeline (~1e-5 relative; the fp32 parity gate);
+  "fp16" : fp16 activations and MFMA operands (11-bit significands instead of bf16's 8: the same kernels at the same rate,
+           stores saturate at +-65504), and the convolutions of the two high-resolution levels (Cout <= 128: bound by their
+           staging transform, not by the matrix pipe) multiply by fp16 hi + lo WEIGHTS in two MFMA passes - the weight rounding
+           is the one error of a 16-bit mode that is the same in every step of a chain, i.e. a bias, not noise
+           (tests/precision_emul.py).  "fp16x1" / "fp16x2": the second pass nowhere / wherever a kernel
+           takes it (A/B forms).
 """
 import os
 
 _default = os.environ.get("HSIDM_PRECISION", "bf16")
 
 
+MODES = ("bf16", "fp32", "fp16", "fp16x1", "fp16x2")
+
+
 def set_default_precision(p):
     global _default
-    if p not in ("bf16", "fp32"):
-        raise ValueError("precision must be 'bf16' or 'fp32'")
+    if p not in MODES:
+        raise ValueError("precision must be one of %s" % (MODES,))
     _default = p
 
 
@@ -23,6 +32,16 @@ def get_default_precision():
 
 def resolve_precision(p):
     p = _default if p is None else p
-    if p not in ("bf16", "fp32"):
-        raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (p,))
+    if p not in MODES:
+        raise ValueError("precision must be one of %s, got %r" % (MODES, p))
     return p
+
+
+def is_16bit(p):
+    """bf16 / fp16 family: the throughput modes (2-byte activations, the persistent kernels)."""
+    return p != "fp32"
+
+
+def wide_weights(p, cout):
+    """Does a convolution with `cout` output channels carry hi + lo weights in mode p (second MFMA pass)?"""
+    return p == "fp16x2" or (p == "fp16" and cout <= 128)

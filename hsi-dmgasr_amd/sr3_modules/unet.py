@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ops
 from .._lib import act_dtype
-from ..precision import resolve_precision
+from ..precision import is_16bit, resolve_precision
 
 
 def exists(x):
@@ -197,7 +197,7 @@ class ResnetBlock(_HipModule):
         else:
             h = self.block1._run(x0, precision, x1=x1, film=film)
         if isinstance(self.res_conv, nn.Conv2d):
-            if precision == "bf16" and ops.use_v2():
+            if is_16bit(precision) and ops.use_v2():
                 # throughput mode: the persistent 3x3 kernel is single-phase; the 1x1 projection is its own launch and enters
                 # block2's epilogue as the residual.  (Measured and dropped, round 2: running it on a second stream beside block1's
                 # convolution - a parallel branch of the captured step - at batches that leave workgroup slots free: the fork / join

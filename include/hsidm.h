@@ -27,6 +27,9 @@ extern "C" {
 /* precision modes */
 #define HSIDM_BF16  0   /* bf16 storage + bf16 MFMA operands, fp32 accumulate / statistics / softmax   */
 #define HSIDM_F32X3 1   /* fp32 storage; operands split bf16 hi+lo, 3 MFMA passes (fp32-grade parity) */
+#define HSIDM_F16   2   /* fp16 storage + fp16 MFMA operands (11-bit significands, |x| <= 65504: stores saturate), fp32
+                           accumulate / statistics / softmax; same kernels, layouts and rate as HSIDM_BF16.  A convolution whose
+                           descriptor carries w_v2_lo / w_lo runs a second MFMA pass on the low halves of its weights */
 
 /* error codes */
 #define HSIDM_OK             0
@@ -88,7 +91,7 @@ typedef struct hsidm_conv_desc {
     hsidm_conv_phase ph[2];
     int32_t nphase;           /* 1, or 2 = phase 1 is a fused 1x1 projection of a second input      */
     const void*  w_hi;        /* packed bf16 [step][Cout_pad][BK], step = (phase, chunk, tap)       */
-    const void*  w_lo;        /* low halves (HSIDM_F32X3 only)                                      */
+    const void*  w_lo;        /* low halves (HSIDM_F32X3: required; HSIDM_F16: optional second weight pass) */
     const void*  w_v2;        /* optional (HSIDM_BF16): the same weights in the register-streaming order
                                  [step][Cout_pad/32][4][64 lanes][8]; enables the persistent kernels
                                  (csrc/conv_v2.h, conv1x1_g.hip).  1x1: K padded to a multiple of 128.
@@ -111,7 +114,7 @@ typedef struct hsidm_conv_desc {
     int32_t ups;              /* HSIDM_UPS_*: nearest x2 upsample folded in (Hout = 2*Hin)          */
     int32_t act;              /* HSIDM_ACT_*                                                        */
     int32_t out_nchw;         /* 1: write NCHW fp32 (network outputs)                               */
-    int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3                                           */
+    int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3 | HSIDM_F16                               */
     int32_t bn;               /* cout slice the weights were packed for: 32, 64 or 128             */
     void*   workspace;        /* optional scratch of hsidm_conv_workspace_bytes(d) bytes: enables the split-K form
                                  (csrc/conv_sk.hip) for launches with few pixel tiles and a long contraction -
@@ -120,6 +123,10 @@ typedef struct hsidm_conv_desc {
                                  phase 1) the split form is the only w_v2 kernel that applies: ask
                                  hsidm_conv_workspace_bytes first, 0 = launch the projection separately         */
     int64_t workspace_bytes;
+    const void*  w_v2_lo;     /* optional (HSIDM_F16 with w_v2): fp16(W - fp16(W)) in the layout of w_v2 - the weights then carry
+                                 ~22 significant bits for twice the matrix instructions (the weight rounding
+                                 is the one systematic error of a 16-bit mode; the pass is nearly free on layers bound by the
+                                 staging transform).  Not taken by the split-K form and the 256-cout items                        */
 } hsidm_conv_desc;
 
 int hsidm_conv2d(const hsidm_conv_desc* d, void* stream);
@@ -131,7 +138,7 @@ int hsidm_conv_stats_nsplit(const hsidm_conv_desc* d);
  * (conv_v2), 3 LDS-staged 1x1 GEMM (conv1x1_g), 4 256-pixel 3x3 (conv_v3), 5 split-K 3x3 (conv_sk, only with d->workspace); bits 4-5 = tile (0: 8x16, 1: 8x8 of two images, 2: 8x8 of one image); bits 8.. = couts per work item (256: the 8-wave form of a 128-packed GroupNorm+SiLU conv).
  * <0 on error. */
 int hsidm_conv_kernel_id(const hsidm_conv_desc* d);
-/* K-chunk (input channels per packed step) of a precision mode: 64 for BF16, 32 for F32X3. */
+/* K-chunk (input channels per packed step) of a precision mode: 64 for BF16 and F16, 32 for F32X3. */
 int hsidm_conv_bk(int prec);
 
 /* ---- GroupNorm statistics (nn.GroupNorm inside Block / SelfAttention, unet.py:84,121) ----------

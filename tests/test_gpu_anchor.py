@@ -1,0 +1,150 @@
+"""Direct anchors: every tuned convolution kernel against a plain fp32 PyTorch reference of the SAME op (F.conv2d after the
+GroupNorm affine map + SiLU, on the host), at benchmark-like shapes, in every precision mode - so that a regression is
+localised to one kernel instead of surfacing three layers up in a chain of kernel-vs-kernel comparisons.
+
+Inputs are taken as the kernel sees them (activations already rounded to the mode's storage type, the GroupNorm table as
+fp32 pairs), so the measured error is the kernel's own: operand rounding after the transform, weight rounding, accumulation
+order, the output store.  Bounds (relative Frobenius error): bf16 4e-3, fp16 6e-4 (one weight pass) / 4.5e-4 (hi + lo weights),
+fp32 mode 1e-4 - about twice what the kernels measure (gpurun_out/parity.jsonl).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_stats, check, log_err
+from hsi_dmgasr_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16": 4e-3, "fp16x1": 6e-4, "fp16x2": 4.5e-4, "fp16": 6e-4, "fp32": 1e-4}
+MODES = ["bf16", "fp16x1", "fp16x2", "fp32"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _reference(x0, x1, ab, silu, w, b, film, res, stride=1, ups=False, ksize=3):
+    """fp32 on the host: out = conv(T(cat(x0, x1))) + bias + film + res, NHWC in / NHWC out."""
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
+    x = x.float().cpu()
+    if ab is not None:
+        a = ab.float().cpu()
+        x = x * a[:, None, None, :, 0] + a[:, None, None, :, 1]
+        if silu:
+            x = x * torch.sigmoid(x)
+    x = x.permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    y = F.conv2d(x, w.float().cpu(), None if b is None else b.float().cpu(), stride=stride, padding=ksize // 2)
+    if film is not None:
+        y = y + film.float().cpu()[:, :, None, None]
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + res.float().cpu()
+    return y.contiguous()
+
+
+# name, B, H, W, C0, C1, Cout, ksize, stride, ups, GN+SiLU (2) / GN (1) / none (0), film, residual, expected kernel label
+CASES = [
+    ("v2_bn128_64x64", 4, 64, 64, 128, 0, 128, 3, 1, False, 2, True, False, "conv_v2 bn128 8x16"),
+    ("v2_bn128_concat_res", 3, 32, 32, 128, 64, 128, 3, 1, False, 2, False, True, "conv_v2 bn128 8x16"),
+    ("v2_bn256_32x32", 20, 32, 32, 256, 0, 256, 3, 1, False, 2, True, False, "conv_v2 bn256 8x16"),
+    ("v2_bn256_res_16x16", 64, 16, 16, 256, 0, 512, 3, 1, False, 2, False, True, "conv_v2 bn256 8x16"),
+    ("v2_8x8x2", 260, 8, 8, 128, 0, 256, 3, 1, False, 2, True, False, "conv_v2 bn256 8x8x2"),
+    ("v3_64_64", 3, 32, 48, 64, 0, 64, 3, 1, False, 2, True, False, "conv_v3 bn64"),
+    ("v3_concat_res", 2, 32, 32, 128, 64, 64, 3, 1, False, 2, False, True, "conv_v3 bn64"),
+    ("up4_128", 3, 16, 16, 128, 0, 128, 3, 1, True, 0, False, False, "up4"),
+    ("dn4_128", 3, 32, 32, 128, 0, 128, 3, 2, False, 0, False, False, "dn4"),
+    ("dn4_64", 2, 64, 64, 64, 0, 64, 3, 2, False, 0, False, False, "dn4"),
+    ("g1_proj_192_64", 2, 64, 64, 128, 64, 64, 1, 1, False, 0, False, False, "conv1x1_g"),
+    ("g1_qkv_gn", 6, 16, 16, 512, 0, 1536, 1, 1, False, 1, False, False, "conv1x1_g"),
+    ("g1_out_res", 6, 16, 16, 512, 0, 512, 1, 1, False, 0, False, True, "conv1x1_g"),
+    ("stem_8_64", 2, 64, 64, 8, 0, 64, 3, 1, False, 0, False, False, "conv1x1_g"),
+]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_kernel_against_fp32_torch(dev, mode, case):
+    from hsi_dmgasr_amd import ops
+    name, B, H, W, C0, C1, Co, ks, stride, ups, xf, with_film, with_res, label = case
+    g = torch.Generator().manual_seed(B * 7 + C0 + Co + ks)
+    cin = C0 + C1
+    w = torch.randn(Co, cin, ks, ks, generator=g) / (ks * ks * cin) ** 0.5
+    b = 0.1 * torch.randn(Co, generator=g)
+    dt = _lib.act_dtype(mode)
+    x0 = torch.randn(B, H, W, C0, generator=g).to(dt).to(dev)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dt).to(dev) if C1 else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, cin, generator=g), 0.2 * torch.randn(B, cin, generator=g)], 2).contiguous().to(dev) if xf else None
+    Ho, Wo = (2 * H, 2 * W) if ups else ((H // 2, W // 2) if stride == 2 else (H, W))
+    film = torch.randn(B, Co, generator=g).to(dev) if with_film else None
+    res = torch.randn(B, Ho, Wo, Co, generator=g).to(dt).to(dev) if with_res else None
+    pk = ops.PackedConv(w.to(dev), b.to(dev), mode, fold_ups=ups, fold_dn=stride == 2)
+    recs = []
+    ops.set_conv_probe(recs)
+    try:
+        y = ops.conv2d(x0, pk, x1=x1, gn_ab=None if ab is None else ops.gn_table(ab), transform=(ops.XF_NONE, ops.XF_AFFINE, ops.XF_AFFINE_SILU)[xf],
+                       film=film, res=res, stride=stride, ups=ups, stats=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_probe(None)
+    if mode != "fp32":                                   # the fp32 mode runs everything on the LDS-tiled kernel
+        got_label = recs[-1]["kernel"]
+        want = label.replace("bn256", "bn128") if mode == "fp16x2" else label      # hi + lo weights: no 256-cout items
+        assert want in got_label, (want, got_label)
+    slab, nsplit = y._hsidm_stats
+    assert_stats(slab, y, name)
+    want_y = _reference(x0, x1, ab, xf == 2, w, b, film, res, stride, ups, ks)
+    check("anchor_" + name, mode, y, want_y, tol=TOL[mode])
+
+
+def test_low_weight_halves_reach_the_matrix_pipe(dev):
+    """The hi + lo weight pass must deliver the low halves: they are fp16 SUBNORMALS (|w| ~ 0.02 -> w - fp16(w) ~ 5e-6 < 6.1e-5), so a
+    matrix pipe that flushed subnormal operands would silently turn the second pass into nothing.  Activations exactly representable
+    in fp16 and no transform: the only error left is the weights' - ~2^-12 with one pass, ~2^-18 with two."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Ci, Co = 2, 32, 32, 64, 64
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    x = (torch.randint(0, 17, (B, H, W, Ci), generator=g).float() / 8).to(torch.float16).to(dev)     # mean 1: a weight bias survives the pixel average
+    errs = {}
+    for mode in ("fp16x1", "fp16x2"):
+        pk = ops.PackedConv(w.to(dev), None, mode)
+        y = ops.conv2d(x, pk)
+        torch.cuda.synchronize()
+        ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+        # compare before the fp16 store rounding matters: the store adds 2^-12 to both, so measure the MEAN error over 4096 outputs per
+        # channel instead (rounding noise averages out, a weight bias does not)
+        d = (y.double().cpu() - ref).mean(dim=(0, 1, 2)) / ref.abs().mean()
+        errs[mode] = float(d.abs().max())
+        log_err("low_weight_halves_" + mode, mode, errs[mode])
+    assert errs["fp16x2"] < 0.25 * errs["fp16x1"] + 2e-6, errs
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
+def test_group_norm_table_against_torch(dev, mode):
+    """hsidm_gn_partial + hsidm_gn_finalize against F.group_norm's affine form on the host (fp32 pairs and both fp16x2 copies)."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cc, groups = 3, 16, 16, 96, 32
+    x = (2.0 + torch.randn(B, H, W, Cc, generator=g)).to(_lib.act_dtype(mode)).to(dev)
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(Cc, generator=g)).to(dev)
+    tab = ops.gn_scale_shift(x, None, gamma, beta, groups, mode)
+    torch.cuda.synchronize()
+    n = B * Cc
+    pairs = tab[:2 * n].reshape(B, Cc, 2).cpu()
+    xf = x.float().cpu().permute(0, 3, 1, 2)
+    want = F.group_norm(xf, groups, gamma.cpu(), beta.cpu(), eps=1e-5)
+    got = xf * pairs[:, :, 0, None, None] + pairs[:, :, 1, None, None]
+    check("gn_table_fp32_pairs", mode, got, want, tol=1e-5)
+    h = tab[2 * n:3 * n].view(torch.int32).cpu().view(torch.float16).reshape(B, Cc, 2).float()
+    got_h = xf * h[:, :, 0, None, None] + h[:, :, 1, None, None]
+    check("gn_table_fp16_pairs", mode, got_h, want, tol=6e-4)
+    hs = tab[3 * n:4 * n].view(torch.int32).cpu().view(torch.float16).reshape(B, Cc, 2).float() / 1.44269504
+    got_s = xf * hs[:, :, 0, None, None] + hs[:, :, 1, None, None]
+    check("gn_table_fp16_log2e_pairs", mode, got_s, want, tol=6e-4)

@@ -4,8 +4,9 @@ kernel dispatch needs.
   * chain.npz: the reference's validation iteration (sr_gae.py:436-474) on the 97.8 M-parameter UNet, its T = 20 cosine
     chain, one CAVE image (5 spectral groups, pretrained CAVE autoencoder), run by the imported reference with the noise
     of tests/golden/synth.py:chain_noise (tests/golden/make_golden_chain.py);
-  * north-star gates: fp32 mode within 1e-3 relative on the latents and the cube; bf16 mode within 0.01 dB (MPSNR) and
-    0.001 degrees (SAM) of the reference's decoded cube, measured against the synthetic ground truth;
+  * north-star gates ("1e-3 relative; PSNR/SAM within 0.01 dB / 0.001"): the fp32 mode and the fp16 mode (fp16 storage and
+    operands, hi + lo weights on the high-resolution levels) are held to ALL of them; the bf16 mode meets the PSNR bound only
+    and is gated at its measured deviation with head-room (DSAM_MAX / LATENT_MAX below say so explicitly);
   * the benchmark's dispatch (256-cout items on 8 waves, multi-round persistent loops, XCD tile remap) only engages at
     B >= 36: one forward of the shipped UNet at B = 40 against the oracle on the host, with the launch set asserted.
 """
@@ -21,14 +22,23 @@ pytestmark = pytest.mark.gpu
 
 FULL = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8], attn_res=[16],
             res_blocks=2, image_size=128)
-# north_star: "PSNR/SAM within 0.01 dB / 0.001".  The fp32 mode meets both with four orders of magnitude to spare; the bf16 mode
-# meets the PSNR bound (measured 0.0012 dB) but not the SAM bound: measured 0.012 degrees after the 20-step chain, i.e. the
-# 8-bit significand of every MFMA operand and stored activation (2^-9 relative per layer, 7.7e-3 on the latents after 20
-# steps) - no re-arrangement inside a bf16 pipeline removes that, so the bf16 gate is the measured value with 2.5x head-room
-# and the fp32 mode is the parity mode.
-DPSNR_MAX = {"fp32": 0.01, "bf16": 0.01}
-DSAM_MAX = {"fp32": 0.001, "bf16": 0.03}
-LATENT_MAX = {"fp32": 1e-3, "bf16": 2e-2}
+# north_star: "Outputs match the reference PyTorch CPU path within 1e-3 relative fp32 (PSNR/SAM within 0.01 dB / 0.001)".
+#   fp32  : meets every bound with four orders of magnitude to spare (bf16 hi + lo operands, three MFMA passes).
+#   fp16  : meets every bound - 11-bit significands, and the weight rounding (the one error that is the same in every step of
+#           the chain: a bias, not noise) removed where the second MFMA pass is nearly free; tests/precision_emul.py reproduces
+#           the device numbers on the host and shows which rounding contributes what.
+#   bf16  : meets the PSNR bound (0.0012 dB) but neither the latent bound (7.7e-3) nor the SAM bound (0.012 degrees): 8-bit
+#           significands on every MFMA operand and stored activation.  Its gate is the measured value with 2.5x head-room - a
+#           regression gate, NOT a north-star claim (bench.py's `parity` object says meets_north_star: false for it).
+# fp16x1 (no second weight pass) sits ON the bounds (emulation: 9.9e-4 / 1.0e-3 degrees) and is only logged.
+# A note on dSAM on this fixture: the UNet's weights are synthetic, so the decoded cube is not an image - 55 % of it is clamped
+# to 0, SAM is 56 degrees, and the index (mean angle over pixels whose spectra are non-zero, eval_hsi.py:47-65; 67 all-zero pixels, 113 with one band left) moves by
+# 1.4e-3 degrees whenever ONE pixel's spectrum crosses between all-zero and not.  dSAM therefore counts such crossings rather
+# than measuring an angle: a mode passes when its perturbation (latents ~7e-4) flips none.
+NORTH_STAR = dict(latents=1e-3, dpsnr=0.01, dsam=0.001)
+DPSNR_MAX = {"fp32": 0.01, "fp16": 0.01, "fp16x2": 0.01, "fp16x1": 0.01, "bf16": 0.01}
+DSAM_MAX = {"fp32": 0.001, "fp16": 0.001, "fp16x2": 0.001, "fp16x1": 0.01, "bf16": 0.03}
+LATENT_MAX = {"fp32": 1e-3, "fp16": 1e-3, "fp16x2": 1e-3, "fp16x1": 2e-3, "bf16": 2e-2}
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +58,7 @@ def _full_unet(dev, prec):
     return u, sd
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp16x2", "fp16x1", "bf16"])
 def test_full_size_T20_chain_against_the_reference_run(dev, prec):
     from hsi_dmgasr_amd import gae, pipeline
     from hsi_dmgasr_amd.sr3_modules import diffusion
@@ -79,7 +89,10 @@ def test_full_size_T20_chain_against_the_reference_run(dev, prec):
     psnr_vs_ref = metrics.mpsnr(ref, got)
     log_err("chain_T20_full_latents", prec, e_lat, {"cube_rel_err": e_y, "dPSNR_dB": dpsnr, "dSAM_deg": dsam,
                                                     "psnr_of_ours_vs_reference_cube_dB": psnr_vs_ref,
-                                                    "max_abs_latent_diff": float(np.abs(lat - g["x0"]).max())})
+                                                    "max_abs_latent_diff": float(np.abs(lat - g["x0"]).max()),
+                                                    "zero_spectrum_crossings": int(np.count_nonzero((np.abs(got).sum(2) == 0) != (np.abs(ref).sum(2) == 0))),
+                                                    "meets_north_star": bool(e_lat <= NORTH_STAR["latents"] and dpsnr <= NORTH_STAR["dpsnr"] and
+                                                                             dsam <= NORTH_STAR["dsam"])})
     # the fixture's own indices were computed by the reference's eval_hsi.py: the oracle's restatements must agree on them
     assert abs(metrics.sam_degrees(a, ref) - float(g["sam"])) < 2e-3
     assert abs(metrics.mpsnr(a, ref) - float(g["mpsnr_formula"])) < 1e-4
