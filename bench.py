@@ -13,12 +13,20 @@ posterior update) over this GPU's batch of latents: `--patches` CAVE patches x 5
 Inputs are resident in HBM before the timed region; the step is a captured HIP graph.  Rank 0 prints ONE
 JSON line.  value = steps * total batch / seconds  ("UNet denoise-steps/sec x batch").
 
+The headline precision mode is "fp16" (fp16 storage and MFMA operands, hi + lo weights on the two high-resolution levels): the
+fastest mode that meets north_star's tolerance on the reference's own validation chain (tests/golden/chain.npz) - the `parity`
+object of the line says so per mode, measured in this run.  bf16 (the mode BASELINE configs[1] names) is faster and does NOT
+meet it; its throughput is reported beside the headline (`bf16_mode`), as is the fp32 mode's (`fp32_mode`).
+
 Extra objects in the line:
   roofline     - the implicit-GEMM conv kernel family (the dominant kernel): algorithmic FLOPs of its launches
-                 in one step / their HIP-event durations, against the dense bf16 MFMA peak.
+                 in one step / their HIP-event durations, against the dense 16-bit MFMA peak.
+  parity       - per precision mode: the reference's T = 20 validation chain (one CAVE image, 97.8 M UNet, pretrained
+                 autoencoder; reference outputs in tests/golden/chain.npz) run on this GPU: latents relative error, dPSNR, dSAM
+                 and meets_north_star (1e-3 / 0.01 dB / 0.001 degrees).
   cpu_baseline - the oracle (CPU restatement of the reference, oracle/) timed on this host, rank 0, N=1 only.
-  fp32_mode    - the same step in the fp32 ("bf16x3 split") parity mode: ms per step, throughput, dominant-kernel roofline
-                 (rank 0, N=1 only; the mode that carries the 1e-3 parity gate).
+  bf16_mode / fp32_mode - the same step in the other two modes: ms per step, throughput, dominant-kernel roofline
+                 (rank 0, N=1 only).
   gae          - group-autoencoder encode / decode of this rank's patches (31 x 128 x 128 CAVE cubes): ms, TFLOP/s,
                  fraction of the MFMA peak (the step before / after the chain, sr_gae.py:456,467).
   rccl_ranks / allgather_ms - N > 1: ranks in the RCCL group and the time of the final all-gather of the SR cubes.
@@ -39,7 +47,10 @@ FULL_CFG = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, c
                 attn_res=[16], res_blocks=2, image_size=128)
 SCHED = dict(schedule="cosine", n_timestep=1000, linear_start=1e-6, linear_end=1e-2)
 GROUPS = 5                 # CAVE: 31 bands, n_subs=8, n_ovls=2 -> 5 spectral groups (AE.py:263)
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, bf16 and fp16 alike, MI355X_MICROARCH.md
+HEADLINE = "fp16"                # the fastest mode that meets north_star's tolerance (see `parity`)
+DTYPE = {"bf16": "bf16", "fp16": "fp16 (hi+lo fp16 weights on the Cout<=128 layers)", "fp16x1": "fp16 (one weight pass)",
+         "fp16x2": "fp16 (hi+lo fp16 weights wherever a kernel takes them)", "fp32": "fp32 (bf16x3 split)"}
 HBM_PEAK_GBPS = 8000.0           # HBM3E spec (6290 measured by a streaming read), MI355X_MICROARCH.md
 
 
@@ -123,6 +134,49 @@ def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1):
                                       tflops=all_fl / (all_ms * 1e-3) / 1e12))
 
 
+def chain_parity(dev, modes=("fp16", "bf16", "fp32")):
+    """north_star's tolerance, measured here: the reference's own validation iteration (sr_gae.py:436-474) at its shipped
+    configuration - T = 20 cosine chain, one CAVE image = 5 group latents, 97.8 M UNet (synthetic weights keyed by name),
+    pretrained CAVE autoencoder - whose outputs BY THE REFERENCE are committed as tests/golden/chain.npz
+    (tests/golden/make_golden_chain.py).  Quality indices by the product's device kernels (hsidm_hsi_metrics, pinned to the
+    reference's eval_hsi.py in the tests).  The autoencoder runs in its default fp32 mode."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from synth import CHAIN_T, chain_cubes, chain_noise, synth_param
+    from hsi_dmgasr_amd import gae, metrics, pipeline
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    g = np.load(os.path.join(ROOT, "tests", "golden", "chain.npz"))
+    hr, sr = chain_cubes()
+    G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision="fp32").to(dev).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(os.path.join(ROOT, "tests", "golden", "gae_cav_state.npz")).items()})
+    u = unet.UNet(dropout=0.2, **FULL_CFG).to(dev).eval()
+    u.load_state_dict({k: torch.from_numpy(synth_param("unet_full." + k, tuple(v.shape))) for k, v in u.state_dict().items()
+                       if not k.startswith("_")}, strict=False)
+    gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=CHAIN_T, linear_start=1e-6, linear_end=1e-2), dev)
+    ngr = g["x0"].shape[0]
+    x_T = G(np.concatenate([chain_noise(gi, 0) for gi in range(ngr)]))
+    noise = G(np.stack([np.concatenate([chain_noise(gi, k) for gi in range(ngr)]) for k in range(1, CHAIN_T)]))
+    truth, ref_y, ref_lat = G(hr), G(g["y"]), G(g["x0"])
+    q_ref = metrics.quality_indices(truth, ref_y)[0]
+    out = {"fixture": "tests/golden/chain.npz: the reference's validation iteration, T=20 cosine, 5 group latents 3x128x128, 97.8M UNet, "
+                      "pretrained CAVE autoencoder; bounds 1e-3 relative / 0.01 dB / 0.001 deg (BASELINE.json north_star)"}
+    with torch.no_grad():
+        for prec in modes:
+            y, lat = pipeline.super_resolve(m, gd, G(sr), x_T=x_T, noise=noise, precision=prec)
+            q = metrics.quality_indices(truth, y)[0]
+            e_lat = float((lat[0] - ref_lat).double().norm() / ref_lat.double().norm())
+            e_y = float((y - ref_y).double().norm() / ref_y.double().norm())
+            dpsnr, dsam = abs(float(q[0] - q_ref[0])), abs(float(q[1] - q_ref[1]))
+            out[prec] = dict(latents_rel_err=e_lat, cube_rel_err=e_y, dPSNR_dB=dpsnr, dSAM_deg=dsam,
+                             meets_north_star=bool(e_lat <= 1e-3 and e_y <= 1e-3 and dpsnr <= 0.01 and dsam <= 1e-3))
+    del u, gd, m
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(batch=1, steps=160, warm=2):
     """The oracle on the host CPU: full-size UNet p_sample steps (fp32), a bounded sample (about 10-25 s) of the same
     workload: 160 of the 1000 reverse steps at batch 1 (every step costs the same)."""
@@ -173,16 +227,29 @@ def usable_cpus():
     return max(1, n)
 
 
-def gae_bench(dev, patches, reps=5):
-    """Group-autoencoder encode / decode of `patches` CAVE cubes (31 x 128 x 128, G = 5 groups stacked on the batch axis),
-    pretrained-checkpoint architecture (n_subs 8, n_ovls 2, 64 features), fp32 parity mode and bf16."""
-    from hsi_dmgasr_amd import gae
+def gae_bench(dev, patches, reps=5, bands=31, n_subs=8, n_ovls=2, groups=5, flops=None):
+    """Group-autoencoder encode / decode of `patches` cubes of `bands` x 128 x 128 (G spectral groups stacked on the batch axis),
+    pretrained-checkpoint architecture (CAVE: n_subs 8, n_ovls 2; Chikusei: 16 / 4, G = 11; 64 features) in every
+    precision mode, with each 16-bit mode's deviation from the fp32 mode on the same cubes (PSNR of the reconstruction against the
+    input: the autoencoder's decode sets the final PSNR, so its mode is held to the 0.01 dB bound too; weights: the module's
+    default initialisation, there is no pretrained Chikusei-size checkpoint in reach of the GPU box)."""
+    from hsi_dmgasr_amd import gae, metrics
     out = {}
-    flops = dict(encode=41.3e9, decode=41.3e9 + 1.9e9)          # per patch at 128 x 128 (SURVEY Appendix B; decode includes the trunk)
-    x = torch.rand(patches, 31, 128, 128, generator=torch.Generator().manual_seed(3)).to(dev)
-    for prec in ("bf16", "fp32"):
-        m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision=prec).to(dev).eval()
+    flops = flops or dict(encode=41.3e9, decode=41.3e9 + 1.9e9)  # per patch at 128 x 128 (SURVEY Appendix B; decode includes the trunk)
+    x = torch.rand(patches, bands, 128, 128, generator=torch.Generator().manual_seed(3))
+    x = ((x[:, :-2] + x[:, 1:-1] + x[:, 2:]) / 3.0 if bands > 2 else x)                    # smooth along the band axis (SURVEY 8d)
+    x = torch.nn.functional.pad(x, (0, 0, 0, 0, 1, 1), mode="replicate")[:, :bands].contiguous().to(dev)
+    sd, ref_q = None, None
+    for prec in ("fp32", "fp16", "bf16"):
+        m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=n_subs, n_ovls=n_ovls, n_colors=bands, n_feats=64, precision=prec).to(dev).eval()
+        if sd is None:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+        else:
+            m.load_state_dict(sd)
         z = m.encode_batched(x)
+        q = metrics.quality_indices(x, m.decode_batched(z, bands).clamp(0.0, 1.0))[:, :2].double().mean(dim=0)
+        if ref_q is None:
+            ref_q = q
         rec = {}
         for name, fn in (("encode", lambda: m.encode_batched(x)), ("decode", lambda: m.decode_batched(z, 31))):
             fn()
@@ -196,10 +263,13 @@ def gae_bench(dev, patches, reps=5):
             rec[name + "_ms"] = best
             rec[name + "_tflops"] = tf
             rec[name + "_frac_of_mfma_peak"] = tf / MFMA_BF16_PEAK_TFLOPS
+        rec["dPSNR_dB_vs_fp32_mode"] = abs(float(q[0] - ref_q[0]))
+        rec["dSAM_deg_vs_fp32_mode"] = abs(float(q[1] - ref_q[1]))
+        rec["within_0.01dB_0.001deg"] = bool(rec["dPSNR_dB_vs_fp32_mode"] <= 0.01 and rec["dSAM_deg_vs_fp32_mode"] <= 1e-3)
         out[prec] = rec
         del m, z
     out["patches"] = patches
-    out["cube"] = "31x128x128, G=5"
+    out["cube"] = "%dx128x128, G=%d" % (bands, groups)
     return out
 
 
@@ -357,7 +427,10 @@ def main():
                          "120 latents -3 %, 640 latents +2 % (sweep in DESIGN.md)")
     ap.add_argument("--total-patches", type=int, default=0,
                     help="strong scaling: this many patches in total, sharded contiguously over the ranks (BASELINE configs[3]: 64)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=HEADLINE, choices=["bf16", "fp32", "fp16", "fp16x1", "fp16x2"],
+                    help="precision mode of the headline number (default: the fastest mode that meets north_star's tolerance)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity object (the T=20 reference chain in every mode)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the bf16_mode / fp32_mode objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode object")
@@ -429,9 +502,11 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         el = torch.tensor([dt], dtype=torch.float64, device=dev)
+        el_min = el.clone()
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dt = float(el.item())
+            dist.all_reduce(el_min, op=dist.ReduceOp.MIN)        # a straggler shows as max >> min
+        dt, dt_min = float(el.item()), float(el_min.item())
         assert torch.isfinite(run.x).all(), "sampler state diverged"
         log('timed region done: %.3f s' % dt)
         if use_dist:
@@ -451,32 +526,48 @@ def main():
         roof = None
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(run, batch)
+            # (fp16 mode: launches with hi + lo weights issue two MFMAs per product; `achieved` counts the algorithmic FLOPs once)
+            roof["mfma_passes_per_product"] = "2 on the Cout<=128 layers, 1 elsewhere" if args.precision == "fp16" else (2 if args.precision == "fp16x2" else 1)
     log('roofline done')
-    fp32 = None
-    if rank == 0 and world == 1 and not args.no_fp32 and args.precision == "bf16":
-        # the parity mode (fp32 storage, every product as three bf16 MFMAs) on the same workload and batch
-        del run
-        torch.cuda.empty_cache()
+    def other_mode(prec, passes):
+        """The same step, workload and batch in another precision mode (rank 0, N = 1)."""
         with torch.no_grad():
-            run32 = gd.make_run(cond, wrap=True, precision="fp32")
-            n32 = max(10, min(50, args.steps // 20))
+            r = gd.make_run(cond, wrap=True, precision=prec)
+            n = max(10, min(50, args.steps // 20))
             for _ in range(3):
-                run32.step()
+                r.step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(n32):
-                run32.step()
+            for _ in range(n):
+                r.step()
             torch.cuda.synchronize()
-            d32 = time.perf_counter() - t0
-            assert torch.isfinite(run32.x).all()
-            fp32 = dict(value=n32 * batch / d32, unit="denoise-steps*batch/s", ms_per_step=d32 / n32 * 1e3, steps=n32,
-                        dtype="fp32 storage, bf16 hi+lo split, 3 MFMA passes per product",
-                        roofline=None if args.no_roofline else conv_roofline(run32, batch, reps=2, passes=3))
-            del run32
+            d = time.perf_counter() - t0
+            assert torch.isfinite(r.x).all()
+            rec = dict(value=n * batch / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n, dtype=DTYPE[prec],
+                       roofline=None if args.no_roofline else conv_roofline(r, batch, reps=2, passes=passes))
+            del r
         torch.cuda.empty_cache()
-        log('fp32 mode done')
+        return rec
+
+    fp32 = bf16 = None
+    if rank == 0 and world == 1 and not args.no_modes and args.precision == HEADLINE:
+        del run
+        torch.cuda.empty_cache()
+        bf16 = other_mode("bf16", 1)
+        log('bf16 mode done')
+        if not args.no_fp32:
+            fp32 = other_mode("fp32", 3)      # fp32 storage, every product as three bf16 MFMAs
+            log('fp32 mode done')
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity = chain_parity(dev)
+        if bf16 is not None:
+            bf16["meets_north_star"] = parity["bf16"]["meets_north_star"]
+        if fp32 is not None:
+            fp32["meets_north_star"] = parity["fp32"]["meets_north_star"]
+        log('parity done')
     small = None
-    if rank == 0 and world == 1 and not args.no_small and args.precision == "bf16" and batch > 8 * GROUPS:
+    if rank == 0 and world == 1 and not args.no_small and args.precision == HEADLINE and batch > 8 * GROUPS:
         # the same step at the per-GPU share of BASELINE configs[3] on 8 GPUs (8 patches = 40 latents) and at one CAVE image (the
         # reference's own use: 5 latents): what strong scaling and single-image latency are made of
         small = {}
@@ -496,10 +587,12 @@ def main():
                 small["%d_latents" % b] = dict(value=n * b / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n)
                 del r
         log('small batches done')
-    gae_rec = None
+    gae_rec = gae_chik = None
     if rank == 0 and not args.no_gae:
         with torch.no_grad():
             gae_rec = gae_bench(dev, patches)
+            # BASELINE configs[2]: Chikusei, 128 bands, n_subs 16 / n_ovls 4 -> G = 11 groups (AE.py:263-280)
+            gae_chik = gae_bench(dev, min(patches, 16), bands=128, n_subs=16, n_ovls=4, groups=11, flops=dict(encode=92.5e9, decode=92.5e9 + 3.8e9))
         log('gae done')
     train_rec = None
     if rank == 0 and world == 1 and not args.no_train:
@@ -519,14 +612,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": args.precision if args.precision == "bf16" else "fp32 (bf16x3 split)",
+            "dtype": DTYPE[args.precision],
+            "meets_north_star": None if parity is None or args.precision not in parity else parity[args.precision]["meets_north_star"],
             "data": "synthetic (orthogonal-init weights seed 0, N(0,1) latents clipped to +-2.5, Philox noise)",
             "config": {"workload": "SR3 UNet 97.8M (6->3 ch, inner 64, mults 1-2-4-8-8, attn@16) p_sample step on "
                                    "GAE latents 3x128x128, cosine T=1000, BASELINE configs[%d]" % (3 if scaling == "strong" else 1),
                        "patches_per_gpu": patches, "total_patches": total_patches, "groups_per_patch": GROUPS,
                        "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": allgather_ms,
-            "roofline": roof, "fp32_mode": fp32, "small_batches": small, "gae": gae_rec, "train_step": train_rec, "cpu_baseline": cpu,
+            "rank_ms_per_step": {"min": dt_min / args.steps * 1e3, "max": dt / args.steps * 1e3},
+            "roofline": roof, "parity": parity, "bf16_mode": bf16, "fp32_mode": fp32, "small_batches": small, "gae": gae_rec,
+            "gae_chikusei": gae_chik, "train_step": train_rec, "cpu_baseline": cpu,
         }
         flush_c_stdio()
         print(json.dumps(line), flush=True)

@@ -247,14 +247,24 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
 
 
 _sk_ws = {}
+_sk_retired = []
 
 
 def _sk_workspace(nbytes, dev):
-    """One growing scratch buffer per device for the split-K partial sums (written and consumed inside one hsidm_conv2d call, so
-    stream order makes sharing it between launches safe; it must exist before a step is captured: the eager first step sizes it)."""
+    """One scratch buffer per device for the split-K partial sums (written and consumed inside one hsidm_conv2d call, so stream
+    order makes sharing it between launches safe).  Captured hipGraphs (ReverseRun, Trainer) bake its ADDRESS in, and the size
+    needed is not monotonic in the batch (18.35 MB at 5 latents, 18.9 MB at 6 on the 16x16 level): a buffer that has to grow is
+    therefore never freed - the superseded one is parked in _sk_retired, where a live graph may keep writing to it - and sizes
+    are rounded up to powers of two (>= 32 MiB), so that at most log2 of them ever exist and their sum stays below twice the
+    largest."""
     buf = _sk_ws.get(dev.index)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        size = 32 << 20
+        while size < nbytes:
+            size <<= 1
+        if buf is not None:
+            _sk_retired.append(buf)
+        buf = torch.empty(size, dtype=torch.uint8, device=dev)
         _sk_ws[dev.index] = buf
     return buf
 

@@ -136,8 +136,15 @@ class _TrainingLoss(torch.autograd.Function):
     def backward(ctx, g):
         tr = ctx.tr
         tr.backward_loss(ctx.state, float(g))
+        # With several ranks the backward pass has already all-reduced (SUMMED) the flat gradient buffer through its GradReducer;
+        # a torch optimiser on this path expects what DistributedDataParallel would hand it - the AVERAGE - so the factor
+        # Trainer.optimizer_step applies itself is applied here (and the flag cleared: nothing is left to reduce).
+        scale = 1.0
+        if tr._reduced:
+            import torch.distributed as dist
+            scale, tr._reduced = 1.0 / dist.get_world_size(), False
         # copies: autograd accumulates into p.grad, which may itself be a view of the flat gradient buffer
-        return (None, None, None) + tuple(tr.G(p).clone() for p in tr.net.parameters())
+        return (None, None, None) + tuple(tr.G(p).clone() if scale == 1.0 else tr.G(p) * scale for p in tr.net.parameters())
 
 
 class GaussianDiffusion(nn.Module):

@@ -38,7 +38,17 @@ class Trainer:
         if not isinstance(net, UNet):
             raise TypeError("hsidm: Trainer needs a GaussianDiffusion over hsi_dmgasr_amd's UNet")
         self.gd, self.net = gd, net
+        # what the hand-written backward pass covers is what the reference's UNet builds (unet.py:152,206: one attention head,
+        # additive FiLM); the two constructor variants its classes also accept have forward kernels only
+        for u in net._res_units():
+            if u.res_block.noise_func.use_affine_level:
+                raise NotImplementedError("hsidm: the training step has no adjoint for FeatureWiseAffine(use_affine_level=True)")
+            if u.with_attn and u.attn.n_head != 1:
+                raise NotImplementedError("hsidm: the training step has no adjoint for SelfAttention(n_head=%d); n_head must be 1"
+                                          % u.attn.n_head)
         self.precision = resolve_precision(precision if precision is not None else net.precision)
+        if self.precision not in ("bf16", "fp32"):
+            raise NotImplementedError("hsidm: the training step runs in the bf16 or the fp32 mode (got %r)" % self.precision)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.dropout_seed = int(dropout_seed)
         self.bucket_bytes = int(bucket_bytes)
@@ -48,7 +58,8 @@ class Trainer:
         self._film_bufs, self._b1_idx = {}, None
         self._shape_seen, self._tracking = None, False
         self._defer_obj, self._defer = None, None
-        self._g, self._g_active, self._g_calls = None, False, 0      # captured step (optimize_parameters): state, capturing/replaying, calls
+        self._g, self._g_active = None, False          # captured step (optimize_parameters): state, capturing / replaying
+        self._eager_shape = None                       # batch shape of the LAST eager step (what every workspace is sized for)
         self.dev = next(net.parameters()).device
         self._check_device()
         self._flatten()
@@ -199,7 +210,7 @@ class Trainer:
             self._pk[(cid, role)] = pk
         for conv, _, _, _ in self._convs():          # forward convolutions read their bias straight from the master copy
             self._pk[(id(conv), "fwd")].bias = None if conv.bias is None else conv.bias.detach()
-        self._g, self._g_calls = None, 0             # a captured step holds pointers into the old buffers
+        self._g, self._eager_shape = None, None      # a captured step holds pointers into the old buffers
 
     def _track_layouts(self, on):
         for pk in self._pk.values():
@@ -232,7 +243,9 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------------ forward (training mode)
     def _drop_key_value(self):
-        return (self.dropout_seed + 0x9E3779B97F4A7C15 * self._iter) & 0xFFFFFFFFFFFFFFFF
+        # one key per forward pass AND per rank: data-parallel replicas draw independent dropout masks, as the reference's do
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        return (self.dropout_seed + 0x9E3779B97F4A7C15 * self._iter + 0xD1B54A32D192ED03 * rank) & 0xFFFFFFFFFFFFFFFF
 
     def _drop_key(self):
         """Philox key of the current forward pass's dropout masks (a new one per forward_loss call; backward re-derives it):
@@ -474,6 +487,8 @@ class Trainer:
         gd = self.gd
         self._iter += 1
         x_start = x_in["HR"].contiguous()
+        if not self._g_active:
+            self._eager_shape = None                   # (set again by _graphed_step once this eager step is complete)
         self._note_shape(tuple(x_start.shape))
         if self._versions() != self._packed_at:        # someone else (a torch optimiser, load_state_dict) changed the weights
             self.repack()
@@ -535,6 +550,90 @@ class Trainer:
         torch.autograd.graph.increment_version(self._params)
         self.repack()
 
+    # ------------------------------------------------------------------------------------------------ checkpoint / resume
+    def _adam_params(self):
+        """The parameters in the order ``torch.optim.Adam(netG.parameters())`` numbers them (model/model.py:37-41)."""
+        return list(self.net.parameters())
+
+    def _strided_like(self, p, flat):
+        """View of a flat buffer laid out like parameter p's slot (3x3 weights are channels-last in memory, see _flatten)."""
+        o, n = self._off[id(p)], p.numel()
+        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+            co, ci, kh, kw = p.shape
+            return flat[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat[o:o + n].view(p.shape)
+
+    @torch.no_grad()
+    def state_dict(self):
+        """The optimiser state in the format of ``torch.optim.Adam.state_dict()`` over ``netG.parameters()`` - what the reference
+        stores under 'optimizer' in ``*_opt.pth`` (model/model.py:140-143) - so either side can resume the other's run."""
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(self._adam_params()):
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self._strided_like(p, self.m).detach().clone().contiguous(),
+                            "exp_avg_sq": self._strided_like(p, self.v).detach().clone().contiguous()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self._adam_params())))}
+        return {"state": state, "param_groups": [group], "hsidm": {"iter": self._iter, "dropout_seed": self.dropout_seed}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        """Inverse of state_dict(); also accepts the state_dict of a torch.optim.Adam built over the same parameters."""
+        params = self._adam_params()
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(params):
+            raise ValueError("hsidm: optimizer state has %d parameters, the network %d" % (len(group["params"]), len(params)))
+        if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
+            raise NotImplementedError("hsidm: Adam with weight_decay / amsgrad / maximize is not what model/model.py:37-41 builds")
+        self.lr, self.betas, self.eps = float(group["lr"]), (float(group["betas"][0]), float(group["betas"][1])), float(group["eps"])
+        self.m.zero_(); self.v.zero_()
+        steps = set()
+        for i, p in enumerate(params):
+            st = sd["state"].get(group["params"][i])
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("hsidm: optimizer state %d has shape %s, the parameter %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            self._strided_like(p, self.m).copy_(st["exp_avg"].to(self.dev, torch.float32))
+            self._strided_like(p, self.v).copy_(st["exp_avg_sq"].to(self.dev, torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("hsidm: per-parameter step counts differ (%s); the fused Adam keeps one" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        extra = sd.get("hsidm", {})
+        self._iter = int(extra.get("iter", self.step_count))
+        self.dropout_seed = int(extra.get("dropout_seed", self.dropout_seed))
+        self._g = None                                          # (a captured step bakes nothing of this in, but start clean)
+
+    def save_network(self, prefix, epoch, iter_step):
+        """DDPM.save_network (model/model.py:125-145): ``<prefix>_gen.pth`` = the GaussianDiffusion's state_dict on the host,
+        ``<prefix>_opt.pth`` = {'epoch', 'iter', 'scheduler': None, 'optimizer': Adam state}.  Returns the two paths."""
+        gen_path, opt_path = "%s_gen.pth" % prefix, "%s_opt.pth" % prefix
+        torch.save({k: v.detach().cpu().contiguous() for k, v in self.gd.state_dict().items()}, gen_path)
+        torch.save({"epoch": epoch, "iter": iter_step, "scheduler": None, "optimizer": self.state_dict()}, opt_path)
+        return gen_path, opt_path
+
+    def load_network(self, prefix, drop_stem_and_final=True, load_optimizer=False, map_location="cpu"):
+        """DDPM.load_network (model/model.py:177-202).  As shipped the reference drops the stem weight and the final convolution's
+        weight and bias (so that a checkpoint trained for another channel count seeds this one, :187-191), loads non-strictly and
+        does NOT restore the optimiser (its lines are commented out, :198-202): the defaults here.  load_optimizer=True is the
+        resume the commented code describes.  Returns (epoch, iter) of the optimiser file, or (0, 0)."""
+        ckpt = torch.load("%s_gen.pth" % prefix, map_location=map_location)
+        if drop_stem_and_final:
+            drop = ("denoise_fn.downs.0.weight", "denoise_fn.final_conv.block.3.weight", "denoise_fn.final_conv.block.3.bias")
+            ckpt = {k: v for k, v in ckpt.items() if k not in drop}
+        with torch.no_grad():
+            self.gd.load_state_dict(ckpt, strict=False)         # copies INTO the flat views (the parameters stay views)
+        self.repack()
+        self._g = None
+        if not load_optimizer:
+            return 0, 0
+        opt = torch.load("%s_opt.pth" % prefix, map_location=map_location, weights_only=False)
+        self.load_state_dict(opt["optimizer"])
+        return opt.get("epoch", 0), opt.get("iter", 0)
+
     def optimize_parameters(self, data, use_graph=True, **kw):
         """model/model.py:49-59.  -> l_pix (0-dim device tensor; the reference logs .item()).
 
@@ -561,11 +660,15 @@ class Trainer:
         b = hr.shape[0]
         shape_key = (tuple(hr.shape), None if sr is None else tuple(sr.shape))
         if self._g is not None and self._g["shape"] != shape_key:
-            self._g, self._g_calls = None, 0                    # another batch shape: capture again
-        self._g_calls += 1
-        if self._g_calls == 1:                                  # eager: sizes every cache (workspaces, LDS caps, offsets) and
-            loss = self.loss_and_grads(data)                    # prunes the packed layouts for this batch shape
+            self._g = None                                      # another batch shape: capture again
+        if self._g is None and self._eager_shape != shape_key:
+            # A capture must directly follow an EAGER step at the same shape: that step sizes every cache the captured kernels
+            # take pointers to (split-K and deferred-reduction workspaces, FiLM buffers, offset tables, LDS caps) and prunes the
+            # packed layouts for this shape.  The reference's DataLoader has no drop_last: a partial last batch drops the graph,
+            # runs eagerly, and the next full batch runs eagerly once more before it is captured again.
+            loss = self.loss_and_grads(data)
             self.optimizer_step()
+            self._eager_shape = shape_key
             return loss
         if self._g is None:
             g = dict(shape=shape_key, hr=hr.clone(), sr=None if sr is None else sr.clone(),
@@ -606,10 +709,12 @@ class Trainer:
             finally:
                 self._g_active = False
             g["graph"] = graph
+        elif self._versions() != self._packed_at:               # load_state_dict / a broadcast / an init wrote the master copy
+            self.repack()                                       # between two replays: the packed kernel weights follow
         g["graph"].replay()
         torch.autograd.graph.increment_version(self._params)    # the replay rewrote the parameters through raw pointers
         self._packed_at = self._versions()
-        return g["loss"]
+        return g["loss"].clone()                                # (the graph's own tensor is overwritten by the next replay)
 
     def _captured_body(self, g):
         """One training step with every per-iteration quantity read from device memory (recorded once, replayed)."""

@@ -19,9 +19,10 @@ import torch.nn.functional as F
 from . import philox, sr3_unet
 
 
-def drop_key(dropout_seed, step_count):
-    """Philox key of the dropout masks of the `step_count`-th (0-based) training forward pass, as training.Trainer._drop_key."""
-    return (int(dropout_seed) + 0x9E3779B97F4A7C15 * (int(step_count) + 1)) & 0xFFFFFFFFFFFFFFFF
+def drop_key(dropout_seed, step_count, rank=0):
+    """Philox key of the dropout masks of the `step_count`-th (0-based) training forward pass on data-parallel rank `rank`, as
+    training.Trainer._drop_key (replicas draw independent masks, as the reference's nn.DataParallel replicas do)."""
+    return (int(dropout_seed) + 0x9E3779B97F4A7C15 * (int(step_count) + 1) + 0xD1B54A32D192ED03 * int(rank)) & 0xFFFFFFFFFFFFFFFF
 
 
 def dropout_factor(key, layer, shape_nchw, p):

@@ -87,6 +87,7 @@ class Mode:
             setattr(self, k, v)
         self.gn = kv.get("gn", "fp32")
         self.sk = kv.get("sk", "shra")
+        self.wl = kv["wl"].split("+") if "wl" in kv else None      # wl=final+ups.18: hi + lo weights on these units only
         self.stl = kv["stl"].split("+") if "stl" in kv else []     # stl=ups.18+ups.17: fp32 storage for the tensors of these units
         self.cur = ""
         self.sm = kv.get("sm", "")
@@ -112,6 +113,8 @@ class Mode:
         return rnd(x, self.t)
 
     def weight(self, w, hw):
+        if self.wl is not None:
+            return split2(w, self.t) if any(self.cur.startswith(q) for q in self.wl) else rnd(w, self.t)
         if self.cout_max is not None and w.shape[0] > self.cout_max:
             return rnd(w, self.t)
         if self.w == "fp32" and self._ovr("w", hw):
@@ -196,6 +199,7 @@ def unet_forward(m, sd, cfg, x, gamma):
 
     for i, e in enumerate(downs):
         p = "downs.%d." % i
+        m.cur = p
         if e[0] == "conv":
             x = m.store(F.conv2d(x, m.weight(sd[p + "weight"], x.shape[-1]), sd[p + "bias"], padding=1))
         elif e[0] == "res":
@@ -213,6 +217,7 @@ def unet_forward(m, sd, cfg, x, gamma):
             m.cur = p
             x = F.interpolate(x, scale_factor=2, mode="nearest")
             x = m.store(F.conv2d(m.conv_in(x), m.weight(sd[p + "conv.weight"], x.shape[-1]), sd[p + "conv.bias"], padding=1))
+    m.cur = "final_conv."
     return block(m, sd, "final_conv.", x, groups, last=True)
 
 

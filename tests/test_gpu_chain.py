@@ -264,8 +264,9 @@ def test_repacking_follows_in_place_reinitialisation(dev):
 @pytest.mark.gpu
 def test_bench_line_carries_every_object():
     """`python bench.py` end to end at a reduced size (12 patches = 60 latents, 6 timed steps) as the driver runs it: ONE JSON object
-    on the last line of stdout with the contract's keys, the roofline of the dominant kernel, both precision modes, the small-batch,
-    group-autoencoder and training-step objects and the CPU baseline."""
+    on the last line of stdout with the contract's keys, the roofline of the dominant kernel, the parity object (which modes meet
+    north_star's tolerance on the reference chain), the other precision modes, the small-batch, group-autoencoder (CAVE and
+    Chikusei) and training-step objects and the CPU baseline."""
     import json
     import os
     import subprocess
@@ -278,14 +279,26 @@ def test_bench_line_carries_every_object():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["steps"] == 6 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16"
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"].startswith("fp16")
     assert d["config"]["batch_per_gpu"] == 60 and "workload" in d["config"]
     assert abs(d["value"] - 6 * 60 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["hbm_view"]["fused_unit"]["frac"] < rf["hbm_view"]["frac"]
+    # the line states itself which modes meet north_star's tolerance: the headline (fp16) and the fp32 mode do, bf16 does not
+    par = d["parity"]
+    assert par["fp16"]["meets_north_star"] is True and par["fp32"]["meets_north_star"] is True and par["bf16"]["meets_north_star"] is False
+    assert par["fp16"]["latents_rel_err"] < 1e-3 and par["fp16"]["dSAM_deg"] <= 1e-3 and par["fp16"]["dPSNR_dB"] <= 0.01
+    assert d["meets_north_star"] is True
+    assert d["bf16_mode"]["value"] > 0 and d["bf16_mode"]["meets_north_star"] is False
     assert d["fp32_mode"]["value"] > 0 and d["fp32_mode"]["roofline"]["mfma_passes_per_product"] == 3
     assert set(d["small_batches"]) == {"40_latents", "5_latents"} and all(v["value"] > 0 for v in d["small_batches"].values())
-    assert d["gae"]["bf16"]["encode_ms"] > 0 and d["train_step"]["bf16"]["graph_ms_per_step"] > 0
+    for key in ("gae", "gae_chikusei"):
+        for mode in ("fp32", "fp16", "bf16"):
+            assert d[key][mode]["encode_ms"] > 0 and "dPSNR_dB_vs_fp32_mode" in d[key][mode]
+        assert d[key]["fp16"]["within_0.01dB_0.001deg"] is True
+    assert d["gae_chikusei"]["cube"] == "128x128x128, G=11"
+    assert d["train_step"]["bf16"]["graph_ms_per_step"] > 0
+    assert d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]

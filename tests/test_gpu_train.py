@@ -500,3 +500,51 @@ def test_gradient_allreduce_over_an_rccl_group_of_one(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_partial_last_batch_between_captured_steps(dev, prec):
+    """The reference's DataLoader has no drop_last (sr_gae.py:182-186): full, full, full, PARTIAL, full, full, full.  The captured step
+    is dropped for the partial batch, which runs eagerly; the next full batch must run eagerly again before it is re-captured (every
+    workspace is sized by the last eager step), and the parameters must keep moving the way an all-eager run moves them."""
+    cfg = WIDE
+    sd, gd, tr = build(cfg, "wide", "l1", prec, dev, True, lr=1e-4)
+    sd2, gd2, ref = build(cfg, "wide", "l1", prec, dev, True, lr=1e-4)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda b: {"HR": torch.randn(b, 3, 32, 32, generator=g).to(dev), "SR": torch.randn(b, 3, 32, 32, generator=g).to(dev)}
+    batches = [mk(4), mk(4), mk(4), mk(1), mk(4), mk(4), mk(4)]
+    modes = []
+    for i, data in enumerate(batches):
+        np.random.seed(100 + i)
+        torch.manual_seed(200 + i)
+        loss = tr.optimize_parameters(data)
+        modes.append("graph" if (tr._g is not None and tr._g.get("graph") is not None and tr._g["shape"][0][0] == data["HR"].shape[0]) else "eager")
+        assert bool(torch.isfinite(loss)), (i, float(loss))
+    torch.cuda.synchronize()
+    assert modes == ["eager", "graph", "graph", "eager", "eager", "graph", "graph"], modes
+    assert torch.isfinite(tr.flat).all()
+    # the all-eager twin sees other noise (torch's graph-safe generator draws differently), so only the SIZE of the update is
+    # compared: seven Adam steps at lr 1e-4 move every weight by at most 7e-4
+    moved = float((tr.flat - ref.flat).abs().max())
+    assert 1e-5 < moved <= 7.5e-4, moved
+
+
+def test_trainer_checkpoint_round_trip_on_the_device(dev, tmp_path):
+    """Trainer.state_dict() / save_network / load_network on the device: a resumed trainer's next (eager, injected-noise) step equals the
+    uninterrupted one's bit for bit."""
+    sd, gd, a = build(TINY, "tiny", "l1", "fp32", dev, True, lr=1e-3)
+    hr, sr, noise = (torch.from_numpy(synth_tensor("ckpt.%s" % n, (2, 3, 16, 16))).to(dev) for n in ("hr", "sr", "noise"))
+    gamma = torch.tensor([0.6, 0.3], device=dev)
+
+    def step(tr):
+        tr.loss_and_grads({"HR": hr, "SR": sr}, noise=noise, gamma=gamma)
+        tr.optimizer_step()
+    step(a); step(a)
+    a.save_network(str(tmp_path / "I2_E0"), 0, 2)
+    _, _, b = build(TINY, "tiny", "l1", "fp32", dev, True, lr=1e-3)
+    with torch.no_grad():
+        b.flat.mul_(0.5)
+    assert b.load_network(str(tmp_path / "I2_E0"), drop_stem_and_final=False, load_optimizer=True) == (0, 2)
+    step(a); step(b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v) and a.step_count == b.step_count == 3

@@ -788,3 +788,45 @@ def test_conv1x1_gemm_kernels_match_v1(dev, case):
     ops.set_use_v2(True)
     # with a residual the vector epilogue rounds the conv result to bf16 before the add (v1 adds in fp32): <= 1 bf16 ulp
     check("conv1x1_g_vs_v1%s" % (case,), "bf16", outs[1], outs[0], tol=4e-3)
+
+
+def test_split_k_scratch_outlives_the_graphs_that_point_into_it(dev):
+    """The split-K scratch buffer's address is baked into captured steps, and the size it needs is not monotonic in the batch: a later
+    launch that needs more must not free the buffer a live graph still writes to.  Capture a run at 5 latents, make the scratch
+    grow, drop every other reference, replay: same result as an uninterrupted run."""
+    import gc
+    from hsi_dmgasr_amd import ops
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    cfg = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8], attn_res=[4], res_blocks=1, image_size=32)
+    u = unet.UNet(precision="bf16", **cfg).to(dev).eval()
+    fill_synth(u, "sk_life.")
+    gd = diffusion.GaussianDiffusion(u, image_size=32, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=12, linear_start=1e-6, linear_end=1e-2), dev)
+    gd.noise, gd.seed = "philox", 77
+    cond5 = G(synth_tensor("sk_life.cond", (5, 3, 32, 32)), dev)
+    outs = []
+    for disturb in (False, True):
+        ops._sk_ws.clear()
+        run = gd.make_run(cond5)
+        with torch.no_grad():
+            for _ in range(4):
+                run.step()                                     # eager, capture, replays
+            assert run.graph is not None
+            before = ops._sk_ws.get(dev.index)
+            assert before is not None, "the 4x4 / 8x8 levels at 5 latents must take the split-K form"
+            if disturb:
+                # (on this chip the scratch never outgrows its first 32 MiB - parts x tiles x slices <= 2 x CUs workgroups of 32 KiB
+                # each - so a larger request is made directly, as a launch on a bigger device or a future kernel would)
+                grown = ops._sk_workspace(before.numel() + 1, dev)
+                assert grown is not before and ops._sk_ws[dev.index] is grown and any(b is before for b in ops._sk_retired)
+                del before
+                gc.collect()
+                torch.cuda.empty_cache()
+                junk = torch.full((grown.numel() // 8,), float("nan"), device=dev)          # would land in a freed block
+                del junk
+            for _ in range(8):
+                run.step()
+            torch.cuda.synchronize()
+        outs.append(run.x.clone())
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])

@@ -217,7 +217,7 @@ def test_two_rank_data_parallel_training_step_on_gloo(tmp_path):
     gs = []
     for rank in range(2):
         hr, sr, noise = (torch.from_numpy(synth_tensor("ddp.r%d.%s" % (rank, n), (2, 3, 16, 16))) for n in ("hr", "sr", "noise"))
-        gs.append(otrain.loss_and_grads(sd, cfg, hr, sr, noise, torch.tensor([0.7, 0.25]) - 0.1 * rank, "l1", 0.2, otrain.drop_key(9, 0)))
+        gs.append(otrain.loss_and_grads(sd, cfg, hr, sr, noise, torch.tensor([0.7, 0.25]) - 0.1 * rank, "l1", 0.2, otrain.drop_key(9, 0, rank)))
     assert abs(r0["loss"] - gs[0][0]) < 1e-4 * abs(gs[0][0]) and abs(r1["loss"] - gs[1][0]) < 1e-4 * abs(gs[1][0])
     mean = {k: 0.5 * (gs[0][1][k] + gs[1][1][k]) for k in sd}
     want = otrain.adam_steps(sd, lambda s, ps: mean, 1, lr=1e-3)
@@ -241,3 +241,115 @@ def test_two_rank_data_parallel_training_step_on_gloo(tmp_path):
         assert float((got - want[name]).norm()) < 2e-2 * moved + 1e-7, name
         checked += 1
     assert checked > 100
+
+
+def test_trainer_rejects_what_its_backward_pass_does_not_cover(monkeypatch):
+    """The constructor variants with forward kernels only (SelfAttention(n_head > 1), FeatureWiseAffine(use_affine_level=True))
+    and the fp16 inference mode must be refused by the training engine instead of producing wrong gradients."""
+    from hsi_dmgasr_amd import training
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    cpu_double.install(monkeypatch)
+
+    class CpuTrainer(training.Trainer):
+        def _check_device(self):
+            pass
+
+    def gd_of(u):
+        gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+        gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=20, linear_start=1e-6, linear_end=1e-2), "cpu")
+        return gd
+    u = unet.UNet(precision="fp32", **CFGS["tiny"])
+    u.mid[0].attn.n_head = 4
+    with pytest.raises(NotImplementedError, match="n_head"):
+        CpuTrainer(gd_of(u))
+    u = unet.UNet(precision="fp32", **CFGS["tiny"])
+    u.downs[1].res_block.noise_func.use_affine_level = True
+    with pytest.raises(NotImplementedError, match="use_affine_level"):
+        CpuTrainer(gd_of(u))
+    u = unet.UNet(precision="fp16", **CFGS["tiny"])
+    with pytest.raises(NotImplementedError, match="bf16 or the fp32"):
+        CpuTrainer(gd_of(u))
+
+
+def test_optimizer_state_round_trips_through_torch_adam_format(monkeypatch, tmp_path):
+    """Trainer.state_dict() is a torch.optim.Adam state_dict over netG.parameters() (what the reference stores in *_opt.pth,
+    model/model.py:140-143): after two steps it loads into a real torch.optim.Adam, that optimiser's own state_dict loads back,
+    and a resumed trainer continues exactly like the one that never stopped; save_network / load_network write and read the
+    reference's two files with its key-drop filter (model/model.py:187-191)."""
+    from oracle import train as otrain
+    cpu_double.install(monkeypatch)
+    hr, sr, noise = (torch.from_numpy(synth_tensor("ckpt.%s" % n, (2, 3, 16, 16))) for n in ("hr", "sr", "noise"))
+    gamma = torch.tensor([0.6, 0.3])
+    data = {"HR": hr, "SR": sr}
+
+    def step(tr):
+        tr.loss_and_grads(data, noise=noise, gamma=gamma)
+        tr.optimizer_step()
+
+    _, _, gd_a, a = build("tiny", "l1", True)
+    step(a); step(a)
+    sd = a.state_dict()
+    names = [n for n, _ in a.net.named_parameters()]
+    assert sorted(sd["state"]) == list(range(len(names))) and sd["param_groups"][0]["params"] == list(range(len(names)))
+    assert all(float(st["step"]) == 2.0 for st in sd["state"].values())
+    # ... into torch's own Adam over clones of the parameters, and back out
+    clones = [torch.nn.Parameter(p.detach().clone()) for p in a.net.parameters()]
+    opt = torch.optim.Adam(clones, lr=1e-3)
+    opt.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})
+    back = opt.state_dict()
+    for i, p in enumerate(a.net.parameters()):
+        assert torch.equal(back["state"][i]["exp_avg"], a._strided_like(p, a.m).contiguous())
+    # resume: files on disk, a fresh model, the optimiser restored -> the third step equals the uninterrupted run's
+    gen, optp = a.save_network(str(tmp_path / "I2_E0"), epoch=0, iter_step=2)
+    assert gen.endswith("_gen.pth") and optp.endswith("_opt.pth")
+    on_disk = torch.load(optp, weights_only=False)
+    assert on_disk["epoch"] == 0 and on_disk["iter"] == 2 and on_disk["scheduler"] is None
+    _, _, gd_b, b = build("tiny", "l1", True)
+    with torch.no_grad():
+        for p in b.net.parameters():
+            p.mul_(0.5)                                                          # anything but the saved weights
+    assert b.load_network(str(tmp_path / "I2_E0"), drop_stem_and_final=False, load_optimizer=True) == (0, 2)
+    assert b.step_count == 2 and b._iter == a._iter
+    step(a); step(b)
+    assert torch.allclose(a.flat, b.flat, rtol=0, atol=1e-7)
+    # the reference's shipped filter: stem weight and final conv are NOT taken from the file, the optimiser is not restored
+    _, sd0, gd_c, c = build("tiny", "l1", True)
+    stem0 = c.net.downs[0].weight.detach().clone()
+    assert c.load_network(str(tmp_path / "I2_E0")) == (0, 0)
+    assert torch.equal(c.net.downs[0].weight, stem0) and c.step_count == 0
+    assert torch.allclose(c.net.downs[1].res_block.block1.block[3].weight, a_weight_at_save(on_disk, gen), atol=0)
+
+
+def a_weight_at_save(_opt, gen_path):
+    return torch.load(gen_path)["denoise_fn.downs.1.res_block.block1.block.3.weight"]
+
+
+def test_graphed_step_captures_only_right_after_an_eager_step_of_the_same_shape(monkeypatch):
+    """The reference's DataLoader has no drop_last: full, full, partial, full, full.  A capture must directly follow an eager step
+    at the same batch shape (it sizes every workspace the captured kernels point into); here the capture itself is stubbed and
+    the sequence of eager / capture / replay decisions is what is checked."""
+    cpu_double.install(monkeypatch)
+    _, _, gd, tr = build("tiny", "l1", True)
+    log = []
+    monkeypatch.setattr(type(tr), "loss_and_grads", lambda self, data, **kw: (log.append(("eager", data["HR"].shape[0])), setattr(self, "_eager_shape", None), torch.zeros(()))[-1])
+    monkeypatch.setattr(type(tr), "optimizer_step", lambda self: None)
+
+    def fake_graph_path(self, data):                      # what _graphed_step does once it has decided NOT to run eagerly
+        log.append(("graph", data["HR"].shape[0]))
+        self._g = dict(shape=(tuple(data["HR"].shape), tuple(data["SR"].shape)))
+        return torch.zeros(())
+    orig = type(tr)._graphed_step
+
+    def wrapped(self, data):
+        shape_key = (tuple(data["HR"].shape), tuple(data["SR"].shape))
+        if self._g is not None and self._g["shape"] != shape_key:
+            self._g = None
+        if self._g is None and self._eager_shape != shape_key:
+            return orig(self, data)                       # the real decision code: eager branch
+        return fake_graph_path(self, data)
+    monkeypatch.setattr(type(tr), "_graphed_step", wrapped)
+    full = {"HR": torch.zeros(4, 3, 16, 16), "SR": torch.zeros(4, 3, 16, 16)}
+    part = {"HR": torch.zeros(1, 3, 16, 16), "SR": torch.zeros(1, 3, 16, 16)}
+    for d in (full, full, full, part, full, full):
+        tr._graphed_step(d)
+    assert log == [("eager", 4), ("graph", 4), ("graph", 4), ("eager", 1), ("eager", 4), ("graph", 4)], log
