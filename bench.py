@@ -251,7 +251,7 @@ def gae_bench(dev, patches, reps=5, bands=31, n_subs=8, n_ovls=2, groups=5, flop
         if ref_q is None:
             ref_q = q
         rec = {}
-        for name, fn in (("encode", lambda: m.encode_batched(x)), ("decode", lambda: m.decode_batched(z, 31))):
+        for name, fn in (("encode", lambda: m.encode_batched(x)), ("decode", lambda: m.decode_batched(z, bands))):
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             best = 1e30

@@ -18,8 +18,10 @@ struct GemmParams {
     int a_f32, b_f32, c_f32;
 };
 
+// element type codes of the three arrays: 0 bf16, 1 fp32, 2 fp16
 __device__ __forceinline__ float ld_elem(const void* p, int64_t i, int is_f32) {
-    return is_f32 ? reinterpret_cast<const float*>(p)[i] : (float)reinterpret_cast<const bf16*>(p)[i];
+    return is_f32 == 1 ? reinterpret_cast<const float*>(p)[i]
+                       : (is_f32 == 2 ? (float)reinterpret_cast<const f16*>(p)[i] : (float)reinterpret_cast<const bf16*>(p)[i]);
 }
 
 // C[b] (M x N, row-major, unit column stride) = alpha * A[b] (M x K) * B[b] (K x N).
@@ -56,10 +58,14 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(GemmParams p) {
     auto fetch = [&](float (&dst)[NL], const void* base, int is_f32, int64_t safe, int64_t off0, int64_t step, int lim) __attribute__((always_inline)) {
         const int64_t o = lim > 0 ? off0 : safe;
         const int last = lim > 0 ? lim - 1 : 0;
-        if (is_f32) {
+        if (is_f32 == 1) {
             const float* q = reinterpret_cast<const float*>(base) + o;
 #pragma unroll
             for (int i = 0; i < NL; ++i) dst[i] = q[(i < last ? i : last) * step];
+        } else if (is_f32 == 2) {
+            const f16* q = reinterpret_cast<const f16*>(base) + o;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) dst[i] = (float)q[(i < last ? i : last) * step];
         } else {
             const bf16* q = reinterpret_cast<const bf16*>(base) + o;
 #pragma unroll
@@ -132,7 +138,8 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(GemmParams p) {
             const float v = p.alpha * (((acc[j] + red[0][row * 33 + col]) + red[1][row * 33 + col]) + red[2][row * 33 + col]);
             if (m < p.M && n < p.N) {
                 const int64_t idx = (int64_t)bz * p.scb + (int64_t)m * p.scm + n;
-                if (p.c_f32) reinterpret_cast<float*>(p.c)[idx] = v;
+                if (p.c_f32 == 1) reinterpret_cast<float*>(p.c)[idx] = v;
+                else if (p.c_f32 == 2) reinterpret_cast<f16*>(p.c)[idx] = (f16)Elem<f16>::sat(v);
                 else reinterpret_cast<bf16*>(p.c)[idx] = (bf16)v;
             }
         }

@@ -380,7 +380,7 @@ def attention_multihead(qkv, n_head, precision):
     B, H, W, C3 = qkv.shape
     Cc, N = C3 // 3, H * W
     hd = Cc // n_head
-    f32 = qkv.dtype == torch.float32
+    f32 = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}[qkv.dtype]        # hsidm_bgemm's element type code
     es = qkv.element_size()
     out = torch.empty((B, H, W, Cc), dtype=qkv.dtype, device=qkv.device)
     P = torch.empty((B, N, N), dtype=torch.float32, device=qkv.device)

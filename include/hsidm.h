@@ -356,7 +356,7 @@ int hsidm_noise_film_bwd(const float* gamma, const float* t_emb, const float* df
                          float* db2, float* dwf, float* dbf, float* workspace, void* stream);
 /* Strided batched GEMM on the exact fp32 matrix instruction (attention backward, csrc/bgemm.hip):
  * C[i](m, n) = alpha * sum_k A[i](m, k) * B[i](k, n); A(m,k) = a[i*sab + m*sam + k*sak], B(k,n) = b[i*sbb + k*sbk + n*sbn],
- * C(m,n) = c[i*scb + m*scm + n]; *_f32: the array holds fp32 (1) or bf16 (0). */
+ * C(m,n) = c[i*scb + m*scm + n]; *_f32: the array's element type - 0 bf16, 1 fp32, 2 fp16. */
 int hsidm_bgemm(const void* a, int a_f32, int64_t sab, int64_t sam, int64_t sak, const void* b, int b_f32, int64_t sbb,
                 int64_t sbk, int64_t sbn, void* c, int c_f32, int64_t scb, int64_t scm, int M, int N, int K, int batch,
                 float alpha, void* stream);

@@ -12,7 +12,8 @@ from synth import synth_param
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # tolerances (relative Frobenius error vs the fp32 CPU oracle)
 TOL = {"fp32": 1e-3,    # north_star: 1e-3 relative for the fp32 path (measured ~1e-5)
-       "bf16": 4e-2}    # bf16 operands: gated on PSNR/SAM for whole pipelines, loose bound per op
+       "fp16": 1e-3, "fp16x1": 1.5e-3, "fp16x2": 1e-3,     # fp16 modes: per op ~3e-4 (tests/test_gpu_anchor.py holds each kernel to 6e-4)
+       "bf16": 4e-2}    # bf16 operands: a regression bound per op (measured 2e-3 ... 9e-3), not a north-star claim
 
 
 def fill_synth(module, prefix, seed=0):

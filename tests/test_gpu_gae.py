@@ -20,7 +20,12 @@ def G(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+# per-tensor bounds against the reference's outputs (relative Frobenius): fp32 mode 1e-3 (north_star; measured ~1e-5), fp16 1.5e-3
+# (11-bit significands through ~40 convolutions; its gate proper is dPSNR / dSAM below), bf16 4e-2 (a regression bound, not a claim)
+GAE_TOL = {"fp32": None, "fp16": 1.5e-3, "bf16": None}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
 @pytest.mark.parametrize("name", ["cave_synth", "chik_synth"])
 def test_gae_synthetic_golden(dev, prec, name):
     from hsi_dmgasr_amd import gae
@@ -32,33 +37,35 @@ def test_gae_synthetic_golden(dev, prec, name):
     x = G(g[name + ".x"], dev)
     z = m.encode(x)
     assert len(z) == m.G and list(g[name + ".start"]) == m.start_idx
-    check("gae_%s_encode" % name, prec, torch.stack(z), g[name + ".z"])
+    check("gae_%s_encode" % name, prec, torch.stack(z), g[name + ".z"], tol=GAE_TOL[prec])
     y = m.decode(x, [G(t, dev) for t in g[name + ".z"]])
-    check("gae_%s_decode" % name, prec, y, g[name + ".y"])
+    check("gae_%s_decode" % name, prec, y, g[name + ".y"], tol=GAE_TOL[prec])
     y2, z2 = m(x)
-    check("gae_%s_forward" % name, prec, y2, g[name + ".y"])
+    check("gae_%s_forward" % name, prec, y2, g[name + ".y"], tol=GAE_TOL[prec])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
 def test_gae_pretrained_cave_psnr_sam(dev, prec):
     """BASELINE configs[0] on the GPU: pretrained CAVE autoencoder, one 31x64x64 patch; PSNR within 0.01 dB and
-    SAM within 0.001 (deg) of the reference's reconstruction for the fp32 path."""
+    SAM within 0.001 (deg) of the reference's reconstruction for the fp32 AND the fp16 mode (north_star's bounds); the bf16 mode
+    measures 0.08 dB / 0.011 deg and is NOT a mode the pipeline uses for the autoencoder (gae.GAE defaults to fp32; bench.py's
+    gae object reports each 16-bit mode's deviation next to its time)."""
     from hsi_dmgasr_amd import gae
     g = load_npz("gae.npz")
     m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision=prec).to(dev).eval()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in load_npz("gae_cav_state.npz").items()})
     x = G(g["cave_real.x"], dev)
     y, z = m(x)
-    check("gae_cave_real_z", prec, torch.stack(z), g["cave_real.z"])
-    check("gae_cave_real_y", prec, y, g["cave_real.y"])
+    check("gae_cave_real_z", prec, torch.stack(z), g["cave_real.z"], tol=GAE_TOL[prec])
+    check("gae_cave_real_y", prec, y, g["cave_real.y"], tol=GAE_TOL[prec])
     a = np.clip(g["cave_real.x"][0].transpose(1, 2, 0), 0, 1)
     ref = np.clip(g["cave_real.y"][0].transpose(1, 2, 0), 0, 1)
     got = np.clip(y.cpu().numpy()[0].transpose(1, 2, 0), 0, 1)
     dpsnr = abs(metrics.mpsnr(a, got) - metrics.mpsnr(a, ref))
     dsam = abs(metrics.sam_degrees(a, got) - metrics.sam_degrees(a, ref))
     log_err("gae_cave_real_dPSNR_dB", prec, dpsnr, {"psnr": metrics.mpsnr(a, got), "dsam_deg": dsam})
-    if prec == "fp32":
-        assert dpsnr < 0.01 and dsam < 0.001, (dpsnr, dsam)
+    if prec in ("fp32", "fp16"):
+        assert dpsnr < 0.01 and dsam < 0.001, (prec, dpsnr, dsam)
     else:
         assert dpsnr < 0.5 and dsam < 0.05, (dpsnr, dsam)
 
