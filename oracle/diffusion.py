@@ -124,6 +124,20 @@ def p_sample_loop(denoise, sched, cond, x_T, noise_fn, continous=False):
     return ret if continous else ret[-1]
 
 
+def p_sample_loop_unconditional(denoise, sched, x_T, noise_fn, continous=False):
+    """p_sample_loop diffusion.py:177-189, the `not self.conditional` branch (what sample() :203-207 runs): the network sees
+    x_t alone and ret_img starts with x_T itself."""
+    T = sched["num_timesteps"]
+    inter = 1 | (T // 10)
+    img = x_T
+    ret = img
+    for i in reversed(range(T)):
+        img = p_sample_step(denoise, sched, img, None, i, noise_fn(i) if i > 0 else None)
+        if i % inter == 0:
+            ret = torch.cat([ret, img], dim=0)
+    return ret if continous else ret[-1]
+
+
 def philox_noise_fn(seed, shape):
     """Noise source mirroring the device sampler's counter-based generator:
     stream index = loop index i for the per-step noise, T for x_T."""

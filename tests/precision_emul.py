@@ -75,13 +75,15 @@ class Mode:
         self.t = parts[0]
         kv = dict(p.split("=") for p in parts[1].split(",")) if len(parts) > 1 else {}
         self.lvl = {}
-        self.cout_max = None
+        self.cout_max = self.cin_max = None
         for k in ("w", "st", "op"):
             v = kv.get(k, "")
             if "@" in v:
                 v, lv = v.split("@")
                 if lv.startswith("c"):                      # w=x2@c128: layers with at most 128 output channels (the product's rule)
-                    self.cout_max = int(lv[1:])
+                    cc = lv[1:].split("i")                  # w=x2@c128i128: ... and at most 128 input channels
+                    self.cout_max = int(cc[0])
+                    self.cin_max = int(cc[1]) if len(cc) > 1 else None
                 else:
                     self.lvl[k] = [int(u) for u in lv.split("+")]
             setattr(self, k, v)
@@ -115,7 +117,7 @@ class Mode:
     def weight(self, w, hw):
         if self.wl is not None:
             return split2(w, self.t) if any(self.cur.startswith(q) for q in self.wl) else rnd(w, self.t)
-        if self.cout_max is not None and w.shape[0] > self.cout_max:
+        if self.cout_max is not None and (w.shape[0] > self.cout_max or (self.cin_max is not None and w.shape[1] > self.cin_max)):
             return rnd(w, self.t)
         if self.w == "fp32" and self._ovr("w", hw):
             return w

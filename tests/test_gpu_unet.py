@@ -830,3 +830,32 @@ def test_split_k_scratch_outlives_the_graphs_that_point_into_it(dev):
             torch.cuda.synchronize()
         outs.append(run.x.clone())
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_unconditional_sample_matches_oracle(dev, prec):
+    """GaussianDiffusion(conditional=False).sample() (reference diffusion.py:182-189, 203-207): the UNet sees x_t alone (in_channel = 3),
+    ret_img starts with x_T; Philox noise, continous frames and the ret_img[-1] convention against the oracle's restatement."""
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import diffusion as odiff, sr3_unet
+    cfg = dict(in_channel=3, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1, image_size=16)
+    u = unet.UNet(precision=prec, **cfg).to(dev).eval()
+    sd = fill_synth(u, "unet_uncond.")
+    opt = dict(schedule="linear", n_timestep=12, linear_start=1e-4, linear_end=2e-2)
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=False)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(opt, dev)
+    gd.noise, gd.seed = "philox", 4242
+    B = 3
+    frames = gd.sample(batch_size=B, continous=True)
+    last = gd.sample(batch_size=B, continous=False)
+    torch.cuda.synchronize()
+    sched = odiff.noise_schedule(opt)
+    den = lambda x, gam: sr3_unet.unet_forward(sd, cfg, x, gam)
+    nf = odiff.philox_noise_fn(4242, (B, 3, 16, 16))
+    with torch.no_grad():
+        want = odiff.p_sample_loop_unconditional(den, sched, nf(12), nf, continous=True)
+    assert frames.shape == want.shape == ((1 + 12) * B, 3, 16, 16)          # inter = 1 | (12 // 10) = 1: x_T and every step
+    tol = {"fp32": 2e-3, "fp16": 6e-3}[prec]
+    check("uncond_sample_frames", prec, frames, want, tol=tol)
+    check("uncond_sample_last", prec, last, want[-1], tol=tol)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libhsidm.so does not export %s" % name
     assert declared - {"hsidm_error_string"} == set(_lib.SIGNATURES), "ctypes table out of sync with hsidm.h"
     assert _lib.lib().hsidm_version() == 1
-    assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32
+    assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32 and _lib.lib().hsidm_conv_bk(_lib.F16) == 64
     assert b"invalid" in _lib.lib().hsidm_error_string(-1)
 
 
@@ -39,7 +39,27 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     assert rows[1] == [P.src0.offset, P.src1.offset, P.gn_ab.offset, P.C0.offset, P.C1.offset, P.transform.offset, P.ntaps.offset]
     assert rows[2] == [D.nphase.offset, D.w_hi.offset, D.w_lo.offset, D.bias.offset, D.film.offset, D.film_stride.offset,
                        D.res.offset, D.res_scale.offset, D.out.offset, D.stats.offset, D.B.offset, D.ksize.offset,
-                       D.prec.offset, D.bn.offset, D.workspace.offset, D.workspace_bytes.offset]
+                       D.prec.offset, D.bn.offset, D.workspace.offset, D.workspace_bytes.offset, D.w_v2_lo.offset]
+
+
+def test_clean_tree_build_produces_a_loadable_library(tmp_path):
+    """Every source of the library compiled from scratch (no object of the in-tree build is reused) for gfx950, linked, loaded: a
+    prebuilt libhsidm.so can never mask a source file that no longer compiles.  The library and its objects go to a temporary
+    directory (csrc/build.sh honours HSIDM_OUT / HSIDM_OBJ), the in-tree binary is not touched."""
+    import torch  # noqa: F401  (libamdhip64 comes from torch's copy, as in _lib.py)
+    from hsi_dmgasr_amd import _lib
+    out = tmp_path / "libhsidm_clean.so"
+    env = dict(os.environ, HSIDM_OUT=str(out), HSIDM_OBJ=str(tmp_path / "obj"), JOBS=str(min(8, os.cpu_count() or 1)))
+    r = subprocess.run(["bash", os.path.join(ROOT, "hsi-dmgasr_amd", "csrc", "build.sh")], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    srcs = [f for f in os.listdir(os.path.join(ROOT, "hsi-dmgasr_amd", "csrc")) if f.endswith(".hip")]
+    assert sorted(f[:-4] + ".o" for f in srcs) == sorted(os.listdir(tmp_path / "obj"))     # one fresh object per source, nothing else
+    L = ctypes.CDLL(str(out))
+    L.hsidm_version.restype = ctypes.c_int
+    assert L.hsidm_version() == 1
+    for name in _lib.SIGNATURES:
+        assert hasattr(L, name), "the clean build does not export %s" % name
+    assert L.hsidm_conv_bk(_lib.F16) == 64
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
