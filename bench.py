@@ -68,7 +68,7 @@ def build_model(dev, precision):
     return gd
 
 
-def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1):
+def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1, mode=None):
     """Roofline of the DOMINANT kernel of one step.  Every conv launch of one eager step is bracketed with HIP events
     on the launch stream (best of `reps`); launches are grouped by the kernel the C ABI dispatches to
     (hsidm_conv_kernel_id) and the group with the largest total time is reported:
@@ -97,9 +97,12 @@ def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1):
     all_fl = sum(g["flops"] for g in groups.values())
     top = max((r for r in best if r["kernel"] == name), key=lambda r: r["flops"] / r["ms"])
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/README.md
+    # PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of the same command, one file per precision mode (profiles/README.md)
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % mode) if mode else os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
-        traffic = json.load(open(tf)).get(name)
+        tab = json.load(open(tf))
+        # (the LDS-tiled kernel takes its transform at run time: its counters are keyed by geometry only)
+        traffic = tab.get(name) or tab.get(name.replace(" gn+silu", "").replace(" gn", ""))
         if traffic is not None and traffic.get("batch_per_gpu") not in (None, batch):
             traffic = None                                      # counters were collected at another batch: not this run's traffic
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12       # algorithmic FLOPs (the fp32 mode issues `passes` MFMAs per product)
@@ -525,7 +528,7 @@ def main():
 
         roof = None
         if rank == 0 and not args.no_roofline:
-            roof = conv_roofline(run, batch)
+            roof = conv_roofline(run, batch, mode=args.precision)
             # (fp16 mode: launches with hi + lo weights issue two MFMAs per product; `achieved` counts the algorithmic FLOPs once)
             roof["mfma_passes_per_product"] = "2 on the Cout<=128 layers, 1 elsewhere" if args.precision == "fp16" else (2 if args.precision == "fp16x2" else 1)
     log('roofline done')
@@ -544,7 +547,7 @@ def main():
             d = time.perf_counter() - t0
             assert torch.isfinite(r.x).all()
             rec = dict(value=n * batch / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n, dtype=DTYPE[prec],
-                       roofline=None if args.no_roofline else conv_roofline(r, batch, reps=2, passes=passes))
+                       roofline=None if args.no_roofline else conv_roofline(r, batch, reps=2, passes=passes, mode=prec))
             del r
         torch.cuda.empty_cache()
         return rec

@@ -26,6 +26,10 @@ def label(name):
     if m:
         bn, xf, im = map(int, m.groups())
         return "conv1x1_g bn%d 8x16 k%d s1%s" % (bn, 3 if im else 1, " gn" if xf == 1 else "")
+    m = re.search(r"conv_igemm_kernelINS_7ConvCfgI(?:f|DF16b|DF16_)Lb[01]ELi(\d+)ELi\d+ELi8ELi(\d+)ELi(\d)ELi(\d)ELi(\d)ELb([01])", name)
+    if m:       # the LDS-tiled kernel takes its input transform at run time: one label per geometry (bench.py strips the suffix)
+        bn, tw, ni, ks, st, nchw = map(int, m.groups())
+        return "conv_igemm bn%d %s k%d s%d%s" % (bn, "8x8x2" if ni == 2 else "8x16", ks, st, " nchw" if nchw else "")
     if "conv_v3_kernel" in name:
         nchw = "<1, true>" in name or "ILi1ELb1E" in name
         return "conv_v3 bn32 8x16 k3 s1 gn+silu nchw" if nchw else "conv_v3 bn64 8x16 k3 s1 gn+silu"
