@@ -4,8 +4,10 @@
 // Both operands are NHWC (channels contiguous), i.e. the contraction index is the strided one for both.  bf16 mode: a pixel tile
 // of dY and the halo tile of A are staged row-major in LDS ([pixel][64 channels], 192-byte rows) and BOTH MFMA operands are
 // fetched with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major: conflict-free at this
-// pitch), so no transposed copy of either tensor is ever written.  fp32 mode: the same tiles in fp32 and the exact fp32 matrix
-// instruction v_mfma_f32_32x32x2_f32, whose operands are one element per lane.
+// pitch), so no transposed copy of either tensor is ever written.  fp32 mode: the fp32 tensors are split into bf16 hi + lo while
+// they are staged (four LDS tiles of the bf16 kind) and every product is three MFMAs, hi*hi + hi*lo + lo*hi - the forward
+// kernels' fp32 mode (conv_igemm.h), ~2^-17 relative per product.  (Round 2 used the exact fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 here: one element per lane at 1/16 of the bf16 rate, 18 of the fp32-mode step's 28 ms.)
 // Work decomposition: workgroup = (64 couts x 64 cins x all taps) x a contiguous range of pixel tiles (split K); a wave owns a
 // 32 x 32 corner for all taps (9 accumulator tiles); partial sums go to a workspace [split][tap][cout][cin] with plain stores and
 // a second kernel adds the splits in order into the PyTorch layout [cout][cin][ky][kx]: deterministic, no atomics.
@@ -38,22 +40,25 @@ struct WgCfg {
     static constexpr bool F32 = std::is_same<T, float>::value;
     static constexpr int EPV = F32 ? 4 : 8;                  // elements per 16-byte vector
     static constexpr int VPP = 64 / EPV;                     // vectors per pixel (64 channels)
-    static constexpr int PITCH = F32 ? 68 : 96;              // elements per LDS pixel row
+    static constexpr int PITCH = 96;                         // bf16 elements per LDS pixel row (fp32 mode: hi and lo tiles of this kind)
+    static constexpr int NPART = F32 ? 2 : 1;
     static constexpr int NPIX = TH * TW;
     static constexpr int HH = NT == 1 ? TH : (MODE == 2 ? 2 * TH + 1 : TH + 2);
     static constexpr int HWD = NT == 1 ? TW : (MODE == 2 ? 2 * TW + 1 : TW + 2);
     static constexpr int NHALO = HH * HWD;
     static constexpr int NV_D = (NPIX * VPP + 255) / 256;
     static constexpr int NV_A = (NHALO * VPP + 255) / 256;
-    static constexpr size_t LDS_BYTES = (size_t)(NPIX + NHALO) * PITCH * sizeof(T);
+    static constexpr size_t LDS_BYTES = (size_t)NPART * (NPIX + NHALO) * PITCH * 2;
 };
 
 template <typename T, int TH, int TW, int NT, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     using C = WgCfg<T, TH, TW, NT, MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* ld = reinterpret_cast<T*>(smem_raw);                  // dY tile  [NPIX][PITCH]
-    T* la = ld + C::NPIX * C::PITCH;                         // A halo   [NHALO][PITCH]
+    bf16* ld = reinterpret_cast<bf16*>(smem_raw);            // dY tile  [NPIX][PITCH]   (fp32 mode: high halves)
+    bf16* la = ld + C::NPIX * C::PITCH;                      // A halo   [NHALO][PITCH]
+    bf16* ld_lo = la + C::NHALO * C::PITCH;                  // fp32 mode: the low halves of both tiles
+    bf16* la_lo = ld_lo + C::NPIX * C::PITCH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -125,16 +130,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             ra[i] = val;
         }
     };
+    // fp32 mode: four fp32 values -> four bf16 high halves + four bf16 low halves (x - bf16(x)), 8 bytes each
+    auto split_store = [&](bf16* hi, bf16* lo, int off, const u32x4& raw) __attribute__((always_inline)) {
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = __uint_as_float(raw[k]);
+            h4[k] = (bf16)x;
+            l4[k] = (bf16)(x - (float)h4[k]);
+        }
+        *reinterpret_cast<bf16x4*>(hi + off) = h4;
+        *reinterpret_cast<bf16x4*>(lo + off) = l4;
+    };
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::NV_D; ++i) {
             const int v = tid + i * 256;
-            if (v < C::NPIX * C::VPP) *reinterpret_cast<u32x4*>(ld + (v / C::VPP) * C::PITCH + (v % C::VPP) * C::EPV) = rd[i];
+            if (v < C::NPIX * C::VPP) {
+                const int off = (v / C::VPP) * C::PITCH + (v % C::VPP) * C::EPV;
+                if constexpr (C::F32) split_store(ld, ld_lo, off, rd[i]);
+                else *reinterpret_cast<u32x4*>(ld + off) = rd[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < C::NV_A; ++i) {
             const int v = tid + i * 256;
-            if (v < C::NHALO * C::VPP) *reinterpret_cast<u32x4*>(la + (v / C::VPP) * C::PITCH + (v % C::VPP) * C::EPV) = ra[i];
+            if (v < C::NHALO * C::VPP) {
+                const int off = (v / C::VPP) * C::PITCH + (v % C::VPP) * C::EPV;
+                if constexpr (C::F32) split_store(la, la_lo, off, ra[i]);
+                else *reinterpret_cast<u32x4*>(la + off) = ra[i];
+            }
         }
     };
 
@@ -153,53 +178,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 cur_b = b_step;
             }
         }
-        if constexpr (!C::F32) {
+        {
             // k index of an MFMA k-group (16 pixels): k = 8h + j  <->  pixel (row kg, x = 8h + j) for TW = 16,
             //                                                        pixel (row 2kg + h, x = j) for TW = 8
             const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
             const int py = TW == 16 ? 0 : h, px = (TW == 16 ? 8 * h : 0) + q;      // this lane's address duty, relative to the k-group
             const int coff = 16 * g1 + 4 * pq;
-            const T* abase = ld + (py * TW + px) * C::PITCH + 32 * wm + coff;
+            const int aoff = (py * TW + px) * C::PITCH + 32 * wm + coff;
             const int sp = MODE == 2 ? 2 : 1;
-            const T* bbase = la + (sp * py * C::HWD + sp * px) * C::PITCH + 32 * wn + coff;
+            const int boff = (sp * py * C::HWD + sp * px) * C::PITCH + 32 * wn + coff;
             constexpr int NKG = C::NPIX / 16, RPG = TW == 16 ? 1 : 2;              // k-groups per tile, tile rows per k-group
             typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+            auto frag = [&](const bf16* p0, int second) __attribute__((always_inline)) -> bf16x8 {
+                const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + second));
+                const s16x8 f = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                return __builtin_bit_cast(bf16x8, f);
+            };
+            const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};      // bf16 1.0
+            const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
-                const T* ap = abase + kg * RPG * TW * C::PITCH;
-                const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap));
-                const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + 4 * C::PITCH));
-                const s16x8 af = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                const int ao = aoff + kg * RPG * TW * C::PITCH;
+                const bf16x8 af = frag(ld + ao, 4 * C::PITCH);
+                bf16x8 af_lo = af;
+                if constexpr (C::F32) af_lo = frag(ld_lo + ao, 4 * C::PITCH);
                 if (do_bias) {
-                    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};      // bf16 1.0
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
+                    if constexpr (C::F32) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_lo, ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int ky = NT == 1 ? 0 : t / 3, kx = NT == 1 ? 0 : t % 3;
-                    const T* bp = bbase + ((sp * kg * RPG + ky) * C::HWD + kx) * C::PITCH;
-                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bp));
-                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bp + 4 * sp * C::PITCH));
-                    const s16x8 bf = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
-                }
-            }
-        } else {
-            // exact fp32: one element per lane, k = lane >> 5 -> two consecutive pixels of a tile row per instruction
-            const int h = lane >> 5, r = lane & 31;
-            const int sp = MODE == 2 ? 2 : 1;
-#pragma unroll 4
-            for (int pp = 0; pp < C::NPIX / 2; ++pp) {
-                const int pix = 2 * pp + h;
-                const int y = pix / TW, x = pix % TW;
-                const float av = ld[pix * C::PITCH + 32 * wm + r];
-                const T* brow = la + (sp * y * C::HWD + sp * x) * C::PITCH + 32 * wn + r;
-                if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, 1.0f, accb, 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int ky = NT == 1 ? 0 : t / 3, kx = NT == 1 ? 0 : t % 3;
-                    const float bv = brow[(ky * C::HWD + kx) * C::PITCH];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    const int bo = boff + ((sp * kg * RPG + ky) * C::HWD + kx) * C::PITCH;
+                    const bf16x8 bf = frag(la + bo, 4 * sp * C::PITCH);
+                    if constexpr (C::F32) {                   // small terms first
+                        const bf16x8 bf_lo = frag(la_lo + bo, 4 * sp * C::PITCH);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_lo, bf, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf_lo, acc[t], 0, 0, 0);
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
                 }
             }
         }

@@ -253,3 +253,33 @@ def test_color_correction_on_device(dev):
             assert np.abs(got[1].flip(0).cpu().numpy() - want).max() < 2e-6       # cubes of a batch are independent
     with pytest.raises(IndexError):
         metrics.color_correction(tt, pp, 99)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_chikusei_full_size_cube_against_the_oracle(dev, prec):
+    """BASELINE configs[2] at its real size: one 128-band 128 x 128 cube, n_subs 16 / n_ovls 4 -> G = 11 spectral groups (AE.py:263-280,
+    SURVEY Appendix B; synthetic weights keyed by name - GAE_4_Chi.pth has this architecture): latents and reconstruction against the
+    oracle on the host, and the two quality indices of the reconstruction within north_star's bounds of the oracle's."""
+    from hsi_dmgasr_amd import gae
+    from helpers import synth_sd, synth_tensor
+    from oracle import gae as ogae
+    ns, no, nc, hw = 16, 4, 128, 128
+    m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=ns, n_ovls=no, n_colors=nc, n_feats=64, precision=prec).to(dev).eval()
+    sd = fill_synth(m, "gae_chik_full.")
+    assert m.G == 11 and m.start_idx[-1] == nc - ns
+    x = np.abs(synth_tensor("gae_chik_full.x", (1, nc + 2, hw, hw), scale=0.35)).clip(0, 1)
+    x = ((x[:, :-2] + x[:, 1:-1] + x[:, 2:]) / 3.0).astype(np.float32)                # smooth spectra (SURVEY 8d)
+    y, z = m(G(x, dev))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want_y, want_z = ogae.gae_forward(sd, torch.from_numpy(x), ns, no)
+    tol = {"fp32": 1e-3, "fp16": 1.5e-3}[prec]
+    check("gae_chikusei_128_z", prec, torch.stack(z), torch.stack(want_z), tol=tol)
+    check("gae_chikusei_128_y", prec, y, want_y, tol=tol)
+    a = x[0].transpose(1, 2, 0)
+    ref = np.clip(want_y.numpy()[0].transpose(1, 2, 0), 0, 1)
+    got = np.clip(y.cpu().numpy()[0].transpose(1, 2, 0), 0, 1)
+    dpsnr = abs(metrics.mpsnr(a, got) - metrics.mpsnr(a, ref))
+    dsam = abs(metrics.sam_degrees(a, got) - metrics.sam_degrees(a, ref))
+    log_err("gae_chikusei_128_dPSNR_dB", prec, dpsnr, {"dsam_deg": dsam, "psnr": metrics.mpsnr(a, got)})
+    assert dpsnr < 0.01 and dsam < 0.001, (prec, dpsnr, dsam)
