@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--batch", type=int, default=40)
     ap.add_argument("--only", default=None)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--sustain", type=float, default=0.0, help="after the timed repetitions keep launching the shape back to back for this many "
+                                                               "seconds and report the sustained time per launch (power / clock A/B: tools/power_ab.sh)")
     ap.add_argument("--v1", action="store_true", help="force the v1 kernel (A/B against conv_v2)")
     ap.add_argument("--no-xf", action="store_true", help="3x3 convs without the GroupNorm+SiLU input transform (cost of the fused prologue)")
     ap.add_argument("--no-fold", action="store_true", help="upsample convs with HSIDM_UPS_ADDRESS instead of the parity-folded kernels")
@@ -57,7 +59,8 @@ def main():
     dev = torch.device("cuda:0")
     ops.set_use_v2(not args.v1)
     prec = args.precision
-    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    from hsi_dmgasr_amd import _lib
+    dt = _lib.act_dtype(prec)
     g = torch.Generator(device="cpu").manual_seed(0)
     B = args.batch
     for name, H, C0, C1, Co, ks, st, up, pj in SHAPES:
@@ -83,6 +86,16 @@ def main():
         Ho = y.shape[1]
         flops = 2.0 * B * Ho * Ho * Co * ((C0 + C1) * ks * ks + pj)
         print("%-22s %9.1f us %8.1f TFLOP/s (reference FLOP count)" % (name, best * 1e3, flops / (best * 1e-3) / 1e12), flush=True)
+        if args.sustain > 0:
+            import time
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < args.sustain:
+                for _ in range(50):
+                    ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=xf, stride=st, ups=bool(up), proj_x0=px)
+                torch.cuda.synchronize()
+                n += 50
+            dt_s = time.perf_counter() - t0
+            print("%-22s sustained %9.1f us per launch over %.1f s = %8.1f TFLOP/s" % (name, dt_s / n * 1e6, dt_s, flops * n / dt_s / 1e12), flush=True)
         del x0, x1, px, y, pk
 
 
