@@ -113,7 +113,7 @@ class PackedConv:
         self.w_lo = (w - self.w_hi.float()).to(et).contiguous() if self.prec != _lib.BF16 else None
         self.bias = None if b is None else b.to(dev).contiguous()
         # fp16 mode: does this layer multiply by hi + lo weights on the persistent kernels too (precision.wide_weights)?
-        self.wide = self.prec == _lib.F16 and wide_weights(precision, self.cout)
+        self.wide = self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)
         for name in ("w_v2", "w_up4", "w_dn4"):
             t = lay[name]
             hi = None if t is None else t.to(et).contiguous()

@@ -42,6 +42,9 @@ def is_16bit(p):
     return p != "fp32"
 
 
-def wide_weights(p, cout):
-    """Does a convolution with `cout` output channels carry hi + lo weights in mode p (second MFMA pass)?"""
+def wide_weights(p, cout, cin=0, ksize=3):
+    """Does a convolution (cout x cin x ksize x ksize) carry hi + lo weights in mode p (second MFMA pass)?"""
+    exp = os.environ.get("HSIDM_WIDE_POLICY")          # diagnostic: a Python expression over cout, cin, ksize (policy experiments)
+    if exp and p == "fp16":
+        return bool(eval(exp, {"cout": cout, "cin": cin, "ksize": ksize}))
     return p == "fp16x2" or (p == "fp16" and cout <= 128)

@@ -1,15 +1,16 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of profiles/ on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh TAG      -> gpurun_out/TAG/{bench.json,kernel_stats.csv,fetch.csv,write.csv,hbm_traffic.json}
+# (bench.py's default mode - fp16 since round 3; copy hbm_traffic.json to profiles/hbm_traffic_fp16.json, which bench.py reads)
 tag=${1:-final}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-fp32 --no-gae --no-train --no-small > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-modes --no-parity --no-gae --no-train --no-small > $out/stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  HSIDM_NO_GRAPH=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-fp32 --no-gae --no-train --no-small > $out/pmc_$c.log 2>&1
+  HSIDM_NO_GRAPH=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-modes --no-parity --no-gae --no-train --no-small > $out/pmc_$c.log 2>&1
 done
 cp $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $out/fetch.csv
 cp $(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $out/write.csv
