@@ -22,6 +22,7 @@ HSIDM_DECL(conv_run_f16_k3s1nchw)
 int conv_v2_run_bf16(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_run_f16(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_run_f16w(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
+int conv_v2_run_f32x3(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 int conv_v2_slots();
 int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, hipStream_t s);
@@ -56,6 +57,9 @@ extern "C" int hsidm_conv_bk(int prec) { return (prec == HSIDM_BF16 || prec == H
 
 // the 16-bit throughput modes share every kernel (templates over the element type, common.h: Elem)
 static inline bool is16(int prec) { return prec == HSIDM_BF16 || prec == HSIDM_F16; }
+// ... and the persistent 3x3 kernel also has an fp32 form (fp32 storage, bf16 hi + lo operands: conv_v2.h, AP = 2), taken when the
+// descriptor carries both halves of the weights in the register-streaming order
+static inline bool v2_mode(const hsidm_conv_desc* d) { return is16(d->prec) || (d->prec == HSIDM_F32X3 && d->w_v2 && d->w_v2_lo); }
 
 enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 
@@ -123,7 +127,7 @@ static bool force_v1_1x1() { return debug_get(DBG_1X1_V1) == 1; }
 static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
     if (!d) return HSIDM_E_BADARG;
     if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3 && d->prec != HSIDM_F16) return HSIDM_E_BADARG;
-    if (d->w_v2_lo && (d->prec != HSIDM_F16 || !d->w_v2)) return HSIDM_E_BADARG;
+    if (d->w_v2_lo && (d->prec == HSIDM_BF16 || !d->w_v2)) return HSIDM_E_BADARG;
     if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
     if (d->ksize != 3 && d->ksize != 1) return HSIDM_E_BADARG;
     if (d->stride != 1 && d->stride != 2) return HSIDM_E_BADARG;
@@ -145,11 +149,11 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     const int xf = d->ph[0].transform;
     path = PATH_V1;
     if (up4) {
-        if (!is16(d->prec) || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || xf != HSIDM_XF_NONE ||
+        if (!v2_mode(d) || !d->w_v2 || d->out_nchw || d->nphase != 1 || d->ksize != 3 || xf != HSIDM_XF_NONE ||
             d->bn != 128) return HSIDM_E_UNSUPPORTED;
     }
     // stride 2 with w_v2: the four input-parity planes on the conv_v2 schedule (w_v2 = [plane][chunk][2x2 taps] layout)
-    if (is16(d->prec) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 2) {
+    if (v2_mode(d) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 2) {
         if (d->ksize != 3 || xf != HSIDM_XF_NONE || (d->bn != 64 && d->bn != 128) || (d->Hin & 1) || (d->Win & 1)) return HSIDM_E_UNSUPPORTED;
         path = PATH_V2;
     }
@@ -157,18 +161,19 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     if (is16(d->prec) && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
         xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 32 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
         !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
-    if (is16(d->prec) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
+    if (v2_mode(d) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
+        else if (!is16(d->prec)) return HSIDM_E_UNSUPPORTED;     // the fp32 form exists for the 3x3 kernel only: no w_v2 otherwise
         // 8x8 maps: two-image tiles halve the work items; when those would leave half of the co-resident workgroup slots
         // empty, one-image 64-pixel tiles keep two workgroups on every CU at the same staging cost per pixel
         if (path == PATH_V2 && tile_kind == 1 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 128 && Hout <= 8 && Wout <= 8 &&
             (long long)d->B * ((d->Cout + 127) / 128) <= conv_v2_slots()) tile_kind = 2;
         // 64-cout GN+SiLU layers on whole 16x16 tiles: the 256-pixel kernel (conv_v3.hip); HSIDM_NO_V3=1: diagnostic A/B switch
-        if (path == PATH_V2 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 64 && d->Cout == 64 && Hout % 16 == 0 &&
+        if (path == PATH_V2 && is16(d->prec) && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 64 && d->Cout == 64 && Hout % 16 == 0 &&
             Wout % 16 == 0 && !debug_get(DBG_NO_V3)) path = PATH_V3;
         // 8 input channels (one 16-byte vector per pixel): w_v2 is the tap-major GEMM layout (include/hsidm.h), which only
         // the GEMM kernel reads
-        if (d->ksize == 3 && d->ph[0].C0 + d->ph[0].C1 == 8) {
+        if (is16(d->prec) && d->ksize == 3 && d->ph[0].C0 + d->ph[0].C1 == 8) {
             const bool g1 = !d->ups && xf == HSIDM_XF_NONE && d->act == HSIDM_ACT_NONE && !d->film && d->ph[0].C1 == 0 &&
                             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 &&
                             (Wout & (Wout - 1)) == 0 && Hout * Wout >= 128;
@@ -176,7 +181,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
             path = PATH_G1;
         }
         // LDS-staged GEMM (conv1x1_g.hip): whole cout slices, 64-pixel statistics groups
-        if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
+        if (is16(d->prec) && d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
     }
     if ((path == PATH_V2 || d->nphase == 2) && d->workspace) {
@@ -259,9 +264,9 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     if (rc != HSIDM_OK) return rc;
     const bool use_v2 = path == PATH_V2 || path == PATH_V3;
     if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
-    if (d->prec == HSIDM_F32X3 && !d->w_lo) return HSIDM_E_BADARG;
+    if (d->prec == HSIDM_F32X3 && !use_v2 && !d->w_lo) return HSIDM_E_BADARG;      // (the persistent form reads w_v2 / w_v2_lo)
     const int elem = d->prec == HSIDM_F16 ? 1 : 0;
-    const int bk = hsidm_conv_bk(d->prec);
+    const int bk = use_v2 ? 64 : hsidm_conv_bk(d->prec);        // (the persistent kernels walk 64-channel chunks in every mode)
     ConvParams p;
     p.nphase = d->nphase;
     int steps = 0;
@@ -315,6 +320,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.w_lo = reinterpret_cast<const bf16*>(d->w_v2_lo);
         const int np = d->w_v2_lo ? 2 : 1;
         auto v2_run = [&](int tk, int bn_, int xf_) {
+            if (d->prec == HSIDM_F32X3) return conv_v2_run_f32x3(tk, bn_, xf_, v, s);
             if (!elem) return conv_v2_run_bf16(tk, bn_, xf_, v, s);
             return np == 2 ? conv_v2_run_f16w(tk, bn_, xf_, v, s) : conv_v2_run_f16(tk, bn_, xf_, v, s);
         };

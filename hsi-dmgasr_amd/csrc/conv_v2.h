@@ -71,11 +71,20 @@ struct ConvV2Params {
 // transform, not by the matrix pipe (the 64- and 128-cout layers of the two high-resolution levels), where it removes the one
 // SYSTEMATIC error of a 16-bit mode (the same weight rounding in every step of the chain).  The weight ring
 // is then fragment-granular (6 pairs, five k-slices ahead) instead of three K steps deep: the same registers.
-template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4, typename E_ = bf16, int NP_ = 1>
+//
+// S_ = float, AP_ = 2 (with E_ = bf16, NP_ = 2): the fp32 mode on this kernel.  Activations are stored in fp32 (two 16-byte vectors per
+// staged pixel-vector, fp32 GroupNorm pairs, a 4-byte epilogue patch, fp32 stores); every staged value is split into bf16 hi + lo
+// into TWO halo tiles per buffer and every product is three MFMAs, lo*hi + hi*lo + hi*hi (conv_igemm.h's arithmetic, ~2^-17 per
+// product).  Four halo tiles are 113 KB: one workgroup per CU, up to 512 registers per wave.
+template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4, typename E_ = bf16, int NP_ = 1, typename S_ = E_, int AP_ = 1>
 struct V2Cfg {
     using E = E_;
-    static constexpr int NP = NP_;
+    using S = S_;                                               // storage type of activations in HBM
+    static constexpr int NP = NP_, AP = AP_;
+    static constexpr bool F32 = sizeof(S_) == 4;
+    static constexpr int SV = F32 ? 2 : 1;                      // 16-byte vectors per staged 8-channel pixel-vector
     static_assert(NP_ == 1 || NP_ == 2, "weight passes");
+    static_assert(AP_ == 1 || (AP_ == 2 && NP_ == 2 && F32), "split activations come with split weights and fp32 storage");
     static constexpr int BN = BN_, TH = TH_, TW = TW_, NI = NI_, XF = XF_;
     // NW = 8: 512 threads, one workgroup per CU, 256 couts per item - the eight waves share one staged (transformed) halo tile,
     // so the GroupNorm+SiLU transform is paid once per 256 couts instead of once per 128
@@ -107,7 +116,14 @@ struct V2Cfg {
     // two halo buffers + the per-thread table of halo positions (MAXHV packed ints per thread, see describe)
     static constexpr size_t POS_BYTES = (size_t)MAXHV * NTHR * 4;
     // NW = 8: the epilogue's transposition patches (8 x 5 KiB) do not fit the free halo buffer: a region of their own
-    static constexpr size_t LDS_BYTES = (size_t)2 * HALO_ELEMS * 2 + POS_BYTES + (NW == 8 ? (size_t)NW * 64 * 40 * 2 : 0);
+    static_assert(!(AP_ == 2 && NW_ == 8), "the 8-wave form has no room for a second halo tile");
+    // The epilogue's transposition patches (one per wave: 64 pixels x 40 elements of the storage type) live in the halo buffer the
+    // item has just freed - unless that buffer is too small for them (the one-image 8x8 tile: 16.6 KB per tile against 20 KB of
+    // patches, which used to run over the position table behind the buffers; the fp32 form of that tile: 33 KB against 40 KB) or
+    // the workgroup has 8 waves: then they get a region of their own behind the position table.
+    static constexpr size_t PATCH_BYTES = (size_t)NW * 64 * 40 * sizeof(S_);
+    static constexpr bool OWN_PATCH = NW == 8 || PATCH_BYTES > (size_t)AP * HALO_ELEMS * 2;
+    static constexpr size_t LDS_BYTES = (size_t)2 * AP * HALO_ELEMS * 2 + POS_BYTES + (OWN_PATCH ? PATCH_BYTES : 0);
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
@@ -189,7 +205,7 @@ __device__ __forceinline__ float lane_xor(float v, int lane_now) {
 }
 
 template <typename C>
-__global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(const ConvV2Params p) {
+__global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void conv_v2_kernel(const ConvV2Params p) {
     constexpr int BN = C::BN, TH = C::TH, TW = C::TW, NI = C::NI, MR = C::MR, WN = C::WN, WM = C::WM;
     constexpr int HPIX = C::HPIX, HCOLS = C::HCOLS, PSTR = C::PSTR, VPP = C::VPP, BK = C::BK, RP = C::RP, HROWS = C::HROWS;
     constexpr int MAXHV = C::MAXHV, NT = C::NT, NH = C::NH;
@@ -198,6 +214,10 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     constexpr int NP = C::NP, FS = C::FS, FL = C::FL;
     constexpr bool FRG = C::FRG;
     using E = typename C::E;
+    using S = typename C::S;
+    constexpr int AP = C::AP, SV = C::SV;
+    constexpr bool F32 = C::F32;
+    constexpr int BUFE = AP * C::HALO_ELEMS;                   // elements of one halo buffer (hi tile [+ lo tile])
     using EL = Elem<E>;
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
     };
     // The positions are constant per thread; recomputing them per item cost ~25 VALU per vector (two divisions by
     // constants), keeping them in registers made the allocator spill.  They live in LDS instead: one ds_read per vector.
-    int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2);
+    int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)2 * BUFE * 2);
 #pragma unroll
     for (int i = 0; i < MAXHV; ++i) pos_tab[i * NTHR + tid] = hv_pos(i, tid);
     int st_b0 = 0;
@@ -331,20 +351,30 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             hv_pix[i] = !ok ? -1 : (DN4 ? (b * p.Hin + 2 * iy) * p.Win + 2 * ix : (b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh));
         }
     };
-    u32x4 hreg[NH];                // staged raw vectors: vector i lives in slot i % NH from its issue tap to its commit tap
+    u32x4 hreg[NH][SV];            // staged raw vectors: vector i lives in slot i % NH from its issue tap to its commit tap
     unsigned abh[8];               // (scale, shift) of this thread's 8 channels, packed fp16x2: 11-bit significands, the
                                    // transformed value is rounded to bf16 (8 bits) anyway; halves the registers held across taps
+    float gsc[F32 ? 8 : 1], gsh[F32 ? 8 : 1];   // fp32 mode: the fp32 pairs (first part of the GroupNorm table)
     bool st_cok = true;
     int st_c = 0, st_cs = 0, st_cl = 0, st_plane = 0;
     // (scale, shift) of 8 consecutive channels of image b: two 16-byte loads from the fp16x2 half of the GroupNorm table
     // (hsidm_gn_finalize writes it behind the fp32 pairs), consumed at commit time: nothing waits on them when they are requested
     auto gn_params = [&](int b, int c) __attribute__((always_inline)) {
+        if constexpr (F32) {
+            const f32x4* t = p.gn_ab + (((size_t)b * ctot + c) >> 1);          // [B][C] (scale, shift) pairs, two channels per f32x4
+            f32x4 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = t[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gsc[2 * k] = r[k][0]; gsh[2 * k] = r[k][1]; gsc[2 * k + 1] = r[k][2]; gsh[2 * k + 1] = r[k][3]; }
+            return;
+        }
         const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)3 * p.B * ctot + (size_t)b * ctot + c);
         const u32x4 lo = t[0], hi = t[1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
     };
-    const E* st_src = reinterpret_cast<const E*>(p.src0);
+    const S* st_src = reinterpret_cast<const S*>(p.src0);
     auto halo_begin = [&](int chunk) __attribute__((always_inline)) {
         // channel slice of the chunk being staged (+ its GroupNorm parameters).  Loads are UNCONDITIONAL (clamped
         // addresses): a predicated load would be merged with its zero alternative right away and that use would
@@ -358,15 +388,17 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         }
         st_cok = c < ctot;
         const int cc = st_cok ? c : 0;
-        if (cc < p.C0) { st_src = reinterpret_cast<const E*>(p.src0); st_cs = p.C0; st_cl = cc; }
-        else           { st_src = reinterpret_cast<const E*>(p.src1); st_cs = p.C1; st_cl = cc - p.C0; }
+        if (cc < p.C0) { st_src = reinterpret_cast<const S*>(p.src0); st_cs = p.C0; st_cl = cc; }
+        else           { st_src = reinterpret_cast<const S*>(p.src1); st_cs = p.C1; st_cl = cc - p.C0; }
         st_c = cc;
         if (C::XF != XF_NONE && NI == 1) gn_params(st_b0, cc);
     };
     auto halo_issue_one = [&](int i) __attribute__((always_inline)) {
         if (HSIDM_ABL(4)) return;
         const int pix = hv_pix[i] >= 0 ? hv_pix[i] + (DN4 ? st_plane : 0) : 0;
-        hreg[i % NH] = *reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
+        const u32x4* src_v = reinterpret_cast<const u32x4*>(st_src + (size_t)pix * st_cs + st_cl);
+#pragma unroll
+        for (int h = 0; h < SV; ++h) hreg[i % NH][h] = src_v[h];
     };
     // dead slot of the last (partial) vector round: the store goes to the row padding instead of being branched around,
     // so that the commit stays in the MFMAs' basic block and the scheduler can interleave the two
@@ -382,12 +414,21 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             gn_params(bb, st_c);
         }
         {
-            const unsigned w = hreg[i % NH][part];
-            cm_v[2 * part] = EL::lo(w);
-            cm_v[2 * part + 1] = EL::hi(w);
-            if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
+            if constexpr (F32) {
+                cm_v[2 * part] = __uint_as_float(hreg[i % NH][part >> 1][(part & 1) * 2]);
+                cm_v[2 * part + 1] = __uint_as_float(hreg[i % NH][part >> 1][(part & 1) * 2 + 1]);
+                if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
 #pragma unroll
-                for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_log2e(fmaf(cm_v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+                    for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_fast(fmaf(cm_v[k], gsc[k], gsh[k]));
+                }
+            } else {
+                const unsigned w = hreg[i % NH][0][part];
+                cm_v[2 * part] = EL::lo(w);
+                cm_v[2 * part + 1] = EL::hi(w);
+                if (C::XF != XF_NONE && !(HSIDM_ABL(2))) {
+#pragma unroll
+                    for (int k = 2 * part; k < 2 * part + 2; ++k) cm_v[k] = silu_log2e(fmaf(cm_v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+                }
             }
         }
         if (part == 3) {
@@ -399,7 +440,16 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 #pragma unroll
             for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
             const int off = (i == MAXHV - 1 && !last_live) ? dead_off : hv_lds(i);
-            *reinterpret_cast<u32x4*>(halo + buf * C::HALO_ELEMS + off) = ou;
+            *reinterpret_cast<u32x4*>(halo + buf * BUFE + off) = ou;
+            if constexpr (AP == 2) {                            // low halves x - bf16(x) into the buffer's second tile
+                x8 ol;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ol[k] = (E)(cm_v[k] - (float)o[k]);
+                u32x4 olu = __builtin_bit_cast(u32x4, ol);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) olu[k] = live ? olu[k] : 0u;
+                *reinterpret_cast<u32x4*>(halo + buf * BUFE + C::HALO_ELEMS + off) = olu;
+            }
         }
     };
     auto halo_commit_one = [&](int i, int buf) __attribute__((always_inline)) {
@@ -492,18 +542,21 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
         const int par_off = UP4 ? py * RP + px * PSTR : 0;            // this parity's 2x2 window inside the 3x3 halo
         HSIDM_SETPRIO(1);
         for (int chunk = 0; chunk < nch; ++chunk) {
-            const E* hb = halo + cur * C::HALO_ELEMS + par_off;
+            const E* hb = halo + cur * BUFE + par_off;
             // A fragments: 3-deep register ring over the 4*NT (tap, k-slice) sub-steps of the chunk, fetched two
             // sub-steps ahead (measured: with one sub-step of lookahead every k-slice waited ~300 cycles on LDS)
             // (NP = 2: a sub-step carries twice the MFMAs, so ONE sub-step of lookahead covers the same LDS latency and the ring is
             // two deep - 16 registers that the low-half weight fragments need)
             constexpr int AD = NP == 2 ? 2 : 3;
-            x8 a[AD][MR];
+            x8 a[AD][MR], a_lo[AP == 2 ? AD : 1][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2, kq = u & 3;
                 const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + kq * 16;
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[u % AD][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + off);
+                for (int mr = 0; mr < MR; ++mr) {
+                    a[u % AD][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + off);
+                    if constexpr (AP == 2) a_lo[u % AD][mr] = *reinterpret_cast<const x8*>(hb + C::HALO_ELEMS + abase[mr] + off);
+                }
             };
             a_fetch(0);
             if (AD == 3) a_fetch(1);
@@ -549,6 +602,10 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], fring_lo[NP == 2 ? u % FS : 0], acc[mr]);
                     }
+                    if constexpr (AP == 2) {                   // third pass: the activations' low halves on the weights' high halves
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a_lo[u % AD][mr], fring[FRG ? u % FS : 0], acc[mr]);
+                    }
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
@@ -557,8 +614,9 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                     }
                     if (NP == 2) {
 #pragma unroll
-                        for (int m = 0; m < MR; ++m) {
+                        for (int m = 0; m < MR * AP; ++m) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (AP == 2 && m < MR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the low-half A fragment
                             __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 3 : 1, 0);
                         }
                     }
@@ -600,7 +658,8 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             constexpr int LTW = (TW == 16) ? 4 : 3;
             constexpr int SCR_STR = 40;                                       // bf16 per pixel row: 32 couts + 16 B pad
             constexpr int NV = 2 * MR;                                        // 16-B vectors per lane and item
-            E* scr = (C::NW == 8 ? reinterpret_cast<E*>(smem_raw + (size_t)2 * C::HALO_ELEMS * 2 + C::POS_BYTES) : halo + (cur ^ 1) * C::HALO_ELEMS) +
+            // (fp32 mode: 4-byte patch elements, 10 KB per wave, in the free buffer's 56 KB)
+            S* scr = reinterpret_cast<S*>(C::OWN_PATCH ? reinterpret_cast<E*>(smem_raw + (size_t)2 * BUFE * 2 + C::POS_BYTES) : halo + (cur ^ 1) * BUFE) +
                         wave * (64 * SCR_STR);
             // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU).  The lane
             // constants are rebuilt from the hardware lane id at the top of every pass: kept across the passes they were
@@ -615,7 +674,8 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             auto run = [&](auto leaky_tag, auto res_tag) __attribute__((always_inline)) {
                 constexpr bool LEAKY = decltype(leaky_tag)::value != 0;
                 constexpr bool RES = decltype(res_tag)::value != 0;
-                x8 rv[RES ? 4 : 1];                                            // residual vectors of the current pass
+                x8 rv[(RES && !F32) ? 4 : 1];                                  // residual vectors of the current pass
+                f32x4 rvf[(RES && F32) ? 4 : 1][2];
                 float vs1[8], vs2[8];
 #pragma unroll
                 for (int g = 0; g < MR; g += 2) {
@@ -631,7 +691,11 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                     if (RES) {                                                 // requested first: the latency hides behind the transposition
 #pragma unroll
                         for (int v4 = 0; v4 < 4; ++v4)
-                            if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + vec_base(g, v4) + lane_el);
+                            if (v4 < 2 * nm) {
+                                const S* rp = reinterpret_cast<const S*>(p.res) + vec_base(g, v4) + lane_el;
+                                if constexpr (F32) { rvf[RES ? v4 : 0][0] = *reinterpret_cast<const f32x4*>(rp); rvf[RES ? v4 : 0][1] = *reinterpret_cast<const f32x4*>(rp + 4); }
+                                else rv[RES ? v4 : 0] = *reinterpret_cast<const x8*>(rp);
+                            }
                     }
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
@@ -642,16 +706,21 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                             float v[2];
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
-                                v[e] = C::XF != XF_NONE ? fmaf(acc[g + m2][j + e], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j + e] + ep_add[NI == 1 ? 0 : img];
+                                v[e] = (C::XF != XF_NONE && !F32) ? fmaf(acc[g + m2][j + e], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j + e] + ep_add[NI == 1 ? 0 : img];
                                 if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                                 // no residual: statistics from the fp32 values in the accumulator layout (the lane owns one cout: 2 VALU
                                 // per value, one exchange between the lane halves) instead of unpacking the stored vectors and the
                                 // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
                                 if (!RES) { s1[NI == 1 ? 0 : img] += v[e]; s2[NI == 1 ? 0 : img] = fmaf(v[e], v[e], s2[NI == 1 ? 0 : img]); }
                             }
-                            const x2 pr = cvt_pair<E>(v[0], v[1]);
-                            scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
-                            scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
+                            if constexpr (F32) {
+                                scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = v[0];
+                                scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = v[1];
+                            } else {
+                                const x2 pr = cvt_pair<E>(v[0], v[1]);
+                                reinterpret_cast<E*>(scr)[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
+                                reinterpret_cast<E*>(scr)[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
+                            }
                         }
                     }
                     HSIDM_STAMP(it, 9);
@@ -662,19 +731,35 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
 #pragma unroll
                     for (int v4 = 0; v4 < 4; ++v4) {
                         if (v4 >= 2 * nm) break;
-                        const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
                         float f[8];
+                        if constexpr (F32) {
+                            const f32x4 r0 = *reinterpret_cast<const f32x4*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                            const f32x4 r1 = *reinterpret_cast<const f32x4*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8 + 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { f[k] = r0[k]; f[4 + k] = r1[k]; }
+                            if (RES) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) f[k] = fmaf(p.res_scale, f[k], rvf[RES ? v4 : 0][k >> 2][k & 3]);
+                            }
+                            f32x4 o0, o1;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { o0[k] = f[k]; o1[k] = f[4 + k]; }
+                            S* op = reinterpret_cast<S*>(p.out) + vec_base(g, v4) + lane_el;
+                            if (!HSIDM_ABL(1)) { *reinterpret_cast<f32x4*>(op) = o0; *reinterpret_cast<f32x4*>(op + 4) = o1; }
+                        } else {
+                        const x8 raw = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(scr) + (pl0 + 16 * v4) * SCR_STR + cq * 8);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
                         x8 o = raw;
                         if (RES) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {
-                                f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
+                                f[k] = fmaf(p.res_scale, f[k], (float)rv[RES ? v4 : 0][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
                                 o[k] = (E)EL::sat(f[k]);
                             }
                         }
                         if (!HSIDM_ABL(1)) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(g, v4) + lane_el) = o;
+                        }
                         if (RES) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
@@ -712,7 +797,7 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
             if (p.act == ACT_LEAKY) { if (p.res) run(SlotTag<1>{}, SlotTag<1>{}); else run(SlotTag<1>{}, SlotTag<0>{}); }
             else                    { if (p.res) run(SlotTag<0>{}, SlotTag<1>{}); else run(SlotTag<0>{}, SlotTag<0>{}); }
             HSIDM_STAMP(it, 14);
-            if (C::NW != 8) lds_barrier();                                   // the patch is part of the next staging buffer (NW = 8: a region of its own)
+            if (!C::OWN_PATCH) lds_barrier();                                // the patch is part of the next staging buffer (else: a region of its own)
         } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -725,13 +810,13 @@ __global__ __launch_bounds__(C::NTHR, C::NW == 8 ? 1 : 2) void conv_v2_kernel(co
                 const int q = pbase + row - img * (TH * TW);
                 const int ty = q / TW, tx = q - ty * TW;
                 const int oy = oyb + US * ty, ox = oxb + US * tx;
-                float v = C::XF != XF_NONE ? fmaf(acc[mr][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[mr][j] + ep_add[NI == 1 ? 0 : img];
+                float v = (C::XF != XF_NONE && !F32) ? fmaf(acc[mr][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[mr][j] + ep_add[NI == 1 ? 0 : img];
                 if (!(nok && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
                 if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                 const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;
-                if (p.res) v = p.res_scale * v + (float)reinterpret_cast<const E*>(p.res)[o];
-                const E st = (E)EL::sat(v);
-                if (!(HSIDM_ABL(1))) reinterpret_cast<E*>(p.out)[o] = st;
+                if (p.res) v = p.res_scale * v + (float)reinterpret_cast<const S*>(p.res)[o];
+                const S st = F32 ? (S)v : (S)EL::sat(v);
+                if (!(HSIDM_ABL(1))) reinterpret_cast<S*>(p.out)[o] = st;
                 const float sv = (float)st;
                 s1[NI == 1 ? 0 : img] += sv;
                 s2[NI == 1 ? 0 : img] += sv * sv;

@@ -54,6 +54,11 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
     if b16 and proj_weight is not None and kh == 3 and not out_nchw and bn == 128:
         lay["w_v2"] = PackedConv._lanes(lay["w"], cpad)         # read by the split-K kernel only (conv_sk.hip: projection chunks)
+    # fp32 mode: the persistent 3x3 kernel has an fp32 form too (conv_v2.h, AP = 2: fp32 storage, hi + lo operands); it reads the same
+    # register-streaming order with 64-channel steps
+    f32_v2 = (not b16) and proj_weight is None and kh == 3 and not out_nchw and bn in (64, 128)
+    if f32_v2:
+        lay["w_v2"] = PackedConv._lanes(PackedConv._steps(weight, cpad, 64).contiguous(), cpad)
     if b16 and proj_weight is None and (not out_nchw or (kh == 3 and bn == 32)):
         wv = lay["w"]
         meta["tap_major"] = kh == 3 and cin == 8
@@ -72,7 +77,7 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
             for px in (0, 1):
                 f = torch.stack([torch.stack([sum(weight[:, :, dy, dx] for dy in rows[py][ty] for dx in rows[px][tx])
                                               for tx in (0, 1)], dim=-1) for ty in (0, 1)], dim=-2)
-                pars.append(PackedConv._steps(f, cpad, bk))
+                pars.append(PackedConv._steps(f, cpad, 64))
         lay["w_up4"] = PackedConv._lanes(torch.cat(pars, dim=0).contiguous(), cpad)
     # stride-2 conv over the four input-parity planes (include/hsidm.h, hsidm_conv_desc.stride)
     if fold_dn and lay["w_v2"] is not None and kh == 3 and bn in (64, 128):
@@ -86,7 +91,7 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
                         dy, dx = tapmap[ry][ty], tapmap[rx][tx]
                         if dy is not None and dx is not None:
                             f[:, :, ty, tx] = weight[:, :, dy, dx]
-                planes.append(PackedConv._steps(f, cpad, bk))
+                planes.append(PackedConv._steps(f, cpad, 64))
         lay["w_dn4"] = PackedConv._lanes(torch.cat(planes, dim=0).contiguous(), cpad)
     return lay, meta
 
@@ -107,13 +112,13 @@ class PackedConv:
         if proj_weight is not None and proj_bias is not None:
             b = proj_bias.detach().float().clone() if b is None else b + proj_bias.detach().float()
         w = lay["w"]
-        et = torch.float16 if self.prec == _lib.F16 else torch.bfloat16            # element type of the packed weights
+        et = torch.float16 if self.prec == _lib.F16 else torch.bfloat16            # element type of the packed weights (fp32 mode: bf16 hi + lo)
         self.w_hi = w.to(et).contiguous()
         # low halves: fp32 mode (three MFMAs per product) and the generic kernel's fp16 form (always hi + lo weights)
         self.w_lo = (w - self.w_hi.float()).to(et).contiguous() if self.prec != _lib.BF16 else None
         self.bias = None if b is None else b.to(dev).contiguous()
         # fp16 mode: does this layer multiply by hi + lo weights on the persistent kernels too (precision.wide_weights)?
-        self.wide = self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)
+        self.wide = (self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)) or self.prec == _lib.F32X3
         for name in ("w_v2", "w_up4", "w_dn4"):
             t = lay[name]
             hi = None if t is None else t.to(et).contiguous()
@@ -126,12 +131,13 @@ class PackedConv:
         self.precision, self.out_nchw = precision, out_nchw
 
     @classmethod
-    def from_buffers(cls, meta, precision, out_nchw, w_hi, w_lo, w_v2, w_dn4, bias):
+    def from_buffers(cls, meta, precision, out_nchw, w_hi, w_lo, w_v2, w_dn4, bias, w_v2_lo=None, w_dn4_lo=None):
         """A PackedConv over caller-owned packed buffers (the training step refreshes them in place every iteration)."""
         self = cls.__new__(cls)
         self._set_meta(meta, precision, out_nchw)
         self.w_hi, self.w_lo, self.w_v2, self.w_up4, self.w_dn4, self.bias = w_hi, w_lo, w_v2, None, w_dn4, bias
-        self.wide, self.w_v2_lo, self.w_up4_lo, self.w_dn4_lo = False, None, None, None
+        # fp32 mode: the low halves of the register-streaming layouts (the persistent kernel's fp32 form reads both)
+        self.wide, self.w_v2_lo, self.w_up4_lo, self.w_dn4_lo = w_v2_lo is not None, w_v2_lo, None, w_dn4_lo
         return self
 
     @staticmethod

@@ -171,7 +171,7 @@ class Trainer:
             if need_dg:
                 roles.append(("dgrad", iw.transpose(0, 1).flip(2, 3).contiguous(), False, False))
             for role, iwt, nchw, fdn in roles:
-                lay, meta = ops.pack_layouts(iwt, prec, out_nchw=nchw, fold_dn=fdn and prec == "bf16")
+                lay, meta = ops.pack_layouts(iwt, prec, out_nchw=nchw, fold_dn=fdn)
                 self._pk_meta[(id(conv), role)] = (meta, nchw)
                 for name in ("w", "w_v2", "w_dn4"):
                     if lay[name] is None:
@@ -205,7 +205,8 @@ class Trainer:
             any_hi = next(v[0] for v in (w, v2, dn4) if v is not None)
             # hsidm_conv2d wants a non-null w_hi even when the dispatch reads another layout: a pruned one aliases a live buffer
             pk = ops.PackedConv.from_buffers(meta, prec, nchw, w[0] if w is not None else any_hi, None if w is None else w[1],
-                                             None if v2 is None else v2[0], None if dn4 is None else dn4[0], None)
+                                             None if v2 is None else v2[0], None if dn4 is None else dn4[0], None,
+                                             w_v2_lo=None if v2 is None else v2[1], w_dn4_lo=None if dn4 is None else dn4[1])
             pk._track = None
             self._pk[(cid, role)] = pk
         for conv, _, _, _ in self._convs():          # forward convolutions read their bias straight from the master copy

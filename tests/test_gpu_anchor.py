@@ -92,10 +92,12 @@ def test_conv_kernel_against_fp32_torch(dev, mode, case):
         torch.cuda.synchronize()
     finally:
         ops.set_conv_probe(None)
-    if mode != "fp32":                                   # the fp32 mode runs everything on the LDS-tiled kernel
-        got_label = recs[-1]["kernel"]
+    got_label = recs[-1]["kernel"]
+    if mode == "fp32":       # the fp32 mode: 3x3 convs on the persistent kernel's fp32 form (128- / 64-cout tiles), 1x1 on the LDS-tiled kernel
+        want = "conv_igemm" if ks == 1 else ("conv_v2 bn64" if C0 + C1 == 8 else label.replace("bn256", "bn128").replace("conv_v3 bn64", "conv_v2 bn64"))
+    else:
         want = label.replace("bn256", "bn128") if mode == "fp16x2" else label      # hi + lo weights: no 256-cout items
-        assert want in got_label, (want, got_label)
+    assert want in got_label, (want, got_label)
     slab, nsplit = y._hsidm_stats
     assert_stats(slab, y, name)
     want_y = _reference(x0, x1, ab, xf == 2, w, b, film, res, stride, ups, ks)
@@ -148,3 +150,72 @@ def test_group_norm_table_against_torch(dev, mode):
     hs = tab[3 * n:4 * n].view(torch.int32).cpu().view(torch.float16).reshape(B, Cc, 2).float() / 1.44269504
     got_s = xf * hs[:, :, 0, None, None] + hs[:, :, 1, None, None]
     check("gn_table_fp16_log2e_pairs", mode, got_s, want, tol=6e-4)
+
+
+F32_CASES = [  # B, H, W, C0, C1, Cout, stride, ups, GN+SiLU, film, residual, res_scale, leaky : the fp32 form of the persistent kernel
+    (3, 16, 16, 64, 0, 64, 1, False, True, True, False, 1.0, False),       # odd batch, 64-cout tiles
+    (3, 8, 8, 32, 0, 32, 1, False, True, True, True, 1.0, False),          # two-image 8x8 tiles, odd batch (a partial tile), 32 couts
+    (5, 8, 8, 512, 0, 512, 1, False, True, False, True, 1.0, False),       # one-image 8x8 tiles (tile_kind 2), four cout slices
+    (1, 8, 8, 1024, 0, 512, 1, False, True, True, False, 1.0, False),      # ... batch 1, sixteen chunks
+    (2, 13, 21, 40, 0, 24, 1, False, True, False, False, 1.0, False),      # ragged map: every tile partial (scalar epilogue), bn 32
+    (4, 32, 32, 64, 0, 64, 1, False, False, False, True, 0.1, True),       # the autoencoder's ResBlock tail: LeakyReLU, 0.1 * conv + x
+    (2, 24, 40, 72, 24, 48, 1, False, True, True, True, 1.0, False),       # concat input, channel counts off the chunk grid
+    (3, 16, 16, 64, 0, 64, 2, False, False, False, False, 1.0, False),     # stride 2 over the parity planes
+    (3, 8, 8, 128, 0, 128, 1, True, False, False, False, 1.0, False),      # folded nearest-x2
+]
+
+
+@pytest.mark.parametrize("case", F32_CASES)
+def test_fp32_form_of_the_persistent_kernel_matches_the_lds_tiled_kernel(dev, case):
+    """fp32 mode: conv_v2's fp32 form (fp32 storage, bf16 hi + lo operands, three MFMAs per product) against the LDS-tiled kernel that
+    carried the mode until round 3 (same arithmetic, other tiling) and against fp32 torch, on the shapes the benchmark-size anchors do
+    not reach: odd batches, partial tiles, one-image 8x8 tiles, LeakyReLU + scaled residual, concat inputs."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, C0, C1, Co, stride, ups, xf, with_film, with_res, res_scale, leaky = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:6]))
+    cin = C0 + C1
+    w = torch.randn(Co, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = 0.1 * torch.randn(Co, generator=g)
+    x0 = torch.randn(B, H, W, C0, generator=g).to(dev)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dev) if C1 else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, cin, generator=g), 0.2 * torch.randn(B, cin, generator=g)], 2).contiguous().to(dev) if xf else None
+    Ho, Wo = (2 * H, 2 * W) if ups else (((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+    film = torch.randn(B, Co, generator=g).to(dev) if with_film else None
+    res = torch.randn(B, Ho, Wo, Co, generator=g).to(dev) if with_res else None
+    pk = ops.PackedConv(w.to(dev), b.to(dev), "fp32", fold_ups=ups, fold_dn=stride == 2)
+    outs, labels = [], []
+    for use_v2 in (False, True):
+        ops.set_use_v2(use_v2)
+        recs = []
+        ops.set_conv_probe(recs)
+        try:
+            y = ops.conv2d(x0, pk, x1=x1, gn_ab=None if ab is None else ops.gn_table(ab), transform=ops.XF_AFFINE_SILU if xf else ops.XF_NONE,
+                           film=film, res=res, res_scale=res_scale, act=ops.ACT_LEAKY if leaky else ops.ACT_NONE, stride=stride, ups=ups, stats=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_conv_probe(None)
+            ops.set_use_v2(True)
+        assert_stats(y._hsidm_stats[0], y, case)
+        outs.append(y.float().cpu())
+        labels.append(recs[-1]["kernel"])
+    # (slices of 32 couts have no fp32 form on the persistent kernel: those two cases compare the LDS-tiled kernel with torch only)
+    assert labels[0].startswith("conv_igemm") and labels[1].startswith("conv_v2" if Co > 32 else "conv_igemm"), labels
+    check("fp32_v2_vs_igemm%s" % (case,), "fp32", outs[1], outs[0], tol=2e-5)
+    xr = x0 if x1 is None else torch.cat([x0, x1], dim=3)
+    xr = xr.float().cpu()
+    if ab is not None:
+        a = ab.float().cpu()
+        xr = xr * a[:, None, None, :, 0] + a[:, None, None, :, 1]
+        xr = xr * torch.sigmoid(xr)
+    xr = xr.permute(0, 3, 1, 2)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    want = F.conv2d(xr, w, b, stride=stride, padding=1)
+    if film is not None:
+        want = want + film.cpu()[:, :, None, None]
+    if leaky:
+        want = F.leaky_relu(want, 0.01)
+    want = res_scale * want.permute(0, 2, 3, 1)
+    if res is not None:
+        want = want + res.cpu()
+    check("fp32_v2_vs_torch%s" % (case,), "fp32", outs[1], want, tol=1e-4)
