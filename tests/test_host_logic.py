@@ -298,3 +298,21 @@ def test_bench_launches_itself_for_several_gpus(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-8:] == ["--gpus", "4", "--steps", "20", "--warmup", "3", "--total-patches", "64"] and cmd[-9].endswith("bench.py")
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_package_installs_under_its_import_name(tmp_path):
+    """`hsi-dmgasr_amd/` is not an importable directory name; in the tree the alias package `hsi_dmgasr_amd/` maps onto it.  An
+    installed copy (setup.py: package_dir) must import by name WITHOUT the repository on the path, library included."""
+    import sys
+    build = tmp_path / "lib"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "setup.py"), "-q", "build_py", "-d", str(build)], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (build / "hsi_dmgasr_amd" / "libhsidm.so").exists() and (build / "hsi_dmgasr_amd" / "sr3_modules" / "unet.py").exists()
+    code = ("import os, sys; assert not any(os.path.abspath(p) == %r for p in sys.path); "
+            "import hsi_dmgasr_amd, hsi_dmgasr_amd.sr3_modules.unet as u, hsi_dmgasr_amd._lib as L; "
+            "assert %r in hsi_dmgasr_amd.__file__ and L.lib().hsidm_version() == 1; "
+            "print(u.UNet(inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1, image_size=16).precision)") % (ROOT, str(build))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = str(build)
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
