@@ -42,9 +42,41 @@ def is_16bit(p):
     return p != "fp32"
 
 
+def _policy(exp, cout, cin, ksize):
+    """Evaluates a policy expression such as "cout <= 128 and (cin <= 192 or ksize == 1)": names, integers, comparisons, and / or /
+    not and parentheses only (parsed, never eval'ed)."""
+    import ast
+    import operator as op
+    cmp = {ast.LtE: op.le, ast.Lt: op.lt, ast.GtE: op.ge, ast.Gt: op.gt, ast.Eq: op.eq, ast.NotEq: op.ne}
+    env = {"cout": cout, "cin": cin, "ksize": ksize}
+
+    def ev(n):
+        if isinstance(n, ast.Expression):
+            return ev(n.body)
+        if isinstance(n, ast.BoolOp):
+            vals = [ev(v) for v in n.values]
+            return all(vals) if isinstance(n.op, ast.And) else any(vals)
+        if isinstance(n, ast.UnaryOp) and isinstance(n.op, ast.Not):
+            return not ev(n.operand)
+        if isinstance(n, ast.Compare):
+            left = ev(n.left)
+            for o, c in zip(n.ops, n.comparators):
+                right = ev(c)
+                if type(o) not in cmp or not cmp[type(o)](left, right):
+                    return False
+                left = right
+            return True
+        if isinstance(n, ast.Name) and n.id in env:
+            return env[n.id]
+        if isinstance(n, ast.Constant) and isinstance(n.value, int):
+            return n.value
+        raise ValueError("HSIDM_WIDE_POLICY: unsupported expression element %s" % type(n).__name__)
+    return bool(ev(ast.parse(exp, mode="eval")))
+
+
 def wide_weights(p, cout, cin=0, ksize=3):
     """Does a convolution (cout x cin x ksize x ksize) carry hi + lo weights in mode p (second MFMA pass)?"""
-    exp = os.environ.get("HSIDM_WIDE_POLICY")          # diagnostic: a Python expression over cout, cin, ksize (policy experiments)
+    exp = os.environ.get("HSIDM_WIDE_POLICY")          # diagnostic (tools/policy_probe.py): comparisons over cout, cin, ksize
     if exp and p == "fp16":
-        return bool(eval(exp, {"cout": cout, "cin": cin, "ksize": ksize}))
+        return _policy(exp, cout, cin, ksize)
     return p == "fp16x2" or (p == "fp16" and cout <= 128)

@@ -316,3 +316,40 @@ def test_package_installs_under_its_import_name(tmp_path):
     env["PYTHONPATH"] = str(build)
     r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
+    """precision.py: the five mode names, which of them are 16-bit, which convolutions carry hi + lo weights, and the diagnostic
+    policy hook (a parsed expression, never eval'ed)."""
+    from hsi_dmgasr_amd import _lib, precision as P
+    import torch
+    assert set(P.MODES) == {"bf16", "fp32", "fp16", "fp16x1", "fp16x2"}
+    assert [_lib.prec_id(m) for m in ("bf16", "fp32", "fp16", "fp16x1", "fp16x2")] == [_lib.BF16, _lib.F32X3, _lib.F16, _lib.F16, _lib.F16]
+    assert _lib.act_dtype("fp16") == torch.float16 and _lib.act_dtype("bf16") == torch.bfloat16 and _lib.act_dtype("fp32") == torch.float32
+    assert P.is_16bit("fp16x2") and P.is_16bit("bf16") and not P.is_16bit("fp32")
+    monkeypatch.delenv("HSIDM_WIDE_POLICY", raising=False)
+    assert P.wide_weights("fp16", 64) and P.wide_weights("fp16", 128) and not P.wide_weights("fp16", 256)
+    assert not P.wide_weights("fp16x1", 64) and P.wide_weights("fp16x2", 512) and not P.wide_weights("bf16", 64)
+    monkeypatch.setenv("HSIDM_WIDE_POLICY", "cout <= 128 and (cin <= 192 or ksize == 1)")
+    assert P.wide_weights("fp16", 128, 192, 3) and not P.wide_weights("fp16", 128, 256, 3) and P.wide_weights("fp16", 128, 256, 1)
+    assert not P.wide_weights("fp16x1", 64, 64, 3)                      # the hook only re-defines the "fp16" mode
+    monkeypatch.setenv("HSIDM_WIDE_POLICY", "__import__('os').system('true')")
+    with pytest.raises(ValueError):
+        P.wide_weights("fp16", 64, 64, 3)
+    with pytest.raises(ValueError):
+        P.resolve_precision("fp8")
+    # packing: a wide layer carries the low halves of every register-streaming layout, a narrow one none
+    from hsi_dmgasr_amd import ops
+    monkeypatch.delenv("HSIDM_WIDE_POLICY")
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    pk = ops.PackedConv(w, None, "fp16", fold_ups=True)
+    assert pk.wide and pk.w_v2.dtype == torch.float16 and pk.w_v2_lo.shape == pk.w_v2.shape and pk.w_up4_lo is not None
+    full = pk.w_v2.double() + pk.w_v2_lo.double()
+    ref = ops.pack_layouts(w, "fp16")[0]["w_v2"].double()
+    assert float((full - ref).abs().max()) < 2.0 ** -17 * float(ref.abs().max())          # hi + lo ~ 18+ bits (lo is subnormal here)
+    assert float((pk.w_v2.double() - ref).abs().max()) > 2.0 ** -13 * float(ref.abs().max())
+    pk1 = ops.PackedConv(torch.randn(256, 64, 3, 3, generator=g) * 0.05, None, "fp16")
+    assert not pk1.wide and pk1.w_v2_lo is None and pk1.w_lo is not None      # (the LDS-tiled fallback always has both halves)
+    pk32 = ops.PackedConv(w, None, "fp32")
+    assert pk32.w_v2 is not None and pk32.w_v2_lo is not None and pk32.w_v2.dtype == torch.bfloat16 and pk32.w_hi.shape[2] == 32
