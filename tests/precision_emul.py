@@ -91,6 +91,7 @@ class Mode:
         self.sk = kv.get("sk", "shra")
         self.wl = kv["wl"].split("+") if "wl" in kv else None      # wl=final+ups.18: hi + lo weights on these units only
         self.stl = kv["stl"].split("+") if "stl" in kv else []     # stl=ups.18+ups.17: fp32 storage for the tensors of these units
+        self.gnx = kv["gnx"].split("+") if "gnx" in kv else []     # gnx=final_conv: fp32 GroupNorm pairs in these units
         self.cur = ""
         self.sm = kv.get("sm", "")
 
@@ -146,7 +147,9 @@ def gn_affine(m, x, groups, gamma, beta, xin=None):
     cg = c // groups
     scale = gamma.view(1, c) * rstd.repeat_interleave(cg, dim=1)
     shift = beta.view(1, c) - mean.repeat_interleave(cg, dim=1) * scale
-    if m.gn == "fp16c":       # what hsidm_gn_finalize writes: the shift formed with the ROUNDED scale
+    if m.gnx and any(m.cur.startswith(q) for q in m.gnx):
+        pass
+    elif m.gn == "fp16c":     # what hsidm_gn_finalize writes: the shift formed with the ROUNDED scale
         scale = rnd(scale, "fp16")
         shift = rnd(beta.view(1, c) - mean.repeat_interleave(cg, dim=1) * scale, "fp16")
     elif m.gn != "fp32":
