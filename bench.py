@@ -367,7 +367,8 @@ def main_train(args, dev, rank, world, use_dist):
     from hsi_dmgasr_amd import parallel
     from hsi_dmgasr_amd.init import init_weights_orthogonal
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
-    prec, B = args.precision, args.train_batch
+    # the training step runs in the bf16 or the fp32 mode (the fp16 mode is an inference mode: DESIGN.md section 5)
+    prec, B = (args.precision if args.precision in ("bf16", "fp32") else "bf16"), args.train_batch
     u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8],
                   attn_res=[16], res_blocks=2, dropout=0.2, image_size=128, precision=prec)
     init_weights_orthogonal(u, seed=0)
