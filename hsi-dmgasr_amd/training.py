@@ -48,7 +48,11 @@ class Trainer:
                                           % u.attn.n_head)
         self.precision = resolve_precision(precision if precision is not None else net.precision)
         if self.precision not in ("bf16", "fp32"):
-            raise NotImplementedError("hsidm: the training step runs in the bf16 or the fp32 mode (got %r)" % self.precision)
+            if precision is not None:
+                raise NotImplementedError("hsidm: the training step runs in the bf16 or the fp32 mode (got %r)" % self.precision)
+            # A network built in an inference-only mode (the fp16 family, the package default) and no mode asked for: train as the
+            # reference trains - in fp32 arithmetic (gradients within 1e-5 of autograd); Trainer(gd, precision="bf16") is the fast form.
+            self.precision = "fp32"
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.dropout_seed = int(dropout_seed)
         self.bucket_bytes = int(bucket_bytes)

@@ -219,3 +219,24 @@ def test_fp32_form_of_the_persistent_kernel_matches_the_lds_tiled_kernel(dev, ca
     if res is not None:
         want = want + res.cpu()
     check("fp32_v2_vs_torch%s" % (case,), "fp32", outs[1], want, tol=1e-4)
+
+
+def test_fp16_stores_saturate_instead_of_overflowing(dev):
+    """fp16's range ends at 65 504: a convolution whose result exceeds it must store +-65504, not inf (an inf would turn the next
+    GroupNorm's statistics, and with them the rest of the chain, into NaN).  Every store path: the vector epilogue (with and without a
+    residual), the scalar epilogue of partial tiles, the 1x1 GEMM, the split-K finish."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (B, H, W, Ci, Co, ks) in ((2, 16, 16, 64, 64, 3), (2, 16, 16, 128, 128, 3), (1, 13, 9, 64, 48, 3), (2, 16, 16, 128, 128, 1), (1, 8, 8, 512, 512, 3)):
+        w = torch.full((Co, Ci, ks, ks), 40.0)                        # 64 x 9 x 40 x 30 ~ 7e5 >> 65504
+        w[::2] *= -1.0
+        x = torch.full((B, H, W, Ci), 30.0).to(torch.float16).to(dev)
+        res = torch.randn(B, H, W, Co, generator=g).to(torch.float16).to(dev)
+        for r in (None, res):
+            pk = ops.PackedConv(w.to(dev), None, "fp16")
+            y = ops.conv2d(x, pk, res=r, stats=True)
+            torch.cuda.synchronize()
+            yf = y.float().cpu()
+            assert torch.isfinite(yf).all(), (B, H, W, Ci, Co, ks, r is not None)
+            inner = yf[:, 2:-2, 2:-2, :] if ks == 3 else yf
+            assert float(inner[..., 1::2].min()) == 65504.0 and float(inner[..., 0::2].max()) == -65504.0

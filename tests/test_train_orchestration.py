@@ -268,7 +268,9 @@ def test_trainer_rejects_what_its_backward_pass_does_not_cover(monkeypatch):
         CpuTrainer(gd_of(u))
     u = unet.UNet(precision="fp16", **CFGS["tiny"])
     with pytest.raises(NotImplementedError, match="bf16 or the fp32"):
-        CpuTrainer(gd_of(u))
+        CpuTrainer(gd_of(u), precision="fp16")
+    assert CpuTrainer(gd_of(u)).precision == "fp32"          # inherited from an inference-only mode: trains as the reference does
+    assert CpuTrainer(gd_of(unet.UNet(**CFGS["tiny"]))).precision == "fp32"          # ... and so does the package default
 
 
 def test_optimizer_state_round_trips_through_torch_adam_format(monkeypatch, tmp_path):
