@@ -163,7 +163,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
     if (v2_mode(d) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
-        else if (!is16(d->prec)) return HSIDM_E_UNSUPPORTED;     // the fp32 form exists for the 3x3 kernel only: no w_v2 otherwise
+        // (fp32 mode: a shape its two persistent forms - this kernel and the 1x1 GEMM - do not take stays on the LDS-tiled kernel)
         // 8x8 maps: two-image tiles halve the work items; when those would leave half of the co-resident workgroup slots
         // empty, one-image 64-pixel tiles keep two workgroups on every CU at the same staging cost per pixel
         if (path == PATH_V2 && tile_kind == 1 && xf == HSIDM_XF_AFFINE_SILU && !d->ups && d->bn == 128 && Hout <= 8 && Wout <= 8 &&
@@ -181,7 +181,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
             path = PATH_G1;
         }
         // LDS-staged GEMM (conv1x1_g.hip): whole cout slices, 64-pixel statistics groups
-        if (is16(d->prec) && d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
+        if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
     }
     if ((path == PATH_V2 || d->nphase == 2) && d->workspace) {
@@ -264,9 +264,9 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     if (rc != HSIDM_OK) return rc;
     const bool use_v2 = path == PATH_V2 || path == PATH_V3;
     if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
-    if (d->prec == HSIDM_F32X3 && !use_v2 && !d->w_lo) return HSIDM_E_BADARG;      // (the persistent form reads w_v2 / w_v2_lo)
+    if (d->prec == HSIDM_F32X3 && !use_v2 && path != PATH_G1 && !d->w_lo) return HSIDM_E_BADARG;      // (the persistent forms read w_v2 / w_v2_lo)
     const int elem = d->prec == HSIDM_F16 ? 1 : 0;
-    const int bk = use_v2 ? 64 : hsidm_conv_bk(d->prec);        // (the persistent kernels walk 64-channel chunks in every mode)
+    const int bk = (use_v2 || path == PATH_G1) ? 64 : hsidm_conv_bk(d->prec);        // (the persistent kernels walk 64-channel chunks in every mode)
     ConvParams p;
     p.nphase = d->nphase;
     int steps = 0;
@@ -294,7 +294,8 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     if (path == PATH_G1) {
         const hsidm_conv_phase& s0 = d->ph[0];
         return conv1x1_g_run(d->bn, s0.transform, reinterpret_cast<const bf16*>(s0.src0), reinterpret_cast<const bf16*>(s0.C1 > 0 ? s0.src1 : nullptr),
-                             s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), reinterpret_cast<const bf16*>(d->w_v2_lo), elem,
+                             s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), reinterpret_cast<const bf16*>(d->w_v2_lo),
+                             d->prec == HSIDM_F32X3 ? 2 : elem,
                              d->bias, reinterpret_cast<const bf16*>(d->res),
                              d->res_scale, reinterpret_cast<bf16*>(d->out), reinterpret_cast<float2*>(d->stats), d->B * Hout * Wout,
                              Hout * Wout, d->Cout, d->ksize == 3 ? 2 : (s0.C0 + s0.C1 + 127) / 128 * 2, d->ksize == 3 ? Hout : 0,

@@ -23,6 +23,7 @@
 // layer is a K = 72 -> 128 GEMM: 2 chunks, 8 k-slices.
 #include "conv_v2.h"
 #include "../../include/hsidm.h"
+#include <type_traits>
 
 // Diagnostic builds (-DG1_ABL=n, tools/g1_ablate.sh): 1 no activation loads, 2 no weight loads, 3 no MFMAs, 4 no A-fragment LDS
 // reads, 5 no barriers, 6 no output stores, 7 no epilogue, 8 no statistics (results are wrong; timing only).  The product build has
@@ -55,16 +56,22 @@ struct C1gParams {
     int n_slices, m_tiles, total_items;
 };
 
-template <int BN, int XF, int IM = 0, typename E = bf16, int NP = 1>
-__global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
+// F32 (with E = bf16, NP = 2): the fp32 mode on this kernel - fp32 activations in HBM (two 16-byte vectors per staged pixel-vector, fp32
+// GroupNorm pairs, fp32 stores), every staged value split into bf16 hi + lo into TWO tiles per buffer, three MFMAs per product
+// (conv_v2.h, AP = 2); the 4-byte epilogue patches (40 KB) get a region of their own: 112 KB of LDS, one workgroup per CU.
+template <int BN, int XF, int IM = 0, typename E = bf16, int NP = 1, bool F32 = false>
+__global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gParams p) {
     using EL = Elem<E>;
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
+    using S = typename std::conditional<F32, float, E>::type;      // storage type of activations in HBM
+    static_assert(!F32 || (NP == 2 && IM == 0), "the fp32 form: hi + lo weights, plain 1x1");
+    constexpr int SV = F32 ? 2 : 1, AP = F32 ? 2 : 1;
     constexpr int WN = BN / 32, WM = 4 / WN, MR = 128 / WM / 32;
-    constexpr int PSTR = 72, TILE = 128 * PSTR;
+    constexpr int PSTR = 72, TILE = 128 * PSTR, BUFE = AP * TILE;
     constexpr int SCR_STR = 40;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* xt = reinterpret_cast<E*>(smem_raw);                     // [2][TILE] (+ 2 KiB: the epilogue patch overruns buffer 1)
+    E* xt = reinterpret_cast<E*>(smem_raw);                     // [2][AP][TILE] (+ 2 KiB: the 16-bit epilogue patch overruns buffer 1)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     const int cv = tid & 7;
     const int px_l = tid >> 3;
     const int hv0 = px_l * PSTR + cv * 8;
-    u32x4 hreg[2][4];
+    u32x4 hreg[2][4][SV];
     int set_m0[2] = {0, 0}, set_cc[2] = {0, 0};
     unsigned set_zero[2] = {0u, 0u};                           // IM: bit i = staged vector i lies outside the image
     bool set_ok[2] = {false, false};
@@ -108,18 +115,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
     // the block's items are G apart and G % n_slices == 0, so the tile advances by a constant
     const int m0_step = (G / p.n_slices) * 128;
     int st_m0 = (item / p.n_slices) * 128, cur_m0 = st_m0;
-    auto issue = [&](int S) __attribute__((always_inline)) {
-        set_ok[S] = st_valid;
+    auto issue = [&](int S_) __attribute__((always_inline)) {
+        set_ok[S_] = st_valid;
         if (!st_valid) return;
         const int m0 = st_m0;
         const int c = st_chunk * 64 + cv * 8;
         const int cc = c < ctot ? c : 0;                        // zero-weight padding: any finite data will do
-        const E* src;
+        const S* src;
         int cs;
-        if (cc < p.C0) { src = reinterpret_cast<const E*>(p.src0) + cc; cs = p.C0; }
-        else           { src = reinterpret_cast<const E*>(p.src1) + (cc - p.C0); cs = p.C1; }
-        set_m0[S] = m0;
-        set_cc[S] = cc;
+        if (cc < p.C0) { src = reinterpret_cast<const S*>(p.src0) + cc; cs = p.C0; }
+        else           { src = reinterpret_cast<const S*>(p.src1) + (cc - p.C0); cs = p.C1; }
+        set_m0[S_] = m0;
+        set_cc[S_] = cc;
         if (IM) {
             const int tap = st_chunk * 8 + cv;                  // k = 8*tap + channel: this thread's vector is one tap of one pixel
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -141,40 +148,69 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 const bool ok = tap < 9 && yy >= 0 && yy < p.im_H && xx >= 0 && xx < p.im_W;
                 zero |= ok ? 0u : (1u << i);
                 const int ms = ok ? m + dy * p.im_W + dx : m;
-                hreg[S][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.src0) + (size_t)ms * 8);
+                hreg[S_][i][0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.src0) + (size_t)ms * 8);
             }
-            set_zero[S] = zero;
+            set_zero[S_] = zero;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int m = m0 + i * 32 + px_l;
                 m = m < p.M ? m : p.M - 1;
-                if (G1_ABL != 1) hreg[S][i] = *reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
+                if (G1_ABL != 1) {
+                    const u32x4* sv = reinterpret_cast<const u32x4*>(src + (size_t)m * cs);
+#pragma unroll
+                    for (int h = 0; h < SV; ++h) hreg[S_][i][h] = sv[h];
+                }
             }
         }
         if (++st_chunk == p.nch) { st_chunk = 0; st_item += G; st_m0 += m0_step; }
         st_valid = st_item < p.total_items;
     };
     unsigned abh[2][8];                                         // GroupNorm (scale, shift), fp16x2, for pixel halves 0-63 / 64-127
-    auto params_fetch = [&](int S) __attribute__((always_inline)) {
-        if (XF == XF_NONE || !set_ok[S]) return;
+    float gsc[F32 ? 2 : 1][8], gsh[F32 ? 2 : 1][8];             // fp32 form: the fp32 pairs
+    auto params_fetch = [&](int S_) __attribute__((always_inline)) {
+        if (XF == XF_NONE || !set_ok[S_]) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            int m = set_m0[S] + 64 * h;
+            int m = set_m0[S_] + 64 * h;
             m = m < p.M ? m : p.M - 1;
             const int b = m / p.HW;
             const int nb = p.M / p.HW;                          // fp16x2 half of the GroupNorm table (conv_v2.h: gn_params)
-            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * nb * ctot + (size_t)b * ctot + set_cc[S]);
+            if constexpr (F32) {
+                const f32x4* tf = p.gn_ab + (((size_t)b * ctot + set_cc[S_]) >> 1);
+                f32x4 r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = tf[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { gsc[h][2 * k] = r[k][0]; gsh[h][2 * k] = r[k][1]; gsc[h][2 * k + 1] = r[k][2]; gsh[h][2 * k + 1] = r[k][3]; }
+                continue;
+            }
+            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)2 * nb * ctot + (size_t)b * ctot + set_cc[S_]);
             const u32x4 lo = t[0], hi = t[1];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { abh[h][k] = lo[k]; abh[h][4 + k] = hi[k]; }
         }
     };
-    auto commit = [&](int S, int i, int buf) __attribute__((always_inline)) {
-        if (!set_ok[S]) return;
-        u32x4 raw = hreg[S][i];
+    auto commit = [&](int S_, int i, int buf) __attribute__((always_inline)) {
+        if (!set_ok[S_]) return;
+        if constexpr (F32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = __uint_as_float(hreg[S_][i][0][k]); v[4 + k] = __uint_as_float(hreg[S_][i][1][k]); }
+            if (XF != XF_NONE) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], gsc[i >> 1][k], gsh[i >> 1][k]);
+            }
+            x8 o, ol;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { o[k] = (E)v[k]; ol[k] = (E)(v[k] - (float)o[k]); }
+            *reinterpret_cast<x8*>(xt + buf * BUFE + hv0 + i * 32 * PSTR) = o;
+            *reinterpret_cast<x8*>(xt + buf * BUFE + TILE + hv0 + i * 32 * PSTR) = ol;
+            return;
+        }
+        u32x4 raw = hreg[S_][i][0];
         if (IM) {
-            const bool z = (set_zero[S] >> i) & 1u;
+            const bool z = (set_zero[S_] >> i) & 1u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) raw[k] = z ? 0u : raw[k];
         }
@@ -190,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             x8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (E)EL::sat(v[k]);       // (GroupNorm affine without an activation: not bounded)
-            *reinterpret_cast<x8*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = o;
+            *reinterpret_cast<x8*>(xt + buf * BUFE + hv0 + i * 32 * PSTR) = o;
         } else {
-            *reinterpret_cast<u32x4*>(xt + buf * TILE + hv0 + i * 32 * PSTR) = raw;
+            *reinterpret_cast<u32x4*>(xt + buf * BUFE + hv0 + i * 32 * PSTR) = raw;
         }
     };
 
@@ -221,14 +257,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
             // chunk after that into set PAR (whose previous content was committed one body ago)
             auto body = [&](auto par_tag) __attribute__((always_inline)) {
                 constexpr int PAR = decltype(par_tag)::value;
-                const E* hb = xt + PAR * TILE;
+                const E* hb = xt + PAR * BUFE;
                 params_fetch(PAR ^ 1);                          // before the data requests: a later wait for the parameters then
                 issue(PAR);                                     // leaves those (and the weight ring) in flight
-                x8 a[3][MR];
+                x8 a[3][MR], a_lo[F32 ? 3 : 1][MR];
                 auto a_fetch = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        if (G1_ABL != 4) a[u % 3][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + u * 16);
+                        if (G1_ABL != 4) {
+                            a[u % 3][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + u * 16);
+                            if constexpr (F32) a_lo[u % 3][mr] = *reinterpret_cast<const x8*>(hb + TILE + abase[mr] + u * 16);
+                        }
                 };
                 a_fetch(0);
                 a_fetch(1);
@@ -249,6 +288,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[kk % 3][mr], fring_lo[NP == 2 ? u % 8 : 0], acc[mr]);
                     }
+                    if constexpr (F32) {                        // third pass: the activations' low halves on the weights' high halves
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a_lo[kk % 3][mr], fring[u % 8], acc[mr]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk == 1) { commit(PAR ^ 1, 0, PAR ^ 1); commit(PAR ^ 1, 1, PAR ^ 1); }
                     if (kk == 2) { commit(PAR ^ 1, 2, PAR ^ 1); commit(PAR ^ 1, 3, PAR ^ 1); }
@@ -262,7 +305,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
         // ---- epilogue: buffer 1 is free (the last chunk of an item has odd parity), buffer 0 holds the next item's chunk 0
         const int m0 = cur_m0;
         cur_m0 += m0_step;
-        E* scr = xt + TILE + wave * (64 * SCR_STR);
+        // 16-bit: the patch sits in buffer 1 (free here); fp32 form: 4-byte patches in a region of their own behind the buffers
+        S* scr = (F32 ? reinterpret_cast<S*>(xt + 2 * BUFE) : reinterpret_cast<S*>(xt + TILE)) + wave * (64 * SCR_STR);
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
@@ -276,11 +320,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
                 if (mp >= p.M) break;
                 const size_t obase = (size_t)mp * p.Cout + n0 + wn * 32;
                 const unsigned lane_el = (unsigned)(pl0 * p.Cout + cq * 8);
-                x8 rv[RES ? 4 : 1];
+                x8 rv[(RES && !F32) ? 4 : 1];
+                f32x4 rvf[(RES && F32) ? 4 : 1][2];
                 if (RES) {
 #pragma unroll
                     for (int v4 = 0; v4 < 4; ++v4)
-                        if (v4 < 2 * nm) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + obase + (size_t)16 * v4 * p.Cout + lane_el);
+                        if (v4 < 2 * nm) {
+                            const S* rp = reinterpret_cast<const S*>(p.res) + obase + (size_t)16 * v4 * p.Cout + lane_el;
+                            if constexpr (F32) { rvf[RES ? v4 : 0][0] = *reinterpret_cast<const f32x4*>(rp); rvf[RES ? v4 : 0][1] = *reinterpret_cast<const f32x4*>(rp + 4); }
+                            else rv[RES ? v4 : 0] = *reinterpret_cast<const x8*>(rp);
+                        }
                 }
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
@@ -288,9 +337,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 #pragma unroll
                     for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
                         const int row = (j & 3) + 8 * (j >> 2);
-                        const x2 pr = cvt_pair<E>(acc[g + m2][j] + bias, acc[g + m2][j + 1] + bias);
-                        scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
-                        scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
+                        if constexpr (F32) {
+                            scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = acc[g + m2][j] + bias;
+                            scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = acc[g + m2][j + 1] + bias;
+                        } else {
+                            const x2 pr = cvt_pair<E>(acc[g + m2][j] + bias, acc[g + m2][j + 1] + bias);
+                            reinterpret_cast<E*>(scr)[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
+                            reinterpret_cast<E*>(scr)[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
+                        }
                     }
                 }
                 float vs1[8], vs2[8];
@@ -299,19 +353,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
                     if (v4 >= 2 * nm) break;
-                    const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
                     float f[8];
+                    if constexpr (F32) {
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
+                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8 + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { f[k] = r0[k]; f[4 + k] = r1[k]; }
+                        if (RES) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) f[k] = fmaf(p.res_scale, f[k], rvf[RES ? v4 : 0][k >> 2][k & 3]);
+                        }
+                        f32x4 o0, o1;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { o0[k] = f[k]; o1[k] = f[4 + k]; }
+                        S* op = reinterpret_cast<S*>(p.out) + obase + (size_t)16 * v4 * p.Cout + lane_el;
+                        if (G1_ABL != 6) { *reinterpret_cast<f32x4*>(op) = o0; *reinterpret_cast<f32x4*>(op + 4) = o1; }
+                    } else {
+                    const x8 raw = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(scr) + (pl0 + 16 * v4) * SCR_STR + cq * 8);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) f[k] = (float)raw[k];
                     x8 o = raw;
                     if (RES) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
+                            f[k] = fmaf(p.res_scale, f[k], (float)rv[RES ? v4 : 0][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
                             o[k] = (E)EL::sat(f[k]);
                         }
                     }
                     if (G1_ABL != 6) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
                 }
@@ -339,12 +409,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_g_kernel(const C1gParams p) {
 }
 
 
-template <int BN, int XF, int IM, typename E, int NP>
+template <int BN, int XF, int IM, typename E, int NP, bool F32 = false>
 static int run_g1(C1gParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * 128 * 72 * 2 + 2048;
+    constexpr size_t lds = F32 ? (size_t)2 * 2 * 128 * 72 * 2 + (size_t)4 * 64 * 40 * 4 : (size_t)2 * 128 * 72 * 2 + 2048;
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP>, lds)) return rc;
-    const int g1_slots = 2 * device_cus();
+    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP, F32>, lds)) return rc;
+    const int g1_slots = (F32 ? 1 : 2) * device_cus();
     p.n_slices = p.Cout_pad / BN;
     p.m_tiles = (p.M + 127) / 128;
     p.total_items = p.m_tiles * p.n_slices;
@@ -353,8 +423,14 @@ static int run_g1(C1gParams& p, hipStream_t s) {
     const int slots = g1_slots;
     int G = (p.total_items < slots ? p.total_items : slots) / lcm * lcm;
     if (G == 0) G = p.total_items;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM, E, NP>), dim3(G), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM, E, NP, F32>), dim3(G), dim3(256), lds, s, p);
     return (int)hipGetLastError();
+}
+
+static int dispatch_g1_f32(int bn, int xf, C1gParams& p, hipStream_t s) {
+    if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE, 0, bf16, 2, true>(p, s) : run_g1<128, XF_AFFINE, 0, bf16, 2, true>(p, s);
+    if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE, 0, bf16, 2, true>(p, s) : run_g1<64, XF_AFFINE, 0, bf16, 2, true>(p, s);
+    return HSIDM_E_UNSUPPORTED;
 }
 
 template <typename E, int NP>
@@ -371,7 +447,8 @@ static int dispatch_g1(int bn, int xf, int im, C1gParams& p, hipStream_t s) {
 
 // bn: 64 or 128 (Cout % bn == 0); xf: XF_NONE or XF_AFFINE; HW % 64 == 0; nch even.
 // im_W > 0: 3x3 conv of an 8-channel input as a tap-major GEMM (C0 = 8, C1 = 0, xf = XF_NONE, nch = 2).
-// elem: 0 bf16, 1 fp16 (the bf16-typed pointers are then fp16 data); w_lo != null (fp16 only): second pass on the weights' low halves
+// elem: 0 bf16, 1 fp16 (the bf16-typed pointers are then fp16 data), 2 the fp32 mode (fp32 tensors, bf16 hi + lo weights: w_lo required);
+// w_lo != null (fp16): second pass on the weights' low halves
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w, const bf16* w_lo,
                   int elem, const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
                   int nch, int im_H, int im_W, hipStream_t s) {
@@ -384,6 +461,7 @@ int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, in
     p.gn_ab = reinterpret_cast<const f32x4*>(gn_ab);
     p.w = w; p.w_lo = w_lo; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
     p.M = M; p.HW = HW; p.Cout = Cout; p.Cout_pad = Cout; p.nch = nch;
+    if (elem == 2) return (w_lo && im_W <= 0) ? dispatch_g1_f32(bn, xf, p, s) : HSIDM_E_UNSUPPORTED;
     if (elem == 0) return w_lo ? HSIDM_E_UNSUPPORTED : dispatch_g1<bf16, 1>(bn, xf, im_W > 0, p, s);
     if (elem == 1) return w_lo ? dispatch_g1<f16, 2>(bn, xf, im_W > 0, p, s) : dispatch_g1<f16, 1>(bn, xf, im_W > 0, p, s);
     return HSIDM_E_UNSUPPORTED;

@@ -56,9 +56,12 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
         lay["w_v2"] = PackedConv._lanes(lay["w"], cpad)         # read by the split-K kernel only (conv_sk.hip: projection chunks)
     # fp32 mode: the persistent 3x3 kernel has an fp32 form too (conv_v2.h, AP = 2: fp32 storage, hi + lo operands); it reads the same
     # register-streaming order with 64-channel steps
-    f32_v2 = (not b16) and proj_weight is None and kh == 3 and not out_nchw and bn in (64, 128)
+    f32_v2 = (not b16) and proj_weight is None and not out_nchw and bn in (64, 128) and (kh == 3 or cout % bn == 0)
     if f32_v2:
-        lay["w_v2"] = PackedConv._lanes(PackedConv._steps(weight, cpad, 64).contiguous(), cpad)
+        wv = PackedConv._steps(weight, cpad, 64).contiguous()
+        if kh == 1 and wv.shape[0] % 2:          # 1x1 GEMM kernel (conv1x1_g.hip): K padded to a multiple of 128
+            wv = torch.cat([wv, torch.zeros_like(wv[:1])], dim=0)
+        lay["w_v2"] = PackedConv._lanes(wv, cpad)
     if b16 and proj_weight is None and (not out_nchw or (kh == 3 and bn == 32)):
         wv = lay["w"]
         meta["tap_major"] = kh == 3 and cin == 8

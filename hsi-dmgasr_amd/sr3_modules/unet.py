@@ -197,15 +197,15 @@ class ResnetBlock(_HipModule):
         else:
             h = self.block1._run(x0, precision, x1=x1, film=film)
         if isinstance(self.res_conv, nn.Conv2d):
-            if is_16bit(precision) and ops.use_v2():
-                # throughput mode: the persistent 3x3 kernel is single-phase; the 1x1 projection is its own launch and enters
-                # block2's epilogue as the residual.  (Measured and dropped, round 2: running it on a second stream beside block1's
+            if ops.use_v2():
+                # the persistent 3x3 kernel is single-phase (in every mode: the fp32 mode has its forms of it and of the 1x1 GEMM since
+                # round 3); the 1x1 projection is its own launch and enters block2's epilogue as the residual.  (Measured and dropped, round 2: running it on a second stream beside block1's
                 # convolution - a parallel branch of the captured step - at batches that leave workgroup slots free: the fork / join
                 # costs more than the overlap returns, 2.98 vs 2.83 ms per step at 5 latents, 5.03 vs 4.93 at 40, in-box A/B.)
                 # Few pixel tiles and a long contraction (one or two CAVE images per GPU on the 32x32 ... 8x8 levels): block2 runs in
                 # its split-K form, where the projection is a few more one-tap chunks of the same launch.
                 B, H, W, _ = h.shape
-                if B * H * W <= 16384 and h.shape[3] % 128 == 0 and h.shape[3] >= 256:
+                if is_16bit(precision) and B * H * W <= 16384 and h.shape[3] % 128 == 0 and h.shape[3] >= 256:
                     out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, sk_only=True)
                     if out is not None:
                         return out

@@ -93,8 +93,8 @@ def test_conv_kernel_against_fp32_torch(dev, mode, case):
     finally:
         ops.set_conv_probe(None)
     got_label = recs[-1]["kernel"]
-    if mode == "fp32":       # the fp32 mode: 3x3 convs on the persistent kernel's fp32 form (128- / 64-cout tiles), 1x1 on the LDS-tiled kernel
-        want = "conv_igemm" if ks == 1 else ("conv_v2 bn64" if C0 + C1 == 8 else label.replace("bn256", "bn128").replace("conv_v3 bn64", "conv_v2 bn64"))
+    if mode == "fp32":       # the fp32 mode: the fp32 forms of the persistent 3x3 kernel (128- / 64-cout tiles) and of the 1x1 GEMM
+        want = "conv_v2 bn64" if C0 + C1 == 8 else label.replace("bn256", "bn128").replace("conv_v3 bn64", "conv_v2 bn64")
     else:
         want = label.replace("bn256", "bn128") if mode == "fp16x2" else label      # hi + lo weights: no 256-cout items
     assert want in got_label, (want, got_label)

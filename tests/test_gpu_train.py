@@ -411,25 +411,45 @@ def test_captured_training_step_replays_correctly(dev):
 
 def test_full_size_training_step_gradients(dev):
     """The shipped 97.8 M-parameter UNet, one training step's gradients in fp32 mode at B = 1, 128 x 128 (BASELINE configs[4]'s
-    network) against the oracle's autograd on the host; and the bf16 mode's deviation from it, logged and bounded."""
+    network) against the oracle's autograd on the host; and the bf16 mode's deviation from it, logged and bounded.
+
+    Both losses.  L2 is the smooth one: its gate is the plain 1e-3.  The reference's L1 objective (config: "loss_type": "l1") has a
+    DISCONTINUOUS gradient, d|noise - eps| = -sign(noise - eps): wherever the device's eps and the oracle's (1e-5 apart in fp32 mode)
+    lie on opposite sides of the noise, one of the 49 152 entries of dL/deps flips - 2 / sqrt(49 152) = 0.9 % of its norm, i.e. ~1e-3
+    on every parameter's gradient - and whether that happens depends on the last bits of eps (it did when the 1x1 convolutions moved
+    to another fp32 kernel in round 3).  So the L1 gate counts those crossings on the two eps tensors and allows what they explain."""
     from oracle import train as otrain
     cfg = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8], attn_res=[16],
                res_blocks=2, image_size=128)
     hr, sr, noise = (torch.from_numpy(synth_tensor("gfull.%s" % n, (1, 3, 128, 128))) for n in ("hr", "sr", "noise"))
     gamma = torch.tensor([0.45])
-    grads = None
-    for prec in PRECS:
-        sd, gd, tr = build(cfg, "full", "l1", prec, dev, True)
-        loss = tr.loss_and_grads({"HR": hr.to(dev), "SR": sr.to(dev)}, noise=noise.to(dev), gamma=gamma)
-        if grads is None:
-            want_loss, grads = otrain.loss_and_grads(sd, cfg, hr, sr, noise, gamma, "l1", 0.2, otrain.drop_key(9, 0))
-        worst, wname, total = grad_errors(tr, grads, prec)
-        log_err("grads_full_unet_b1", prec, total, {"worst_param": wname, "worst_param_err": worst,
-                                                    "loss_rel_err": abs(float(loss) - want_loss) / abs(want_loss)})
-        assert abs(float(loss) - want_loss) < TOL[prec] * abs(want_loss)
-        assert total < (1e-3 if prec == "fp32" else 4e-2), (prec, total, worst, wname)
-        del tr, gd
-        torch.cuda.empty_cache()
+    for kind in ("l2", "l1"):
+        grads = None
+        for prec in PRECS:
+            sd, gd, tr = build(cfg, "full", kind, prec, dev, True)
+            loss_sum, state = tr.forward_loss({"HR": hr.to(dev), "SR": sr.to(dev)}, noise=noise.to(dev), gamma=gamma)
+            scale = 1.0 / float(state[2])
+            tr.backward_loss(state, scale)
+            loss = float(loss_sum) * scale
+            eps_dev = state[1].float().cpu()
+            if grads is None:
+                want_loss, grads = otrain.loss_and_grads(sd, cfg, hr, sr, noise, gamma, kind, 0.2, otrain.drop_key(9, 0))
+                with torch.no_grad():
+                    g4 = gamma.view(1, 1, 1, 1)
+                    eps_ref = otrain.unet_forward_train(sd, cfg, torch.cat([sr, g4 * hr + (1 - g4 ** 2).sqrt() * noise], dim=1), gamma.view(1, 1),
+                                                        0.2, otrain.drop_key(9, 0))
+            flips = int((torch.sign(noise - eps_dev) != torch.sign(noise - eps_ref)).sum()) if kind == "l1" else 0
+            worst, wname, total = grad_errors(tr, grads, prec)
+            log_err("grads_full_unet_b1_" + kind, prec, total, {"worst_param": wname, "worst_param_err": worst, "sign_crossings": flips,
+                                                               "loss_rel_err": abs(loss - want_loss) / abs(want_loss)})
+            assert abs(loss - want_loss) < TOL[prec] * abs(want_loss)
+            if prec == "fp32":
+                assert flips <= 3, flips                                        # (eps itself is within 1e-5: crossings are rare events)
+                assert total < 1e-3 + 2.0 * (flips / noise.numel()) ** 0.5, (kind, total, flips, worst, wname)
+            else:
+                assert total < 4e-2, (kind, prec, total, worst, wname)
+            del tr, gd
+            torch.cuda.empty_cache()
 
 
 def test_deferred_weight_gradient_reductions_match_the_immediate_ones(dev):
