@@ -374,6 +374,189 @@ static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStre
     return (int)hipGetLastError();
 }
 
+// ---- attention_v2, fp32 mode (fp32 storage; every operand as bf16 hi + lo, three MFMAs per product) ------------------
+// The structure of attention_v2_kernel with the split done where the operand is produced: K and V chunks are split at the commit into
+// a hi and a lo image in LDS (32-channel chunks: both images of both buffers are 96 KiB at 256 keys, one workgroup per CU), the Q
+// fragments are split in registers as they arrive, the probabilities are split in the registers their scores occupied.  Replaces the
+// score-panel kernel above for the UNet's shapes in the fp32 mode (6 launches x 775 us of a 66.7 ms step at 240 images).
+template <int NKT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void attention_v2_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, float scale) {
+    using bx8 = typename Elem<bf16>::x8;
+    using bx4 = typename Elem<bf16>::x4;
+    constexpr int N = 32 * NKT, T = 64 * NW, CH = 32, NV = N * (CH / 4) / T;
+    // bf16 per key row: 80 B for the K image (ds_read_b128 fragments: an odd multiple of 16 B), 96 B for the V image (transposed reads:
+    // the four key rows of a 16-lane group start 24 banks apart, eight banks each - conflict-free)
+    constexpr int KRS = 40, VRS = 48;
+    constexpr int IMG = N * VRS, BUFE = 2 * IMG;                       // [hi | lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* buf = reinterpret_cast<bf16*>(smem_raw);                     // [2][BUFE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y, q0 = blockIdx.x * 32 * NW + 32 * wave;
+    const size_t row3 = (size_t)3 * C;
+    const float* base = qkv + (size_t)b * N * row3;
+    const int nch = C / CH;
+
+    f32x4 hreg[NV];
+    auto issue = [&](int chunk, int third) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * T;
+            hreg[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(v >> 3) * row3 + third * C + chunk * CH + (v & 7) * 4);
+        }
+    };
+    auto commit = [&](int bi, int rs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * T;
+            bx4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (bf16)hreg[i][e];
+                lo[e] = (bf16)(hreg[i][e] - (float)hi[e]);
+            }
+            bf16* dst = buf + bi * BUFE + (v >> 3) * rs + (v & 7) * 4;
+            *reinterpret_cast<bx4*>(dst) = hi;
+            *reinterpret_cast<bx4*>(dst + IMG) = lo;
+        }
+    };
+    auto split8 = [&](const f32x4& x, const f32x4& y, bx8& hi, bx8& lo) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (bf16)x[e];
+            lo[e] = (bf16)(x[e] - (float)hi[e]);
+            hi[4 + e] = (bf16)y[e];
+            lo[4 + e] = (bf16)(y[e] - (float)hi[4 + e]);
+        }
+    };
+
+    // ---- phase 1: S^T[key][query] = K Q^T ---------------------------------------------------------------------------------------
+    const float* qrow = base + (size_t)(q0 + lr) * row3 + 8 * lh;
+    f32x4 qraw[2][2];
+    bx8 qh[2], ql[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        qraw[kk][0] = *reinterpret_cast<const f32x4*>(qrow + kk * 16);
+        qraw[kk][1] = *reinterpret_cast<const f32x4*>(qrow + kk * 16 + 4);
+    }
+    issue(0, 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) split8(qraw[kk][0], qraw[kk][1], qh[kk], ql[kk]);
+    commit(0, KRS);
+    __syncthreads();
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[kt][j] = 0.f;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool more = chunk + 1 < nch;
+        if (more) {
+            issue(chunk + 1, 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                qraw[kk][0] = *reinterpret_cast<const f32x4*>(qrow + (chunk + 1) * CH + kk * 16);
+                qraw[kk][1] = *reinterpret_cast<const f32x4*>(qrow + (chunk + 1) * CH + kk * 16 + 4);
+            }
+        }
+        const bf16* kb = buf + (chunk & 1) * BUFE + lr * KRS + 8 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const bx8 ah = *reinterpret_cast<const bx8*>(kb + kt * 32 * KRS + kk * 16);
+                const bx8 al = *reinterpret_cast<const bx8*>(kb + IMG + kt * 32 * KRS + kk * 16);
+                sc[kt] = Elem<bf16>::mfma(al, qh[kk], sc[kt]);
+                sc[kt] = Elem<bf16>::mfma(ah, ql[kk], sc[kt]);
+                sc[kt] = Elem<bf16>::mfma(ah, qh[kk], sc[kt]);
+            }
+        if (more) {
+            commit((chunk + 1) & 1, KRS);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) split8(qraw[kk][0], qraw[kk][1], qh[kk], ql[kk]);
+        }
+        __syncthreads();
+    }
+
+    // ---- exact softmax over the keys of this lane's query (fp32) -----------------------------------------------------------------
+    issue(0, 2);
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sc[kt][j] *= scale; m = fmaxf(m, sc[kt][j]); }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sc[kt][j] = __expf(sc[kt][j] - m); sum += sc[kt][j]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    bx8 ph[NKT][2], pl[NKT][2];                            // P^T fragments, hi and lo (attention_v2_kernel: k order of an accumulator tile)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = sc[kt][8 * st + j] * inv;
+                ph[kt][st][j] = (bf16)pv;
+                pl[kt][st][j] = (bf16)(pv - (float)ph[kt][st][j]);
+            }
+    commit(0, VRS);
+    __syncthreads();
+
+    // ---- phase 2: O^T[channel][query] = V^T P^T, 32 channels per chunk ----------------------------------------------------------
+    const int gi = lane & 15;
+    const int tr_lane = (4 * lh + (gi >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (gi & 3);
+    float* orow = out + ((size_t)b * N + q0 + lr) * C + 4 * lh;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool more = chunk + 1 < nch;
+        if (more) issue(chunk + 1, 2);
+        const bf16* vb = buf + (chunk & 1) * BUFE + tr_lane;
+        f32x16 o;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const bf16* a0 = vb + (kt * 32 + st * 16) * VRS;
+                const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 8 * VRS));
+                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + IMG));
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + IMG + 8 * VRS));
+                const s16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const s16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                o = Elem<bf16>::mfma(__builtin_bit_cast(bx8, vl), ph[kt][st], o);
+                o = Elem<bf16>::mfma(__builtin_bit_cast(bx8, vh), pl[kt][st], o);
+                o = Elem<bf16>::mfma(__builtin_bit_cast(bx8, vh), ph[kt][st], o);
+            }
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+            const f32x4 w4 = {o[4 * jg], o[4 * jg + 1], o[4 * jg + 2], o[4 * jg + 3]};
+            *reinterpret_cast<f32x4*>(orow + chunk * CH + 8 * jg) = w4;
+        }
+        if (more) commit((chunk + 1) & 1, VRS);
+        __syncthreads();
+    }
+}
+
+template <int NKT, int NW>
+static int launch_attention_v2_f32(const void* qkv, void* out, int B, int C, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 2 * 32 * NKT * 48 * 2;
+    static PerDeviceOnce once;
+    if (int rc = raise_lds_cap(once, &attention_v2_f32_kernel<NKT, NW>, lds)) return rc;
+    dim3 grid(NKT / NW, B);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_f32_kernel<NKT, NW>), grid, dim3(64 * NW), lds, s, (const float*)qkv, (float*)out, C,
+                       1.0f / sqrtf((float)C));
+    return (int)hipGetLastError();
+}
+
 }  // namespace hsidm
 
 extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int N, int C, void* stream) {
@@ -389,6 +572,10 @@ extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int 
     }
     if (prec == HSIDM_F16) return hsidm::launch_attention<hsidm::f16, false, hsidm::f16>(qkv, out, B, N, C, (hipStream_t)stream);
     if (prec == HSIDM_BF16) return hsidm::launch_attention<hsidm::bf16, false>(qkv, out, B, N, C, (hipStream_t)stream);
+    if (prec == HSIDM_F32X3 && !hsidm::debug_get(hsidm::DBG_ATTENTION_V1)) {
+        if (N == 256) return hsidm::launch_attention_v2_f32<8, 4>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 64) return hsidm::launch_attention_v2_f32<2, 2>(qkv, out, B, C, (hipStream_t)stream);
+    }
     if (prec == HSIDM_F32X3) return hsidm::launch_attention<float, true>(qkv, out, B, N, C, (hipStream_t)stream);
     return HSIDM_E_BADARG;
 }

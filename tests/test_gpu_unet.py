@@ -367,6 +367,27 @@ def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
     check("attention_panel%s" % (shape,), "bf16", old.reshape(B, H * W, C), ref, tol=1e-2)
 
 
+
+@pytest.mark.parametrize("shape", [(3, 16, 16, 512), (5, 8, 8, 64), (2, 16, 16, 32), (260, 8, 8, 64), (136, 16, 16, 96), (1, 4, 8, 96)])
+def test_attention_core_fp32_mode(dev, shape):
+    """fp32 mode (fp32 storage, bf16 hi + lo operands, three MFMAs per product): the register-resident form (N = 64 / 256, C % 32 == 0)
+    and the score-panel kernel (other shapes, HSIDM_ATTENTION_V1=1) against torch in float64 on the same fp32 inputs; the two kernels
+    agree with each other to the rounding of the split."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    qkv = torch.randn(B, H, W, 3 * C, generator=g) * 1.5
+    q, k, v = qkv.double().reshape(B, H * W, 3, C).unbind(2)
+    ref = (torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v).float()
+    got = ops.attention(qkv.to(dev), "fp32")
+    torch.cuda.synchronize()
+    with _lib.debug_switch("ATTENTION_V1", 1):
+        old = ops.attention(qkv.to(dev), "fp32")
+        torch.cuda.synchronize()
+    check("attention_f32%s" % (shape,), "fp32", got.reshape(B, H * W, C), ref, tol=2e-5)
+    check("attention_f32_panel%s" % (shape,), "fp32", old.reshape(B, H * W, C), ref, tol=2e-5)
+
+
 CONV_CASES = [  # B, H, W, C0, C1, Cout, ups, proj_cin, xf
     (3, 16, 32, 64, 0, 128, False, 0, True),      # 8x16 tiles, BN=128, several items per block
     (2, 24, 40, 64, 32, 64, False, 0, True),      # concat input, BN=64, partial tiles

@@ -14,7 +14,7 @@ ap.add_argument("--batch", type=int, default=120)
 ap.add_argument("--reps", type=int, default=8)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-for mode, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+for mode, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16), ("fp32", torch.float32)):
     for hw, C in ((16, 512), (8, 512)):
         qkv = torch.randn(args.batch, hw, hw, 3 * C, device=dev).to(dt)
         best = 1e9

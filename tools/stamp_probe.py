@@ -27,9 +27,11 @@ def main():
     B = int(os.environ.get("HSIDM_PROBE_BATCH", "40"))
     g = torch.Generator().manual_seed(0)
     w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
-    pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), "bf16")
-    x0 = torch.randn(B, H, H, C0, generator=g).to(dev, torch.bfloat16)
-    x1 = torch.randn(B, H, H, C1, generator=g).to(dev, torch.bfloat16) if C1 else None
+    prec = os.environ.get("HSIDM_PROBE_PREC", "bf16")            # bf16 | fp16 (hi + lo weights where the policy says) | fp16x1
+    adt = torch.bfloat16 if prec == "bf16" else torch.float16
+    pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), prec)
+    x0 = torch.randn(B, H, H, C0, generator=g).to(dev, adt)
+    x1 = torch.randn(B, H, H, C1, generator=g).to(dev, adt) if C1 else None
     ab = ops.gn_table(torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev))
     xf = ops.XF_AFFINE_SILU if not up else ops.XF_NONE
     stamps = torch.zeros(512 * 4 * 8 * 16, dtype=torch.int64, device=dev)
