@@ -36,6 +36,8 @@ template <typename E> struct Elem;
 template <> struct Elem<bf16> {
     using x8 = bf16x8; using x4 = bf16x4; using x2 = bf16x2;
     static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    // 16x16x32: lane (c = lane % 16, g = lane / 16) holds A[row c][k 8g..8g+7], B[k 8g..8g+7][col c]; C register j = [row 4g + j][col c]
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
     static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
     static __device__ __forceinline__ float sat(float v) { return v; }
@@ -43,6 +45,7 @@ template <> struct Elem<bf16> {
 template <> struct Elem<f16> {
     using x8 = f16x8; using x4 = f16x4; using x2 = f16x2;
     static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
     static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
     static __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }

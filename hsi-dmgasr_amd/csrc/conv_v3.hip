@@ -13,6 +13,12 @@
 //     before the MFMA phase and held in registers through it; the overlap of one workgroup's transform/epilogue with
 //     MFMAs comes from the OTHER workgroup on the CU;
 //   * weights stream through conv_v2's 3-step register ring, epilogue / statistics / FiLM handling are conv_v2's.
+// Matrix instruction: v_mfma_f32_16x16x32 (round 3).  Same cycles per FLOP as the 32x32x16 form, but the chip holds a higher clock
+// on it under its power management (tools/ubench/mfma_shape.hip on this pool: 1 310 vs 1 150 TFLOP/s in a loop shaped like this
+// one, +14 %; MI355X_MICROARCH.md "DVFS give-back" item 7).  A 16-row A operand is ONE tile row of 16 pixels: lane (c = lane % 16,
+// g = lane / 16) reads channels 8g .. 8g+7 of the 32-channel slice of pixel column c; with 160-byte pixels the four 16-lane service
+// groups of a ds_read_b128 cover all 64 banks once at every tap (144-byte pixels would be 2-way).  The B operand (16 couts x 32
+// channels) is read from the SAME packed weight order as before - its 16-byte units are only addressed per lane differently.
 // Requirements (api.hip falls back to conv_v2 otherwise): Cout == 64, H % 16 == 0, W % 16 == 0, no upsampling.
 #include "conv_v2.h"
 #include <cstdlib>
@@ -23,8 +29,8 @@ namespace hsidm {
 namespace v3 {
 constexpr int TH = 16, TW = 16, BM = 256, BN = 64, BK = 64;
 constexpr int HROWS = TH + 2, HCOLS = TW + 2, HPIX = HROWS * HCOLS;      // 18 x 18
-constexpr int PSTR = BK + 8, VPP = BK / 8;
-constexpr int RP = 1408;                                                   // halo row pitch: 2816 B = 0 mod 256 (conv_v2.h)
+constexpr int PSTR = BK + 16, VPP = BK / 8;                                // 160-byte pixels (see above); the last 32 B are padding
+constexpr int RP = HCOLS * PSTR;                                           // halo row pitch
 constexpr int HVEC = HPIX * VPP, MAXHV = (HVEC + 255) / 256;               // 2592 vectors, 11 per thread
 constexpr int HALO_ELEMS = HROWS * RP;
 constexpr int SCR_STR = 40;                                                // bf16 per row of an epilogue patch: 32 couts + 16 B pad
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
     constexpr bool FRG = NP == 2;
-    constexpr int FS = 6, FL = 5;
+    constexpr int FS = 6, FL = 4;                               // a k-slice pair keeps its two fragments for both row halves: FL <= FS - 2
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* halo = reinterpret_cast<E*>(smem_raw);
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lc = lane & 15, lg = lane >> 4;                  // MFMA 16x16x32: row / column lc, k group lg
     const int G = gridDim.x;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     // tile index -> (image, tile row, tile column): shifts when the tile grid is a power of two (the UNet's maps are); a division by
@@ -74,8 +80,12 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 
     // ---- weight stream (conv_v2's order: [step = chunk*9 + tap][cout/32][kk][lane][8]) ----------------------------------
     const int nsw = p.Cout_pad >> 5;
-    const E* wlane = reinterpret_cast<const E*>(p.w) + ((size_t)wn * 4 * 64 + lane) * 8;
-    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + ((size_t)wn * 4 * 64 + lane) * 8;
+    // B operand (n, q) of a 32-cout slice: cout 16n + lc, channels 32q + 8 lg .. +7 = the 16-byte unit at fragment 2q + lg/2,
+    // lane 32 (lg % 2) + 16n + lc of the packed order; fragment index e = 2q + n below
+    const size_t wl_off = ((size_t)wn * 4 * 64 + (lg >> 1) * 64 + 32 * (lg & 1) + lc) * 8;
+    const E* wlane = reinterpret_cast<const E*>(p.w) + wl_off;
+    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + wl_off;
+    auto frag_off = [](int e) __attribute__((always_inline)) -> int { return (e >> 1) * (2 * 64 * 8) + (e & 1) * (16 * 8); };
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
     x8 ring[FRG ? 1 : 3][4];
     x8 fring[FRG ? FS : 1], fring_lo[FRG ? FS : 1];
@@ -83,11 +93,11 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     auto b_issue = [&](x8 (&dst)[4]) __attribute__((always_inline)) {
         const E* src = wlane + (size_t)wnext * wstep_stride;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + kk * 64 * 8);
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + frag_off(kk));
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
     auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
-        const size_t off = (size_t)wnext * wstep_stride + kk * 64 * 8;
+        const size_t off = (size_t)wnext * wstep_stride + frag_off(kk);
         fring[FRG ? slot : 0] = *reinterpret_cast<const x8*>(wlane + off);
         fring_lo[FRG ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + off);
         if (kk == 3) wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     };
     // dead slots of the last (partial) vector round store into the row padding instead of being branched around, so the
     // eleven transforms form one basic block the scheduler can interleave (conv_v2.h: dead_off)
-    const int dead_off = (tid % HROWS) * RP + HCOLS * PSTR + ((tid >> 5) % ((RP - HCOLS * PSTR) / 8)) * 8;
+    const int dead_off = (tid / HCOLS) * RP + (tid % HCOLS) * PSTR + BK;      // (the padding of halo pixel `tid`)
     auto commit_all = [&]() __attribute__((always_inline)) {
         int posv[MAXHV];                                        // table reads before the first halo store (they may alias for the compiler)
 #pragma unroll
@@ -179,13 +189,12 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         }
     };
 
-    // ---- MFMA fragment bases: MFMA tile mr = tile rows (16/WM) wm + 2 mr, +1; lane = (row lr/16, column lr%16) ------------------
+    // ---- MFMA fragment bases: pair mr = tile rows (16/WM) wm + 2 mr, +1 (one 16-row A operand each); lane = (column lc, k group lg) ----
     int abase[MR];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (16 / WM) + mr * 2 + (lr >> 4)) * RP + (lr & 15) * PSTR + 8 * lh;
-    f32x16 acc[MR];
+    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (16 / WM) + mr * 2) * RP + lc * PSTR + 8 * lg;
+    f32x4 acc[MR][2][2];                                        // [tile-row pair][row of the pair][16-cout half]
 
-    const int n = wn * 32 + lr;                                 // Cout == 64: every lane's cout exists
     auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
         float v;
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
@@ -212,14 +221,20 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         HSIDM_STAMP(it, 0);
         const int tile = tile_of(item);
         const int b = div_tpi(tile);
-        float ep_add = 0.f, ep_bias = 0.f;                      // landed by the epilogue (conv_v2.h: untracked loads)
-        {   // lane's channel from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
+        // landed by the epilogue (conv_v2.h: untracked loads); [16-cout half].  The loads are UNCONDITIONAL (an absent FiLM / bias
+        // vector reads a word of the weights and is discarded after the wait): a select on the result would read the register
+        // before the data has landed - the compiler does not know these registers are pending
+        float ep_add[2], ep_bias[2];
+        {   // lane's channels from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
             int lane_s = lane_id_now();
             asm volatile("" : "+v"(lane_s));
-            const int n_raw = wn * 32 + (lane_s & 31);
-            const int n_s = (!NCHW_ || n_raw < p.Cout) ? n_raw : 0;         // NCHW_: 3 of the slice's 32 couts exist
-            if (p.film) ep_add = untracked_load(p.film + (size_t)b * p.film_stride + n_s);
-            if (p.bias) ep_bias = untracked_load(p.bias + n_s);
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int n_raw = wn * 32 + 16 * nh + (lane_s & 15);
+                const int n_s = (!NCHW_ || n_raw < p.Cout) ? n_raw : 0;     // NCHW_: 3 of the slice's 32 couts exist
+                ep_add[nh] = untracked_load(p.film ? p.film + (size_t)b * p.film_stride + n_s : reinterpret_cast<const float*>(p.w));
+                ep_bias[nh] = untracked_load(p.bias ? p.bias + n_s : reinterpret_cast<const float*>(p.w));
+            }
         }
 
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -234,13 +249,15 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             lds_barrier();
             if (chunk == 0) HSIDM_STAMP(it, 3);
             HSIDM_SETPRIO(1);
+            // A operands: ring over the 36 sub-steps w = 4 tap + 2 q + r of the chunk (q: 32-channel slice of the tap, r: row of the
+            // tile-row pair); sub-step w runs 2 MR (x NP) MFMAs - both 16-cout halves on the slice's two weight fragments 4 tap + 2 q + n
             constexpr int AD = NP == 2 ? 2 : 3;                 // (conv_v2.h: one sub-step of lookahead when it carries twice the MFMAs)
             x8 a[AD][MR];
-            auto a_fetch = [&](int u) __attribute__((always_inline)) {
-                const int tp = u >> 2, kq = u & 3;
-                const int off = (tp / 3) * RP + (tp % 3) * PSTR + kq * 16;
+            auto a_fetch = [&](int w) __attribute__((always_inline)) {
+                const int tp = w >> 2;
+                const int off = (tp / 3 + (w & 1)) * RP + (tp % 3) * PSTR + ((w >> 1) & 1) * 32;
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[u % AD][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
+                for (int mr = 0; mr < MR; ++mr) a[w % AD][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
             };
             a_fetch(0);
             if (AD == 3) a_fetch(1);
@@ -249,21 +266,24 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 if (!FRG) b_issue(ring[(tap + 2) % 3]);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int u = tap * 4 + kk;
-                    if (u + AD - 1 < 36) a_fetch(u + AD - 1);
-                    if (FRG) f_issue((u + FL) % FS, (u + FL) % 4);
-                    if (u == 0 && chunk == 0) {
-                        // first k-slice of the item: C = 0 as the MFMA's inline constant instead of 64 v_mov per lane and item
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const int w = tap * 4 + kk, q = kk >> 1, r = kk & 1;
+                    if (w + AD - 1 < 36) a_fetch(w + AD - 1);
+                    if (FRG) f_issue((w + FL) % FS, (w + FL) % 4);
+                    const bool first = w < 2 && chunk == 0;     // first use of these accumulators: C = 0 as the MFMA's inline constant
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[0][mr], FRG ? fring[0] : ring[0][0], zero);
-                    } else {
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const int e = q * 2 + nh;               // weight fragment of the step
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], FRG ? fring[FRG ? u % FS : 0] : ring[FRG ? 0 : tap % 3][kk], acc[mr]);
+                        for (int mr = 0; mr < MR; ++mr)
+                            acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], FRG ? fring[FRG ? (tap * 4 + e) % FS : 0] : ring[FRG ? 0 : tap % 3][e], first ? zero : acc[mr][r][nh]);
                     }
                     if (NP == 2) {
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], fring_lo[FRG ? u % FS : 0], acc[mr]);
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr)
+                                acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], fring_lo[FRG ? (tap * 4 + q * 2 + nh) % FS : 0], acc[mr][r][nh]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -279,24 +299,31 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int tr = tile - b * tiles_per_img;
         const int try_e = div_tx(tr);
         const int oy0 = try_e * TH, ox0 = (tr - try_e * p.tiles_x) * TW;
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add), "+v"(ep_bias));       // older than the 8 weight + 11 halo requests in flight
-        ep_add += ep_bias;
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add[0]), "+v"(ep_add[1]), "+v"(ep_bias[0]), "+v"(ep_bias[1]));   // older than the 8 weight + 11 halo requests in flight
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) ep_add[nh] = (p.film ? ep_add[nh] : 0.f) + (p.bias ? ep_bias[nh] : 0.f);
         if constexpr (NCHW_) {
-            // fp32 NCHW straight from the accumulator layout: lane = cout (3 live lanes per half), register j = pixel row
-            // (j&3) + 8(j>>2) + 4(lane>>5) of the 32-pixel MFMA tile = two tile rows of 16
+            // fp32 NCHW straight from the accumulator layout: lane = cout 16 nh + lane % 16 (3 live lanes), the four registers of
+            // an accumulator = pixel columns 4 (lane / 16) .. + 3 of one tile row: one 16-byte store each
             int lane_o = lane_id_now();
             asm volatile("" : "+v"(lane_o));
-            const int n_o = lane_o & 31, lh_o = lane_o >> 5;
-            if (n_o < p.Cout) {
-                float* plane = reinterpret_cast<float*>(p.out) + ((size_t)b * p.Cout + n_o) * p.Hout * p.Wout;
+            const int c_o = lane_o & 15, g_o = lane_o >> 4;
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
+            for (int nh = 0; nh < 2; ++nh) {
+                const int n_o = 16 * nh + c_o;
+                if (n_o < p.Cout) {
+                    float* plane = reinterpret_cast<float*>(p.out) + ((size_t)b * p.Cout + n_o) * p.Hout * p.Wout;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int row = (j & 3) + 8 * (j >> 2) + 4 * lh_o;
-                        const int oy = oy0 + wm * (16 / WM) + mr * 2 + (row >> 4), ox = ox0 + (row & 15);
-                        plane[(size_t)oy * p.Wout + ox] = fmaf(acc[mr][j], kLn2, ep_add);
-                    }
+                    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int oy = oy0 + wm * (16 / WM) + mr * 2 + r;
+                            f32x4 o4;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o4[j] = fmaf(acc[mr][r][nh][j], kLn2, ep_add[nh]);
+                            *reinterpret_cast<f32x4*>(plane + (size_t)oy * p.Wout + ox0 + 4 * g_o) = o4;
+                        }
+                }
             }
             HSIDM_STAMP(it, 13);
             continue;                                                               // no transposition patch: no barrier
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
-        const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
+        const int lc_e = lane_e & 15, lg_e = lane_e >> 4;
         const unsigned lane_el = (unsigned)(pl0 * p.Cout + cq * 8);                // pass pixel (row v4, column pl0): row part is uniform
         const size_t row_stride = (size_t)p.Wout * p.Cout;
         const size_t item_base = (((size_t)b * p.Hout + oy0 + wm * (16 / WM)) * p.Wout + ox0) * p.Cout + wn * 32;
@@ -318,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             // owns one cout there, so 2 VALU per value and one exchange between the lane halves replace the unpacking of the
             // stored vectors and the 15-move butterfly (the rounding noise is zero-mean, 2^-9 relative: invisible to GroupNorm).
             // With a residual the stored sum only exists in the vector domain.
-            float as1 = 0.f, as2 = 0.f;
+            float as1[2] = {0.f, 0.f}, as2[2] = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
 #pragma unroll
@@ -332,20 +359,25 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                     for (int v4 = 0; v4 < 2; ++v4) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + vec_base(v4) + lane_el);
                 }
+                // patch row = 16 (row of the pair) + pixel column; the lane holds columns 4 lg .. + 3 of couts 16 nh + lc
 #pragma unroll
-                    for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
-                        const int row = (j & 3) + 8 * (j >> 2);
-                        float v[2];
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            v[e] = fmaf(acc[g][j + e], kLn2, ep_add);       // the staged activations carry log2(e) (silu_log2e)
-                            if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-                            if (!RES) { as1 += v[e]; as2 = fmaf(v[e], v[e], as2); }   // statistics in the accumulator layout (see below)
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {                        // columns j, j + 1: one packed conversion (cvt_pair)
+                            float v[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                v[e] = fmaf(acc[g][r][nh][j + e], kLn2, ep_add[nh]);   // the staged activations carry log2(e) (silu_log2e)
+                                if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+                                if (!RES) { as1[nh] += v[e]; as2[nh] = fmaf(v[e], v[e], as2[nh]); }   // statistics in the accumulator layout (see below)
+                            }
+                            const x2 pr = cvt_pair<E>(v[0], v[1]);
+                            const int at = (16 * r + 4 * lg_e + j) * SCR_STR + 16 * nh + lc_e;
+                            scr[at] = pr[0];
+                            scr[at + SCR_STR] = pr[1];
                         }
-                        const x2 pr = cvt_pair<E>(v[0], v[1]);
-                        scr[row * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
-                        scr[(row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
-                    }
 #pragma unroll
                 for (int v4 = 0; v4 < 2; ++v4) {
                     const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
@@ -368,9 +400,14 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 }
             }
             if (p.stats && !RES) {
-                const float a = as1 + lane_xor<32>(as1, lane_e), d = as2 + lane_xor<32>(as2, lane_e);
-                if (lh_e == 0)
-                    p.stats[((size_t)b * (tiles_per_img * WM) + tr * WM + wm) * p.Cout + wn * 32 + lr_e] = make_float2(a, d);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {                                    // the four lanes lg = 0..3 of a cout hold its column quarters
+                    float a = as1[nh] + lane_xor<16>(as1[nh], lane_e), d = as2[nh] + lane_xor<16>(as2[nh], lane_e);
+                    a += lane_xor<32>(a, lane_e);
+                    d += lane_xor<32>(d, lane_e);
+                    if (lg_e == 0)
+                        p.stats[((size_t)b * (tiles_per_img * WM) + tr * WM + wm) * p.Cout + wn * 32 + 16 * nh + lc_e] = make_float2(a, d);
+                }
             }
             if (p.stats && RES) {                                                   // one entry per (image, tile, pixel half)
                 const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
