@@ -23,6 +23,15 @@
 //
 // Tile: 128 output pixels (8x16 of one image, or 8x8 of two) x BN couts, 4 waves; wave tile =
 // (128/WM) pixels x 32 couts, WM x WN = 4, WN = BN/32.  K step = 64 input channels of one tap.
+//
+// Matrix instruction (round 3): v_mfma_f32_16x16x32.  It costs the same cycles per FLOP as the 32x32x16 form, but under the chip's
+// power management the clock held on it is higher (tools/ubench/mfma_shape.hip, a loop shaped like this one: 1 310 vs 1 150 TFLOP/s;
+// MI355X_MICROARCH.md "DVFS give-back" item 7) - and these kernels sit at that limit.  A 32-pixel x 32-cout block is four of them:
+// (16-pixel half r) x (16-cout half nh).  A operand of half r: lane (c = lane % 16, g = lane / 16) reads channels 8g .. 8g+7 of a
+// 32-channel slice of pixel c (one tile row of 16, or two of 8); pixels are 160 bytes apart and the row pitch of the 8-wide tile is
+// 1792 bytes, which makes the four 16-lane service groups of every ds_read_b128 cover all 64 banks once at every tap.  B operand
+// (nh, slice q): cout 16 nh + c, channels 32q + 8g .. +7 - a 16-byte unit of the SAME packed weight order as before (fragment
+// 2q + g/2, lane 32 (g%2) + 16 nh + c): no host-side change.  Sub-steps of a tap: kk = 2q + r, each 2 MR MFMAs (both cout halves).
 #pragma once
 #include "conv_igemm.h"
 
@@ -94,23 +103,23 @@ struct V2Cfg {
     static constexpr int NT = FR ? 4 : 9;                       // taps per channel chunk
     static constexpr bool FRG = FR || NP_ == 2;                 // weights through the fragment ring (else the 3-step ring)
     // ring slots / lookahead in k-slices; the slot count divides the k-slices of a chunk (16 | 36) so that every index is static
-    static constexpr int FS = FR ? (NP_ == 2 ? 4 : 8) : 6, FL = FR ? (NP_ == 2 ? 3 : 6) : 5;
+    // (a 32-channel slice keeps its two fragments through both of its sub-steps: FL <= FS - 2)
+    // (the fp32 form has one workgroup per CU and registers to spare: a deeper ring, ten / six fragments ahead)
+    static constexpr int FS = AP_ == 2 ? (FR ? 8 : 12) : (FR ? (NP_ == 2 ? 4 : 8) : 6), FL = AP_ == 2 ? FS - 2 : (FR ? (NP_ == 2 ? 2 : 6) : 4);
     static constexpr int BM = TH * TW * NI, BK = 64;           // 128 pixels; 64 for the one-image 8x8 tile (maps of 8x8 pixels
                                                                 // at batches too small to fill the GPU with two-image tiles)
     static_assert(BM == 128 || (BM == 64 && BN_ == 128), "tile");
     static constexpr int WN = BN / 32, WM = NW / WN, MR = BM / WM / 32;
     static constexpr int HROWS = TH + 2, HCOLS = TW + 2, HPIX = HROWS * HCOLS;
-    static constexpr int PSTR = BK + 8, VPP = BK / 8;
+    static constexpr int PSTR = BK + 16, VPP = BK / 8;          // 160-byte pixels (the last 32 B are padding; see the bank note above)
     static constexpr int HVEC = NI * HPIX * VPP;
     static constexpr int MAXHV = (HVEC + NTHR - 1) / NTHR;
     static constexpr int NH = FR ? MAXHV : 4;                   // raw staging registers (vectors in flight)
     static_assert(MAXHV <= 7, "one staged vector per tap 2..8");
     static_assert(!FR || XF_ == 0, "the up/downsample convs have no GroupNorm prologue");
-    // LDS pitch of one halo row (bf16 elements).  A wave's ds_read_b128 A-fragment covers 32 pixels = two tile rows of 16
-    // (or four of 8); with the natural pitch (18 pixels x 144 B = 2592 B) the second row lands 32 B off the 256-byte bank
-    // period and two lanes of every 16-lane service group hit the same banks (measured: SQ_LDS_BANK_CONFLICT = 48 % of
-    // SQ_LDS_IDX_ACTIVE).  A pitch of 0 (TW 16) / 128 (TW 8) bytes modulo 256 makes every group cover all 64 banks once.
-    static constexpr int RP = (TW == 16) ? 1408 : 832;
+    // LDS pitch of one halo row (elements).  TW = 16: an A operand is one tile row, any pitch serves; TW = 8: it is two tile rows
+    // of 8, conflict-free at 112 sixteen-byte units (searched: the only pitch in [100, 116] units that is, with 10-unit pixels).
+    static constexpr int RP = (TW == 16) ? HCOLS * PSTR : 896;
     static_assert(RP >= HCOLS * PSTR, "row pitch");
     static constexpr int HALO_ELEMS = NI * HROWS * RP;
     // two halo buffers + the per-thread table of halo positions (MAXHV packed ints per thread, see describe)
@@ -124,6 +133,10 @@ struct V2Cfg {
     static constexpr size_t PATCH_BYTES = (size_t)NW * 64 * 40 * sizeof(S_);
     static constexpr bool OWN_PATCH = NW == 8 || PATCH_BYTES > (size_t)AP * HALO_ELEMS * 2;
     static constexpr size_t LDS_BYTES = (size_t)2 * AP * HALO_ELEMS * 2 + POS_BYTES + (OWN_PATCH ? PATCH_BYTES : 0);
+    // depth of the A-operand ring in sub-steps (kernel: a_fetch).  Two where a sub-step carries twice the MFMAs (NP = 2) and on the
+    // two-image 128-cout GroupNorm form, where the third set made the allocator spill 37 registers (per-image FiLM / statistics
+    // registers on top of MR = 4) - and a spilled register of the untracked FiLM / bias prefetch is not an option (kernel: ep_add)
+    static constexpr int AD = (NP_ == 2 || (NI_ == 2 && XF_ != 0 && BN_ == 128 && NW_ == 4)) ? 2 : 3;
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
@@ -228,8 +241,8 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int wm = WM == 1 ? 0 : wave / WN, wn = wave % WN;    // (WM == 1: a constant, so that per-image arrays are indexed statically)
+    const int lc = lane & 15, lg = lane >> 4;                  // MFMA 16x16x32: row / column lc, k group lg
     const int G = gridDim.x;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int ctot = p.C0 + p.C1;
@@ -241,7 +254,9 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 
     // ---- weight stream: one contiguous 1 KiB per (step, 32-cout slice, kk) --------------------------------
     const int nsw = p.Cout_pad >> 5;
-    const size_t wlane_off = ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    // (per lane: the 16-byte unit (cout 16 nh + lc, channels 32q + 8 lg ..) of fragment e = 2q + nh sits at frag_off(e) behind this)
+    const size_t wlane_off = ((size_t)(ns * WN + wn) * 4 * 64 + (lg >> 1) * 64 + 32 * (lg & 1) + lc) * 8;
+    auto frag_off = [](int e) __attribute__((always_inline)) -> int { return (e >> 1) * (2 * 64 * 8) + (e & 1) * (16 * 8); };
     const E* wlane = reinterpret_cast<const E*>(p.w) + wlane_off;
     const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + wlane_off;
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
         const E* src = wlane + (size_t)wnext * wstep_stride;
         if (!(HSIDM_ABL(8))) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + kk * 64 * 8);
+            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + frag_off(kk));
         }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     x8 fring[FRG ? FS : 1], fring_lo[(FRG && NP == 2) ? FS : 1];
     auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
         if (!(HSIDM_ABL(8))) {
-            const size_t off = (size_t)(w_base + wnext) * wstep_stride + kk * 64 * 8;
+            const size_t off = (size_t)(w_base + wnext) * wstep_stride + frag_off(kk);
             fring[FRG ? slot : 0] = *reinterpret_cast<const x8*>(wlane + off);
             if (NP == 2) fring_lo[NP == 2 ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + off);
         }
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     };
     // dead slot of the last (partial) vector round: the store goes to the row padding instead of being branched around,
     // so that the commit stays in the MFMAs' basic block and the scheduler can interleave the two
-    const int dead_off = (tid % (NI * HROWS)) * RP + HCOLS * PSTR + ((tid >> 4) % ((RP - HCOLS * PSTR) / 8)) * 8;
+    const int dead_off = ((tid % (NI * HPIX)) / HCOLS) * RP + ((tid % (NI * HPIX)) % HCOLS) * PSTR + BK + 8 * ((tid / (NI * HPIX)) & 1);   // a pixel's padding
     // The commit of one staged vector is cut into four slices (two elements each) that ride in the four k-slices of a tap,
     // so that every scheduling region holds 4 MFMAs and ~1/4 of the transform instead of 16 MFMAs followed by a block of
     // 70 VALU instructions (a single wave then overlaps the two; measured with one workgroup per CU).
@@ -458,16 +473,17 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     };
 
     // ---- MFMA fragment bases --------------------------------------------------------------------------------------
-    int abase[MR];
+    int abase[MR];                                              // 16-pixel half r = 0 of the 32-pixel group mr; half 1 is RHALF further
+    constexpr int RHALF = (16 / TW) * RP;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-        const int pm = wm * (C::BM / WM) + mr * 32 + lr;
+        const int pm = wm * (C::BM / WM) + mr * 32 + lc;
         const int img = pm / (TH * TW);
         const int q = pm - img * (TH * TW);
         const int ty = q / TW, tx = q - ty * TW;
-        abase[mr] = (img * HROWS + ty) * RP + tx * PSTR + 8 * lh;
+        abase[mr] = (img * HROWS + ty) * RP + tx * PSTR + 8 * lg;
     }
-    f32x16 acc[MR];
+    f32x4 acc[MR][2][2];                                        // [32-pixel group][16-pixel half][16-cout half]
 
     // ---- staging cursor: the (item, chunk) whose halo tile is fetched next -------------------------------------------
     const int nch = p.nchunks;
@@ -503,8 +519,8 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     // compiler waited for them with s_waitcnt vmcnt(0) at the loop latch, i.e. for the acknowledgement of every output
     // store of the item, once per item.  vmcnt retires in order and a whole K loop of tracked weight loads follows, so
     // the values have long landed when the epilogue's own `s_waitcnt vmcnt(4)` names them.
-    const int n = n0 + wn * 32 + lr;
-    const bool nok = n < p.Cout;
+    const int n_lane = n0 + wn * 32 + lc;                       // couts n_lane, n_lane + 16
+    const bool nok[2] = {n_lane < p.Cout, n_lane + 16 < p.Cout};
     auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
         float v;
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
@@ -513,23 +529,28 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         HSIDM_STAMP(it, 0);
-        float ep_add[NI], ep_bias = 0.f;                       // landed by the epilogue (see above)
+        // landed by the epilogue (see above); [image][16-cout half].  The loads are UNCONDITIONAL - an absent FiLM / bias vector
+        // reads a word of the weights that is discarded after the wait: a select on the result would read the register before
+        // the data has landed (the compiler does not know these registers are pending)
+        float ep_add[NI][2], ep_bias[2];
         {
-            // the lane's channel is recomputed from the hardware lane id here: kept as a loop-invariant 64-bit address
+            // the lane's channels are recomputed from the hardware lane id here: kept as a loop-invariant 64-bit address
             // (p.film + n, p.bias + n) it was spilled, and each reload cost an s_waitcnt vmcnt(0) at the start of every item
             int lane_s = lane_id_now();
             asm volatile("" : "+v"(lane_s));
-            const int n_s = n0 + wn * 32 + (lane_s & 31);
-            const int nn = n_s < p.Cout ? n_s : 0;
             int par_;
             const int fb0 = div_tpi(item_tile(item, par_)) * NI;
 #pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
-                ep_add[q] = 0.f;
-                if (p.film) ep_add[q] = untracked_load(p.film + (size_t)fb * p.film_stride + nn);
+            for (int nh = 0; nh < 2; ++nh) {
+                const int n_s = n0 + wn * 32 + 16 * nh + (lane_s & 15);
+                const int nn = n_s < p.Cout ? n_s : 0;
+#pragma unroll
+                for (int q = 0; q < NI; ++q) {
+                    const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
+                    ep_add[q][nh] = untracked_load(p.film ? p.film + (size_t)fb * p.film_stride + nn : reinterpret_cast<const float*>(p.w));
+                }
+                ep_bias[nh] = untracked_load(p.bias ? p.bias + nn : reinterpret_cast<const float*>(p.w));
             }
-            if (p.bias) ep_bias = untracked_load(p.bias + nn);
         }
         if (UP4) {                                             // the ring wraps to the next item's weights during this item
             int par_nx;
@@ -543,15 +564,16 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
         HSIDM_SETPRIO(1);
         for (int chunk = 0; chunk < nch; ++chunk) {
             const E* hb = halo + cur * BUFE + par_off;
-            // A fragments: 3-deep register ring over the 4*NT (tap, k-slice) sub-steps of the chunk, fetched two
-            // sub-steps ahead (measured: with one sub-step of lookahead every k-slice waited ~300 cycles on LDS)
+            // A operands: 3-deep register ring over the 4*NT sub-steps u = 4 tap + 2 q + r of the chunk (q: 32-channel slice of the tap,
+            // r: 16-pixel half of every 32-pixel group), fetched two sub-steps ahead (measured: with one sub-step of lookahead every
+            // sub-step waited ~300 cycles on LDS).  Sub-step u runs 2 MR MFMAs: both 16-cout halves, on the weight fragments 2q + nh.
             // (NP = 2: a sub-step carries twice the MFMAs, so ONE sub-step of lookahead covers the same LDS latency and the ring is
             // two deep - 16 registers that the low-half weight fragments need)
-            constexpr int AD = NP == 2 ? 2 : 3;
+            constexpr int AD = C::AD;
             x8 a[AD][MR], a_lo[AP == 2 ? AD : 1][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
-                const int tp = u >> 2, kq = u & 3;
-                const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + kq * 16;
+                const int tp = u >> 2;
+                const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + ((u >> 1) & 1) * 32 + (u & 1) * RHALF;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     a[u % AD][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + off);
@@ -569,7 +591,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                 }
                 // Issue and commit are unconditional (past the last item they move stale but valid data into the unused
                 // buffer): no branch separates them from the MFMAs, and the group barriers below ask the scheduler for
-                // "1 MFMA, a few VALU, 1 LDS read" slices instead of 4 MFMAs back to back followed by a block of VALU.
+                // "2 MFMAs, a few VALU, 1 LDS read" slices instead of 8 MFMAs back to back followed by a block of VALU.
                 if (!FR) {
                     if (tap < MAXHV) halo_issue_one(tap);
                 } else if (tap < 2) {                          // 4 taps per chunk: vectors 0-3 at tap 0, the rest at tap 1
@@ -579,44 +601,50 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int u = tap * 4 + kk;
+                    const int u = tap * 4 + kk, q = kk >> 1, r = kk & 1;
                     if (u + AD - 1 < 4 * NT) a_fetch(u + AD - 1);
                     if (FRG) f_issue((u + FL) % FS, (u + FL) % 4);       // weights FL fragments ahead
                     if (!(HSIDM_ABL(16))) {
-                        if (!FR) {                             // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, k-slices 2-3)
+                        if (!FR) {                             // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, sub-steps 2-3)
                             if (tap >= 3 && tap - 3 < MAXHV) halo_commit_part(tap - 3, cur ^ 1, kk);
-                        } else if (tap >= 2 && (tap - 2) * 4 + kk < MAXHV) {   // one whole vector per k-slice, two taps after its issue
+                        } else if (tap >= 2 && (tap - 2) * 4 + kk < MAXHV) {   // one whole vector per sub-step, two taps after its issue
                             halo_commit_one((tap - 2) * 4 + kk, cur ^ 1);
                         }
                     }
-                    if (u == 0 && chunk == 0) {
-                        // first k-slice of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    // first sub-steps of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item
+                    const bool first = u < 2 && chunk == 0;
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[0][mr], FRG ? fring[0] : ring[0][0], zero);
-                    } else {
+                    for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], FRG ? fring[FRG ? u % FS : 0] : ring[FRG ? 0 : tap % 3][kk], acc[mr]);
-                    }
-                    if (NP == 2) {                             // second pass on the weights' low halves (MR MFMAs after the tile's first)
+                        for (int nh = 0; nh < 2; ++nh)
+                            acc[mr][r][nh] = EL::mfma16(a[u % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh],
+                                                        first ? zero : acc[mr][r][nh]);
+                    if (NP == 2) {                             // second pass on the weights' low halves
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[u % AD][mr], fring_lo[NP == 2 ? u % FS : 0], acc[mr]);
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a[u % AD][mr], fring_lo[NP == 2 ? (tap * 4 + q * 2 + nh) % FS : 0], acc[mr][r][nh]);
                     }
                     if constexpr (AP == 2) {                   // third pass: the activations' low halves on the weights' high halves
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a_lo[u % AD][mr], fring[FRG ? u % FS : 0], acc[mr]);
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a_lo[u % AD][mr], fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0], acc[mr][r][nh]);
                     }
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // 1 LDS read (A fragment, two sub-steps ahead)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    // 2 MFMAs (one A operand, both cout halves)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // 1 LDS read (A operand, two sub-steps ahead)
                         __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? (NP == 2 ? 3 : 6) : (NP == 2 ? 1 : 2), 0);   // a slice of the staging VALU
                     }
                     if (NP == 2) {
 #pragma unroll
                         for (int m = 0; m < MR * AP; ++m) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            if (AP == 2 && m < MR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the low-half A fragment
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if (AP == 2 && m < MR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the low-half A operand
                             __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 3 : 1, 0);
                         }
                     }
@@ -641,13 +669,15 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
         constexpr int US = UP4 ? 2 : 1;                                       // output pixel = US * tile pixel + parity
         const int oyb = US * oy0 + py, oxb = US * ox0 + px;                  // (py = px = 0 unless UP4)
         const int lim_h = UP4 ? p.Hin : p.Hout, lim_w = UP4 ? p.Win : p.Wout;
-        float s1[NI], s2[NI];
+        float s1[NI][2], s2[NI][2];                                           // [image][16-cout half]
 #pragma unroll
-        for (int q = 0; q < NI; ++q) s1[q] = s2[q] = 0.f;
-        if (NI == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0]), "+v"(ep_bias));
-        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0]), "+v"(ep_add[NI - 1]), "+v"(ep_bias));
+        for (int q = 0; q < NI; ++q) s1[q][0] = s1[q][1] = s2[q][0] = s2[q][1] = 0.f;
+        if (NI == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0][0]), "+v"(ep_add[0][1]), "+v"(ep_bias[0]), "+v"(ep_bias[1]));
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0][0]), "+v"(ep_add[0][1]), "+v"(ep_add[NI - 1][0]), "+v"(ep_add[NI - 1][1]), "+v"(ep_bias[0]), "+v"(ep_bias[1]));
 #pragma unroll
-        for (int q = 0; q < NI; ++q) ep_add[q] = nok ? ep_add[q] + ep_bias : 0.f;
+        for (int q = 0; q < NI; ++q)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) ep_add[q][nh] = nok[nh] ? (p.film ? ep_add[q][nh] : 0.f) + (p.bias ? ep_bias[nh] : 0.f) : 0.f;
         const bool full = oy0 + TH <= lim_h && ox0 + TW <= lim_w && b0 + NI <= p.B && n0 + BN <= p.Cout;
         if (full) {
             // Whole tile inside the image.  2-byte stores straight from the accumulator layout cost ~200 cycles each
@@ -686,7 +716,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                     int lane_e = lane_id_now();
                     asm volatile("" : "+v"(lane_e));
                     const int pl0 = lane_e >> 2, cq = lane_e & 3;
-                    const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
+                    const int lc_e = lane_e & 15, lg_e = lane_e >> 4;
                     const unsigned lane_el = (unsigned)((US * (pl0 >> LTW) * p.Wout + US * (pl0 & (TW - 1))) * p.Cout + cq * 8);
                     if (RES) {                                                 // requested first: the latency hides behind the transposition
 #pragma unroll
@@ -700,28 +730,34 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         if (m2 >= nm) break;
+                        // patch row = 32 m2 + 16 (half r) + pixel of the half; the lane holds pixels 4 lg .. + 3 of couts 16 nh + lc
 #pragma unroll
-                        for (int j = 0; j < 16; j += 2) {                       // rows row, row + 1 of the 32-row tile
-                            const int row = (j & 3) + 8 * (j >> 2);
-                            float v[2];
+                        for (int r = 0; r < 2; ++r)
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                v[e] = (C::XF != XF_NONE && !F32) ? fmaf(acc[g + m2][j + e], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[g + m2][j + e] + ep_add[NI == 1 ? 0 : img];
-                                if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-                                // no residual: statistics from the fp32 values in the accumulator layout (the lane owns one cout: 2 VALU
-                                // per value, one exchange between the lane halves) instead of unpacking the stored vectors and the
-                                // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
-                                if (!RES) { s1[NI == 1 ? 0 : img] += v[e]; s2[NI == 1 ? 0 : img] = fmaf(v[e], v[e], s2[NI == 1 ? 0 : img]); }
-                            }
-                            if constexpr (F32) {
-                                scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = v[0];
-                                scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = v[1];
-                            } else {
-                                const x2 pr = cvt_pair<E>(v[0], v[1]);
-                                reinterpret_cast<E*>(scr)[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
-                                reinterpret_cast<E*>(scr)[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
-                            }
-                        }
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int j = 0; j < 4; j += 2) {                // pixels j, j + 1: one packed conversion
+                                    float v[2];
+#pragma unroll
+                                    for (int e = 0; e < 2; ++e) {
+                                        const float av = acc[g + m2][r][nh][j + e], ea = ep_add[NI == 1 ? 0 : img][nh];
+                                        v[e] = (C::XF != XF_NONE && !F32) ? fmaf(av, kLn2, ea) : av + ea;
+                                        if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+                                        // no residual: statistics from the fp32 values in the accumulator layout (the lane owns two couts: 2 VALU
+                                        // per value, two exchanges between the lane quarters) instead of unpacking the stored vectors and the
+                                        // 15-move butterfly below; the rounding noise of the store is zero-mean and 2^-9 relative
+                                        if (!RES) { s1[NI == 1 ? 0 : img][nh] += v[e]; s2[NI == 1 ? 0 : img][nh] = fmaf(v[e], v[e], s2[NI == 1 ? 0 : img][nh]); }
+                                    }
+                                    const int at = (m2 * 32 + 16 * r + 4 * lg_e + j) * SCR_STR + 16 * nh + lc_e;
+                                    if constexpr (F32) {
+                                        scr[at] = v[0];
+                                        scr[at + SCR_STR] = v[1];
+                                    } else {
+                                        const x2 pr = cvt_pair<E>(v[0], v[1]);
+                                        reinterpret_cast<E*>(scr)[at] = pr[0];
+                                        reinterpret_cast<E*>(scr)[at + SCR_STR] = pr[1];
+                                    }
+                                }
                     }
                     HSIDM_STAMP(it, 9);
                     if (NI == 2 || g == 0) {
@@ -802,42 +838,52 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             const int pbase = wm * (C::BM / WM) + mr * 32;
-            const int img = pbase / (TH * TW);                       // a 32-row MFMA tile never straddles images
+            const int img = pbase / (TH * TW);                       // a 32-pixel group never straddles images
             const int b = b0 + img;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
-                const int q = pbase + row - img * (TH * TW);
-                const int ty = q / TW, tx = q - ty * TW;
-                const int oy = oyb + US * ty, ox = oxb + US * tx;
-                float v = (C::XF != XF_NONE && !F32) ? fmaf(acc[mr][j], kLn2, ep_add[NI == 1 ? 0 : img]) : acc[mr][j] + ep_add[NI == 1 ? 0 : img];
-                if (!(nok && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
-                if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n;
-                if (p.res) v = p.res_scale * v + (float)reinterpret_cast<const S*>(p.res)[o];
-                const S st = F32 ? (S)v : (S)EL::sat(v);
-                if (!(HSIDM_ABL(1))) reinterpret_cast<S*>(p.out)[o] = st;
-                const float sv = (float)st;
-                s1[NI == 1 ? 0 : img] += sv;
-                s2[NI == 1 ? 0 : img] += sv * sv;
-            }
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = 16 * r + 4 * lg + j;
+                        const int q = pbase + row - img * (TH * TW);
+                        const int ty = q / TW, tx = q - ty * TW;
+                        const int oy = oyb + US * ty, ox = oxb + US * tx;
+                        const float ea = ep_add[NI == 1 ? 0 : img][nh];
+                        float v = (C::XF != XF_NONE && !F32) ? fmaf(acc[mr][r][nh][j], kLn2, ea) : acc[mr][r][nh][j] + ea;
+                        if (!(nok[nh] && b < p.B && oy0 + ty < lim_h && ox0 + tx < lim_w)) continue;
+                        if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n_lane + 16 * nh;
+                        if (p.res) v = p.res_scale * v + (float)reinterpret_cast<const S*>(p.res)[o];
+                        const S st = F32 ? (S)v : (S)EL::sat(v);
+                        if (!(HSIDM_ABL(1))) reinterpret_cast<S*>(p.out)[o] = st;
+                        const float sv = (float)st;
+                        s1[NI == 1 ? 0 : img][nh] += sv;
+                        s2[NI == 1 ? 0 : img][nh] += sv * sv;
+                    }
         }
         }
         if (p.stats && (!full || !p.res)) {
-            // wave partial over its pixels: combine the two lane halves, lanes 0..31 write one entry each
+            // wave partial over its pixels: combine the four lane quarters (lg), lanes 0..15 write one entry per cout half
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
                 int lane_w = lane_id_now();                               // rebuilt here, not kept across the item (see lane_xor)
                 asm volatile("" : "+v"(lane_w));
-                const float a = s1[q] + lane_xor<32>(s1[q], lane_w);
-                const float d = s2[q] + lane_xor<32>(s2[q], lane_w);
                 int img, sub;
                 if (NI == 1) { img = 0; sub = wm; }
                 else if (WM == 1) { img = q; sub = 0; }
                 else { img = (wm * (C::BM / WM)) / (TH * TW); sub = wm % (WM / 2 > 0 ? WM / 2 : 1); if (q != img) continue; }
                 const int b = b0 + img;
-                if (lh == 0 && nok && b < p.B)
-                    p.stats[((size_t)b * (tiles_per_img * (US * US) * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n] = make_float2(a, d);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float a = s1[q][nh] + lane_xor<16>(s1[q][nh], lane_w);
+                    float d = s2[q][nh] + lane_xor<16>(s2[q][nh], lane_w);
+                    a += lane_xor<32>(a, lane_w);
+                    d += lane_xor<32>(d, lane_w);
+                    if (lg == 0 && nok[nh] && b < p.B)
+                        p.stats[((size_t)b * (tiles_per_img * (US * US) * C::SUBS) + trem * C::SUBS + sub) * p.Cout + n_lane + 16 * nh] = make_float2(a, d);
+                }
             }
         }
         HSIDM_STAMP(it, 13);
