@@ -12,6 +12,9 @@ A mode is  <type>[:key=value,...]  with type in {fp32, bf16, fp16}; keys
     op  = fp32 | x2     operand exact / hi + lo
     gn  = fp32 | fp16 | fp16c   type of the (scale, shift) pairs (default: fp32); fp16c: the shift formed with the rounded scale
     w=x2@c128           hi + lo weights on layers with at most 128 output channels (the product's "fp16" mode)
+    w=dK                one-pass weights, DITHERED over the steps of the chain: step s uses round(w + d[s % K] ulp) with K offsets
+                        spread over (-1/2, 1/2) ulp (bit-reversed order), so that the weight error - the one rounding that is the
+                        same in every step - averages to 1/K of its size over K consecutive steps
     a value of w / st / op may carry "@128+64": the map sizes (of the conv's INPUT) on which the override applies
 """
 import json
@@ -93,6 +96,7 @@ class Mode:
         self.stl = kv["stl"].split("+") if "stl" in kv else []     # stl=ups.18+ups.17: fp32 storage for the tensors of these units
         self.gnx = kv["gnx"].split("+") if "gnx" in kv else []     # gnx=final_conv: fp32 GroupNorm pairs in these units
         self.cur = ""
+        self.phase = 0                                             # step of the chain (w=dK)
         self.sm = kv.get("sm", "")
 
     def _ovr(self, k, hw):
@@ -126,6 +130,12 @@ class Mode:
             return split2(w, self.t)
         if self.w == "ed" and self._ovr("w", hw):
             return round_zero_sum(w, self.t)
+        if self.w.startswith("d") and self._ovr("w", hw):
+            K = int(self.w[1:])
+            ph = int(format(self.phase % K, "0%db" % max(1, (K - 1).bit_length()))[::-1], 2) if K & (K - 1) == 0 else self.phase % K
+            mant = 10 if self.t == "fp16" else 7
+            ulp = torch.exp2(torch.floor(torch.log2(w.abs().clamp_min(2.0 ** -14))) - mant)
+            return rnd(w + ((ph + 0.5) / K - 0.5) * ulp, self.t)
         return rnd(w, self.t)
 
     def conv_in(self, x):
@@ -248,6 +258,7 @@ def run(spec, steps=CHAIN_T, seed=0):
               (lambda xc, gam: unet_forward(m, sd, FULL, xc, gam))
         for i in reversed(range(CHAIN_T)):
             zn = torch.from_numpy(np.concatenate([cn(gi, CHAIN_T - i) for gi in range(ngr)])) if i > 0 else None
+            m.phase = CHAIN_T - 1 - i
             x = diffusion.p_sample_step(den, sched, x, z, i, zn)
             if CHAIN_T - i >= steps:
                 break

@@ -117,6 +117,36 @@ def test_packed_conv_layout_roundtrip(prec, bk):
     assert torch.allclose(pk.bias, b + pb)
 
 
+
+def test_register_streaming_weight_order_serves_both_mfma_operand_shapes():
+    """The packed order [step][Cout_pad/32][4][64 lanes][8] (PackedConv._lanes) read the two ways the kernels read it:
+    * 32x32x16 B operand (conv1x1_g, conv_sk, the generic paths): fragment kk, lane (h, r) = W[32 s + r][16 kk + 8 h ..];
+    * 16x16x32 B operand (conv_v2 / conv_v3 since round 3: conv_v2.h, wlane_off / frag_off): fragment e = 2q + nh at element offset
+      frag_off(e) = (e / 2) * 1024 + (e % 2) * 128 behind the lane base ((g / 2) * 64 + 32 (g % 2) + c) * 8, lane (c = lane % 16,
+      g = lane / 16) = W[32 s + 16 nh + c][32 q + 8 g ..] - the same memory, no repacking."""
+    from hsi_dmgasr_amd import ops
+    cpad, steps = 96, 3
+    w = torch.arange(steps * cpad * 64, dtype=torch.float64).reshape(steps, cpad, 64)        # value = its own (step, cout, k) index
+    flat = ops.PackedConv._lanes(w, cpad).reshape(steps, cpad // 32, -1)
+    for st in range(steps):
+        for sl in range(cpad // 32):
+            seen = torch.zeros(32, 64, dtype=torch.int32)
+            for lane in range(64):
+                c, g = lane % 16, lane // 16
+                base = ((g // 2) * 64 + 32 * (g % 2) + c) * 8
+                for e in range(4):
+                    q, nh = e // 2, e % 2
+                    off = base + (e // 2) * 1024 + (e % 2) * 128
+                    got = flat[st, sl, off:off + 8]
+                    cout, k0 = 32 * sl + 16 * nh + c, 32 * q + 8 * g
+                    assert torch.equal(got, w[st, cout, k0:k0 + 8]), (st, sl, lane, e)
+                    seen[16 * nh + c, k0:k0 + 8] += 1
+                    # the 32x32x16 reading of the same block
+                    r, h = lane % 32, lane // 32
+                    assert torch.equal(flat[st, sl, (e * 64 + lane) * 8:(e * 64 + lane) * 8 + 8], w[st, 32 * sl + r, 16 * e + 8 * h:16 * e + 8 * h + 8])
+            assert torch.all(seen == 1)                      # every weight of the slice exactly once
+
+
 def test_unet_and_gae_schema_match_the_reference_checkpoints():
     from hsi_dmgasr_amd import gae
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
