@@ -135,7 +135,7 @@ struct V2Cfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * AP * HALO_ELEMS * 2 + POS_BYTES + (OWN_PATCH ? PATCH_BYTES : 0);
     // depth of the A-operand ring in sub-steps (kernel: a_fetch).  Two where a sub-step carries twice the MFMAs (NP = 2) and on the
     // two-image 128-cout GroupNorm form, where the third set made the allocator spill 37 registers (per-image FiLM / statistics
-    // registers on top of MR = 4) - and a spilled register of the untracked FiLM / bias prefetch is not an option (kernel: ep_add)
+    // registers on top of MR = 4)
     static constexpr int AD = (NP_ == 2 || (NI_ == 2 && XF_ != 0 && BN_ == 128 && NW_ == 4)) ? 2 : 3;
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
@@ -514,44 +514,20 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     lds_barrier();
     stage_advance();
 
-    // Per-lane output channel n; bias[n] + FiLM[image][n] are added to the accumulators in the epilogue.  They are fetched at
-    // the start of the item with loads the compiler does not track (inline asm): as a tracked, loop-carried value the
-    // compiler waited for them with s_waitcnt vmcnt(0) at the loop latch, i.e. for the acknowledgement of every output
-    // store of the item, once per item.  vmcnt retires in order and a whole K loop of tracked weight loads follows, so
-    // the values have long landed when the epilogue's own `s_waitcnt vmcnt(4)` names them.
+    // Per-lane output channels; bias[n] + FiLM[image][n] are added to the accumulators in the epilogue.  They are loaded with
+    // ordinary (compiler-tracked) loads at the first tap of the item's LAST chunk: vmcnt retires in order and that chunk issues 36+
+    // weight loads behind them, so the counted waits on those weights already cover them - the ISA shows no additional s_waitcnt.
+    // (Until round 3 they were fetched at the start of the item with loads the compiler did not track - as a tracked value that is
+    // live across the whole item they had cost an s_waitcnt vmcnt(0) at the chunk loop's latch - which left registers the hardware
+    // writes late at the mercy of the allocator: a spill of one, or a select on one, reads it too early.)
     const int n_lane = n0 + wn * 32 + lc;                       // couts n_lane, n_lane + 16
     const bool nok[2] = {n_lane < p.Cout, n_lane + 16 < p.Cout};
-    auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
-        float v;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
-        return v;
-    };
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         HSIDM_STAMP(it, 0);
-        // landed by the epilogue (see above); [image][16-cout half].  The loads are UNCONDITIONAL - an absent FiLM / bias vector
-        // reads a word of the weights that is discarded after the wait: a select on the result would read the register before
-        // the data has landed (the compiler does not know these registers are pending)
-        float ep_add[NI][2], ep_bias[2];
-        {
-            // the lane's channels are recomputed from the hardware lane id here: kept as a loop-invariant 64-bit address
-            // (p.film + n, p.bias + n) it was spilled, and each reload cost an s_waitcnt vmcnt(0) at the start of every item
-            int lane_s = lane_id_now();
-            asm volatile("" : "+v"(lane_s));
-            int par_;
-            const int fb0 = div_tpi(item_tile(item, par_)) * NI;
+        float ep_add[NI][2], ep_bias[2] = {0.f, 0.f};          // [image][16-cout half]; loaded in the last chunk (see above)
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                const int n_s = n0 + wn * 32 + 16 * nh + (lane_s & 15);
-                const int nn = n_s < p.Cout ? n_s : 0;
-#pragma unroll
-                for (int q = 0; q < NI; ++q) {
-                    const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
-                    ep_add[q][nh] = untracked_load(p.film ? p.film + (size_t)fb * p.film_stride + nn : reinterpret_cast<const float*>(p.w));
-                }
-                ep_bias[nh] = untracked_load(p.bias ? p.bias + nn : reinterpret_cast<const float*>(p.w));
-            }
-        }
+        for (int q = 0; q < NI; ++q) ep_add[q][0] = ep_add[q][1] = 0.f;
         if (UP4) {                                             // the ring wraps to the next item's weights during this item
             int par_nx;
             item_tile(item + G < p.total_items ? item + G : (int)blockIdx.x, par_nx);
@@ -588,6 +564,25 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                 if (st_valid && tap == 0) {                    // staging of the next chunk, one vector per tap
                     if (st_chunk == 0) describe(st_item);
                     halo_begin(st_chunk);
+                }
+                if (tap == 0 && chunk == nch - 1) {            // FiLM + bias for the epilogue (see above)
+                    // the lane's channels are recomputed from the hardware lane id here: kept as loop-invariant 64-bit addresses
+                    // (p.film + n, p.bias + n) they were spilled
+                    int lane_s = lane_id_now();
+                    asm volatile("" : "+v"(lane_s));
+                    int par_;
+                    const int fb0 = div_tpi(item_tile(item, par_)) * NI;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const int n_s = n0 + wn * 32 + 16 * nh + (lane_s & 15);
+                        const int nn = n_s < p.Cout ? n_s : 0;
+#pragma unroll
+                        for (int q = 0; q < NI; ++q) {
+                            const int fb = (fb0 + q < p.B) ? fb0 + q : fb0;
+                            if (p.film) ep_add[q][nh] = p.film[(size_t)fb * p.film_stride + nn];
+                        }
+                        if (p.bias) ep_bias[nh] = p.bias[nn];
+                    }
                 }
                 // Issue and commit are unconditional (past the last item they move stale but valid data into the unused
                 // buffer): no branch separates them from the MFMAs, and the group barriers below ask the scheduler for
@@ -672,12 +667,10 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
         float s1[NI][2], s2[NI][2];                                           // [image][16-cout half]
 #pragma unroll
         for (int q = 0; q < NI; ++q) s1[q][0] = s1[q][1] = s2[q][0] = s2[q][1] = 0.f;
-        if (NI == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0][0]), "+v"(ep_add[0][1]), "+v"(ep_bias[0]), "+v"(ep_bias[1]));
-        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(ep_add[0][0]), "+v"(ep_add[0][1]), "+v"(ep_add[NI - 1][0]), "+v"(ep_add[NI - 1][1]), "+v"(ep_bias[0]), "+v"(ep_bias[1]));
 #pragma unroll
         for (int q = 0; q < NI; ++q)
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) ep_add[q][nh] = nok[nh] ? (p.film ? ep_add[q][nh] : 0.f) + (p.bias ? ep_bias[nh] : 0.f) : 0.f;
+            for (int nh = 0; nh < 2; ++nh) ep_add[q][nh] = nok[nh] ? ep_add[q][nh] + ep_bias[nh] : 0.f;
         const bool full = oy0 + TH <= lim_h && ox0 + TW <= lim_w && b0 + NI <= p.B && n0 + BN <= p.Cout;
         if (full) {
             // Whole tile inside the image.  2-byte stores straight from the accumulator layout cost ~200 cycles each

@@ -195,11 +195,6 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (16 / WM) + mr * 2) * RP + lc * PSTR + 8 * lg;
     f32x4 acc[MR][2][2];                                        // [tile-row pair][row of the pair][16-cout half]
 
-    auto untracked_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
-        float v;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
-        return v;
-    };
 
     // prologue: two weight steps in flight, raw vectors of (first item, chunk 0) requested
     if (!FRG) {
@@ -221,21 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         HSIDM_STAMP(it, 0);
         const int tile = tile_of(item);
         const int b = div_tpi(tile);
-        // landed by the epilogue (conv_v2.h: untracked loads); [16-cout half].  The loads are UNCONDITIONAL (an absent FiLM / bias
-        // vector reads a word of the weights and is discarded after the wait): a select on the result would read the register
-        // before the data has landed - the compiler does not know these registers are pending
-        float ep_add[2], ep_bias[2];
-        {   // lane's channels from the hardware lane id: a loop-invariant address register pair would be spilled (conv_v2.h)
-            int lane_s = lane_id_now();
-            asm volatile("" : "+v"(lane_s));
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                const int n_raw = wn * 32 + 16 * nh + (lane_s & 15);
-                const int n_s = (!NCHW_ || n_raw < p.Cout) ? n_raw : 0;     // NCHW_: 3 of the slice's 32 couts exist
-                ep_add[nh] = untracked_load(p.film ? p.film + (size_t)b * p.film_stride + n_s : reinterpret_cast<const float*>(p.w));
-                ep_bias[nh] = untracked_load(p.bias ? p.bias + n_s : reinterpret_cast<const float*>(p.w));
-            }
-        }
+        float ep_add[2] = {0.f, 0.f}, ep_bias[2] = {0.f, 0.f};  // FiLM / bias of the lane's couts [16-cout half]: loaded in the last chunk
 
         for (int chunk = 0; chunk < nch; ++chunk) {
             commit_all();                                       // hreg holds (item, chunk): transform -> LDS
@@ -248,6 +229,23 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             if (chunk == 0) HSIDM_STAMP(it, 2);
             lds_barrier();
             if (chunk == 0) HSIDM_STAMP(it, 3);
+            if (chunk == nch - 1) {
+                // FiLM + bias of the lane's two couts, needed by the epilogue: ordinary (compiler-tracked) loads issued HERE, ahead of
+                // the last chunk's MFMA phase.  vmcnt retires in order and the phase issues 36+ weight loads behind them, so the
+                // counted waits on those weights already cover them: the ISA shows no additional s_waitcnt for these values.
+                // (Rounds 1-3 fetched them at the start of the item with loads the compiler did not track - kept as a tracked value
+                // across the whole item they had cost an s_waitcnt vmcnt(0) per item - which left a register the hardware writes
+                // late at the mercy of the allocator: a spill or a select on it reads it too early.  In-box A/B: equal time.)
+                int lane_s = lane_id_now();
+                asm volatile("" : "+v"(lane_s));
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int n_raw = wn * 32 + 16 * nh + (lane_s & 15);
+                    const int n_s = (!NCHW_ || n_raw < p.Cout) ? n_raw : 0;
+                    if (p.film) ep_add[nh] = p.film[(size_t)b * p.film_stride + n_s];
+                    if (p.bias) ep_bias[nh] = p.bias[n_s];
+                }
+            }
             HSIDM_SETPRIO(1);
             // A operands: ring over the 36 sub-steps w = 4 tap + 2 q + r of the chunk (q: 32-channel slice of the tap, r: row of the
             // tile-row pair); sub-step w runs 2 MR (x NP) MFMAs - both 16-cout halves on the slice's two weight fragments 4 tap + 2 q + n
@@ -299,9 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int tr = tile - b * tiles_per_img;
         const int try_e = div_tx(tr);
         const int oy0 = try_e * TH, ox0 = (tr - try_e * p.tiles_x) * TW;
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(ep_add[0]), "+v"(ep_add[1]), "+v"(ep_bias[0]), "+v"(ep_bias[1]));   // older than the 8 weight + 11 halo requests in flight
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) ep_add[nh] = (p.film ? ep_add[nh] : 0.f) + (p.bias ? ep_bias[nh] : 0.f);
+        for (int nh = 0; nh < 2; ++nh) ep_add[nh] += ep_bias[nh];
         if constexpr (NCHW_) {
             // fp32 NCHW straight from the accumulator layout: lane = cout 16 nh + lane % 16 (3 live lanes), the four registers of
             // an accumulator = pixel columns 4 (lane / 16) .. + 3 of one tile row: one 16-byte store each
