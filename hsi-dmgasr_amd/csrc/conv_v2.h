@@ -105,7 +105,8 @@ struct V2Cfg {
     // ring slots / lookahead in k-slices; the slot count divides the k-slices of a chunk (16 | 36) so that every index is static
     // (a 32-channel slice keeps its two fragments through both of its sub-steps: FL <= FS - 2)
     // (the fp32 form has one workgroup per CU and registers to spare: a deeper ring, ten / six fragments ahead)
-    static constexpr int FS = AP_ == 2 ? (FR ? 8 : 12) : (FR ? (NP_ == 2 ? 4 : 8) : 6), FL = AP_ == 2 ? FS - 2 : (FR ? (NP_ == 2 ? 2 : 6) : 4);
+    // (folded forms: 8 slots, six ahead, with hi + lo weights too - 4 / 2 kept their launches 7 - 12 % longer: up 128 -> 128 968 -> 903 us)
+    static constexpr int FS = AP_ == 2 ? (FR ? 8 : 12) : (FR ? 8 : 6), FL = AP_ == 2 ? FS - 2 : (FR ? 6 : 4);
     static constexpr int BM = TH * TW * NI, BK = 64;           // 128 pixels; 64 for the one-image 8x8 tile (maps of 8x8 pixels
                                                                 // at batches too small to fill the GPU with two-image tiles)
     static_assert(BM == 128 || (BM == 64 && BN_ == 128), "tile");
