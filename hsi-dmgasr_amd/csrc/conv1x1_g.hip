@@ -7,7 +7,8 @@
 // rows per wave-load) and is bound by the texture addresser, 1.6x off the HBM floor on the 128x128 level.  Here
 //   * the activation tile (128 consecutive pixels x 64 channels) is fetched with row-contiguous 16-byte loads (8 lanes
 //     = one 128-byte line), held in registers for one K chunk and a half, and committed to a double-buffered padded
-//     LDS tile (144-byte pixel rows, the conv_v2 layout: conflict-free ds_read_b128 A-fragments);
+//     LDS tile (160-byte pixel rows, the conv_v2 layout: conflict-free ds_read_b128 A operands of v_mfma_f32_16x16x32, the matrix
+//     instruction of the conv kernels since round 3 - conv_v2.h; weights are 16-byte units of the same packed order);
 //   * weights never touch LDS: each wave streams its B-fragments from L2 through an 8-slot register ring, six
 //     fragments (1.5 K chunks) ahead, in the order conv_v2 uses (one wave-load = 1 KiB contiguous);
 //   * the workgroup is persistent over (pixel tile, cout slice) items with conv_v2's XCD-aware slice mapping; the
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
     static_assert(!F32 || (NP == 2 && IM == 0), "the fp32 form: hi + lo weights, plain 1x1");
     constexpr int SV = F32 ? 2 : 1, AP = F32 ? 2 : 1;
     constexpr int WN = BN / 32, WM = 4 / WN, MR = 128 / WM / 32;
-    constexpr int PSTR = 72, TILE = 128 * PSTR, BUFE = AP * TILE;
+    constexpr int PSTR = 80, TILE = 128 * PSTR, BUFE = AP * TILE;
     constexpr int SCR_STR = 40;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* xt = reinterpret_cast<E*>(smem_raw);                     // [2][AP][TILE] (+ 2 KiB: the 16-bit epilogue patch overruns buffer 1)
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lc = lane & 15, lg = lane >> 4;                   // MFMA 16x16x32: row / column lc, k group lg (conv_v2.h)
     const int G = gridDim.x;
     const int ctot = p.C0 + p.C1;
 
@@ -88,15 +89,17 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 
     // ---- weight stream -------------------------------------------------------------------------------------------
     const int nsw = p.Cout_pad >> 5;
-    const E* wlane = reinterpret_cast<const E*>(p.w) + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
-    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + ((size_t)(ns * WN + wn) * 4 * 64 + lane) * 8;
+    const size_t wl_off = ((size_t)(ns * WN + wn) * 4 * 64 + (lg >> 1) * 64 + 32 * (lg & 1) + lc) * 8;     // (conv_v2.h: wlane_off, frag_off)
+    const E* wlane = reinterpret_cast<const E*>(p.w) + wl_off;
+    const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + wl_off;
+    auto frag_off = [](int e) __attribute__((always_inline)) -> int { return (e >> 1) * (2 * 64 * 8) + (e & 1) * (16 * 8); };
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
     x8 fring[8], fring_lo[NP == 2 ? 8 : 1];
     int wnext = 0;
     auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
         if (G1_ABL != 2) {
-            fring[slot] = *reinterpret_cast<const x8*>(wlane + (size_t)wnext * wstep_stride + kk * 64 * 8);
-            if (NP == 2) fring_lo[NP == 2 ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + (size_t)wnext * wstep_stride + kk * 64 * 8);
+            fring[slot] = *reinterpret_cast<const x8*>(wlane + (size_t)wnext * wstep_stride + frag_off(kk));
+            if (NP == 2) fring_lo[NP == 2 ? slot : 0] = *reinterpret_cast<const x8*>(wlane_lo + (size_t)wnext * wstep_stride + frag_off(kk));
         }
         if (kk == 3) wnext = (wnext + 1 == p.nch) ? 0 : wnext + 1;
     };
@@ -235,8 +238,8 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
     // ---- MFMA fragment bases ---------------------------------------------------------------------------------------
     int abase[MR];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (128 / WM) + mr * 32 + lr) * PSTR + 8 * lh;
-    f32x16 acc[MR];
+    for (int mr = 0; mr < MR; ++mr) abase[mr] = (wm * (128 / WM) + mr * 32 + lc) * PSTR + 8 * lg;     // 16-pixel half r: + 16 r PSTR
+    f32x4 acc[MR][2][2];                                        // [32-pixel group][16-pixel half][16-cout half]
 
     // prologue: chunks 0 and 1 requested, six weight fragments in flight, chunk 0 committed
 #pragma unroll
@@ -248,8 +251,8 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
     for (int i = 0; i < 4; ++i) commit(0, i, 0);
     lds_barrier();
 
-    const int n = n0 + wn * 32 + lr;
-    const float bias = p.bias ? p.bias[n] : 0.f;                // Cout % BN == 0 on this path
+    const int n_lane = n0 + wn * 32 + lc;                       // couts n_lane, n_lane + 16 (Cout % BN == 0 on this path)
+    const float bias[2] = {p.bias ? p.bias[n_lane] : 0.f, p.bias ? p.bias[n_lane + 16] : 0.f};
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         for (int chunk = 0; chunk < p.nch; chunk += 2) {
@@ -261,12 +264,12 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                 params_fetch(PAR ^ 1);                          // before the data requests: a later wait for the parameters then
                 issue(PAR);                                     // leaves those (and the weight ring) in flight
                 x8 a[3][MR], a_lo[F32 ? 3 : 1][MR];
-                auto a_fetch = [&](int u) __attribute__((always_inline)) {
+                auto a_fetch = [&](int u) __attribute__((always_inline)) {          // sub-step u = 2 q + r: 32-channel slice q, pixel half r
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
                         if (G1_ABL != 4) {
-                            a[u % 3][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + u * 16);
-                            if constexpr (F32) a_lo[u % 3][mr] = *reinterpret_cast<const x8*>(hb + TILE + abase[mr] + u * 16);
+                            a[u % 3][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + (u >> 1) * 32 + (u & 1) * 16 * PSTR);
+                            if constexpr (F32) a_lo[u % 3][mr] = *reinterpret_cast<const x8*>(hb + TILE + abase[mr] + (u >> 1) * 32 + (u & 1) * 16 * PSTR);
                         }
                 };
                 a_fetch(0);
@@ -274,23 +277,31 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int u = PAR * 4 + kk;                 // position in the two-chunk trip: the weight ring's period
+                    const int q = kk >> 1, r = kk & 1;
                     if (kk + 2 < 4) a_fetch(kk + 2);
                     f_issue((u + 6) % 8, (u + 6) % 4);
-                    if (u == 0 && chunk == 0) {                // first k-slice of the item: C = 0 as the MFMA's inline constant
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const bool first = PAR == 0 && kk < 2 && chunk == 0;   // first use of these accumulators: C = 0 as the inline constant
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    if (G1_ABL != 3) {
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[0][mr], fring[0], zero);
-                    } else if (G1_ABL != 3) {
+                        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[kk % 3][mr], fring[u % 8], acc[mr]);
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a[kk % 3][mr], fring[(PAR * 4 + q * 2 + nh) % 8], first ? zero : acc[mr][r][nh]);
                     }
                     if (NP == 2 && G1_ABL != 3) {
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a[kk % 3][mr], fring_lo[NP == 2 ? u % 8 : 0], acc[mr]);
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a[kk % 3][mr], fring_lo[NP == 2 ? (PAR * 4 + q * 2 + nh) % 8 : 0], acc[mr][r][nh]);
                     }
                     if constexpr (F32) {                        // third pass: the activations' low halves on the weights' high halves
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) acc[mr] = EL::mfma(a_lo[kk % 3][mr], fring[u % 8], acc[mr]);
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a_lo[kk % 3][mr], fring[(PAR * 4 + q * 2 + nh) % 8], acc[mr][r][nh]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk == 1) { commit(PAR ^ 1, 0, PAR ^ 1); commit(PAR ^ 1, 1, PAR ^ 1); }
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
         int lane_e = lane_id_now();   // rebuilt here, not kept (conv_v2.h)
         asm volatile("" : "+v"(lane_e));
         const int pl0 = lane_e >> 2, cq = lane_e & 3;
-        const int lr_e = lane_e & 31, lh_e = lane_e >> 5;
+        const int lc_e = lane_e & 15, lg_e = lane_e >> 4;
         auto run = [&](auto res_tag) __attribute__((always_inline)) {
             constexpr bool RES = decltype(res_tag)::value != 0;
 #pragma unroll
@@ -335,17 +346,21 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                 for (int m2 = 0; m2 < 2; ++m2) {
                     if (m2 >= nm) break;
 #pragma unroll
-                    for (int j = 0; j < 16; j += 2) {                           // rows row, row + 1: one packed conversion (cvt_pair)
-                        const int row = (j & 3) + 8 * (j >> 2);
-                        if constexpr (F32) {
-                            scr[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = acc[g + m2][j] + bias;
-                            scr[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = acc[g + m2][j + 1] + bias;
-                        } else {
-                            const x2 pr = cvt_pair<E>(acc[g + m2][j] + bias, acc[g + m2][j + 1] + bias);
-                            reinterpret_cast<E*>(scr)[(m2 * 32 + row) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[0];
-                            reinterpret_cast<E*>(scr)[(m2 * 32 + row + 1) * SCR_STR + (4 * lh_e * SCR_STR + lr_e)] = pr[1];
-                        }
-                    }
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2) {                    // pixels j, j + 1 of the lane's four: one packed conversion
+                                const int at = (m2 * 32 + 16 * r + 4 * lg_e + j) * SCR_STR + 16 * nh + lc_e;
+                                if constexpr (F32) {
+                                    scr[at] = acc[g + m2][r][nh][j] + bias[nh];
+                                    scr[at + SCR_STR] = acc[g + m2][r][nh][j + 1] + bias[nh];
+                                } else {
+                                    const x2 pr = cvt_pair<E>(acc[g + m2][r][nh][j] + bias[nh], acc[g + m2][r][nh][j + 1] + bias[nh]);
+                                    reinterpret_cast<E*>(scr)[at] = pr[0];
+                                    reinterpret_cast<E*>(scr)[at + SCR_STR] = pr[1];
+                                }
+                            }
                 }
                 float vs1[8], vs2[8];
 #pragma unroll
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 
 template <int BN, int XF, int IM, typename E, int NP, bool F32 = false>
 static int run_g1(C1gParams& p, hipStream_t s) {
-    constexpr size_t lds = F32 ? (size_t)2 * 2 * 128 * 72 * 2 + (size_t)4 * 64 * 40 * 4 : (size_t)2 * 128 * 72 * 2 + 2048;
+    constexpr size_t lds = F32 ? (size_t)2 * 2 * 128 * 80 * 2 + (size_t)4 * 64 * 40 * 4 : (size_t)2 * 128 * 80 * 2 + 2048;
     static PerDeviceOnce once;
     if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP, F32>, lds)) return rc;
     const int g1_slots = (F32 ? 1 : 2) * device_cus();
