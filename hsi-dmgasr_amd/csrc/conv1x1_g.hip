@@ -280,14 +280,20 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                     const int q = kk >> 1, r = kk & 1;
                     if (kk + 2 < 4) a_fetch(kk + 2);
                     f_issue((u + 6) % 8, (u + 6) % 4);
-                    const bool first = PAR == 0 && kk < 2 && chunk == 0;   // first use of these accumulators: C = 0 as the inline constant
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    if (G1_ABL != 3) {
+                    // first use of these accumulators: C = 0 as the MFMA's inline constant, behind a uniform branch (a select between
+                    // the constant and the accumulator costs a v_cndmask per register - and, in the fp32 form, moves through the AGPRs)
+                    if (PAR == 0 && kk < 2 && chunk == 0) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh) acc[mr][r][nh] = EL::mfma16(a[kk % 3][mr], fring[(PAR * 4 + q * 2 + nh) % 8], zero);
+                    } else if (G1_ABL != 3) {
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                             for (int nh = 0; nh < 2; ++nh)
-                                acc[mr][r][nh] = EL::mfma16(a[kk % 3][mr], fring[(PAR * 4 + q * 2 + nh) % 8], first ? zero : acc[mr][r][nh]);
+                                acc[mr][r][nh] = EL::mfma16(a[kk % 3][mr], fring[(PAR * 4 + q * 2 + nh) % 8], acc[mr][r][nh]);
                     }
                     if (NP == 2 && G1_ABL != 3) {
 #pragma unroll

@@ -607,15 +607,23 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                             halo_commit_one((tap - 2) * 4 + kk, cur ^ 1);
                         }
                     }
-                    // first sub-steps of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item
-                    const bool first = u < 2 && chunk == 0;
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    // first sub-steps of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item (behind a
+                    // uniform branch: a select between the constant and the accumulator would cost a v_cndmask per register)
+                    if (u < 2 && chunk == 0) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
+                        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                        for (int nh = 0; nh < 2; ++nh)
-                            acc[mr][r][nh] = EL::mfma16(a[u % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh],
-                                                        first ? zero : acc[mr][r][nh]);
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a[u % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh], zero);
+                    } else {
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+                                acc[mr][r][nh] = EL::mfma16(a[u % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh],
+                                                            acc[mr][r][nh]);
+                    }
                     if (NP == 2) {                             // second pass on the weights' low halves
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr)

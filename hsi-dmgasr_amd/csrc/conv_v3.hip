@@ -267,14 +267,19 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     const int w = tap * 4 + kk, q = kk >> 1, r = kk & 1;
                     if (w + AD - 1 < 36) a_fetch(w + AD - 1);
                     if (FRG) f_issue((w + FL) % FS, (w + FL) % 4);
-                    const bool first = w < 2 && chunk == 0;     // first use of these accumulators: C = 0 as the MFMA's inline constant
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    if (w < 2 && chunk == 0) {                  // first use of these accumulators: C = 0 as the MFMA's inline constant (uniform branch)
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int nh = 0; nh < 2; ++nh) {
-                        const int e = q * 2 + nh;               // weight fragment of the step
+                        for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr)
-                            acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], FRG ? fring[FRG ? (tap * 4 + e) % FS : 0] : ring[FRG ? 0 : tap % 3][e], first ? zero : acc[mr][r][nh]);
+                            for (int mr = 0; mr < MR; ++mr)
+                                acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh], zero);
+                    } else {
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr)
+                                acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh], acc[mr][r][nh]);
                     }
                     if (NP == 2) {
 #pragma unroll
