@@ -176,8 +176,26 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 v[2 * k] = EL::lo(hreg[i][k]);
                 v[2 * k + 1] = EL::hi(hreg[i][k]);
             }
+            // the transform in STAGES over the vector's eight elements (scheduling barriers in between): element by element the
+            // compiler emits one dependent chain fma -> exp -> add -> rcp -> mul per element, with an s_nop behind every
+            // transcendental and nothing to issue while its result is in flight (183 s_nop in the 872 instructions of this block; staged: 16
+            // in 697; the hi + lo launches -0.7 ... -1.4 %, the rest unchanged: the partner workgroup's MFMA phase was filling most of those slots)
+            float e[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = silu_log2e(fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k])));
+            for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], h2_lo(abh[k]), h2_hi(abh[k]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = __builtin_amdgcn_exp2f(-v[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = 1.0f + e[k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = __builtin_amdgcn_rcpf(e[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] * e[k];
+            __builtin_amdgcn_sched_barrier(0);
             x8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (E)v[k];
