@@ -50,6 +50,16 @@ template <> struct Elem<f16> {
     static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
     static __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 };
+// The conv kernels saturate their fp16 stores in HARDWARE: with MODE.FP16_OVFL set, a conversion to fp16 that overflows gives
+// +-65504 instead of an infinity (a true infinity stays one; probed on gfx950 for v_cvt_pk_f16_f32 and v_cvt_f16_f32).  A wave that
+// called fp16_saturating_stores() converts with cvt_pair_hw / a plain cast - without the v_med3 of Elem<f16>::sat, 64 ... 128 vector
+// instructions per lane and work item in the convolution epilogues.  (hwreg(MODE, offset 23, size 1) = 1473.)
+__device__ __forceinline__ void fp16_saturating_stores() { __builtin_amdgcn_s_setreg(1473, 1); }
+template <typename E>
+__device__ __forceinline__ typename Elem<E>::x2 cvt_pair_hw(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_convertvector(v, typename Elem<E>::x2);
+}
 // two fp32 -> one packed pair (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even), saturated for fp16
 template <typename E>
 __device__ __forceinline__ typename Elem<E>::x2 cvt_pair(float a, float b) {

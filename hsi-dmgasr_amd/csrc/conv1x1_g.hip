@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
     constexpr int SCR_STR = 40;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* xt = reinterpret_cast<E*>(smem_raw);                     // [2][AP][TILE] (+ 2 KiB: the 16-bit epilogue patch overruns buffer 1)
+    if constexpr (!__is_same(E, bf16)) fp16_saturating_stores();        // (common.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
             for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], h2_lo(abh[i >> 1][k]), h2_hi(abh[i >> 1][k]));
             x8 o;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (E)EL::sat(v[k]);       // (GroupNorm affine without an activation: not bounded)
+            for (int k = 0; k < 8; ++k) o[k] = (E)v[k];       // (GroupNorm affine without an activation: not bounded)
             *reinterpret_cast<x8*>(xt + buf * BUFE + hv0 + i * 32 * PSTR) = o;
         } else {
             *reinterpret_cast<u32x4*>(xt + buf * BUFE + hv0 + i * 32 * PSTR) = raw;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                                     scr[at] = acc[g + m2][r][nh][j] + bias[nh];
                                     scr[at + SCR_STR] = acc[g + m2][r][nh][j + 1] + bias[nh];
                                 } else {
-                                    const x2 pr = cvt_pair<E>(acc[g + m2][r][nh][j] + bias[nh], acc[g + m2][r][nh][j + 1] + bias[nh]);
+                                    const x2 pr = cvt_pair_hw<E>(acc[g + m2][r][nh][j] + bias[nh], acc[g + m2][r][nh][j + 1] + bias[nh]);
                                     reinterpret_cast<E*>(scr)[at] = pr[0];
                                     reinterpret_cast<E*>(scr)[at + SCR_STR] = pr[1];
                                 }
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             f[k] = fmaf(p.res_scale, f[k], (float)rv[RES ? v4 : 0][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
-                            o[k] = (E)EL::sat(f[k]);
+                            o[k] = (E)f[k];
                         }
                     }
                     if (G1_ABL != 6) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;

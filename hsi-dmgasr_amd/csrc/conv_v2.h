@@ -238,6 +238,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* halo = reinterpret_cast<E*>(smem_raw);                // [2][HALO_ELEMS]
+    if constexpr (sizeof(E) == 2 && !__is_same(E, bf16)) fp16_saturating_stores();      // (common.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                                         scr[at] = v[0];
                                         scr[at + SCR_STR] = v[1];
                                     } else {
-                                        const x2 pr = cvt_pair<E>(v[0], v[1]);
+                                        const x2 pr = cvt_pair_hw<E>(v[0], v[1]);
                                         reinterpret_cast<E*>(scr)[at] = pr[0];
                                         reinterpret_cast<E*>(scr)[at + SCR_STR] = pr[1];
                                     }
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {
                                 f[k] = fmaf(p.res_scale, f[k], (float)rv[RES ? v4 : 0][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
-                                o[k] = (E)EL::sat(f[k]);
+                                o[k] = (E)f[k];
                             }
                         }
                         if (!HSIDM_ABL(1)) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(g, v4) + lane_el) = o;
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                         if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                         const size_t o = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + n_lane + 16 * nh;
                         if (p.res) v = p.res_scale * v + (float)reinterpret_cast<const S*>(p.res)[o];
-                        const S st = F32 ? (S)v : (S)EL::sat(v);
+                        const S st = F32 ? (S)v : (S)v;
                         if (!(HSIDM_ABL(1))) reinterpret_cast<S*>(p.out)[o] = st;
                         const float sv = (float)st;
                         s1[NI == 1 ? 0 : img][nh] += sv;

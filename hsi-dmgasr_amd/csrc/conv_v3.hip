@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* halo = reinterpret_cast<E*>(smem_raw);
+    if constexpr (!__is_same(E, bf16)) fp16_saturating_stores();     // (common.h)
     int* pos_tab = reinterpret_cast<int*>(smem_raw + (size_t)HALO_ELEMS * 2);
 
     const int tid = threadIdx.x;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                                 if (LEAKY) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                                 if (!RES) { as1[nh] += v[e]; as2[nh] = fmaf(v[e], v[e], as2[nh]); }   // statistics in the accumulator layout (see below)
                             }
-                            const x2 pr = cvt_pair<E>(v[0], v[1]);
+                            const x2 pr = cvt_pair_hw<E>(v[0], v[1]);
                             const int at = (16 * r + 4 * lg_e + j) * SCR_STR + 16 * nh + lc_e;
                             scr[at] = pr[0];
                             scr[at + SCR_STR] = pr[1];
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             f[k] = fmaf(p.res_scale, f[k], (float)rv[v4][k]);   // statistics from the fp32 sum (the store's rounding noise is zero-mean)
-                            o[k] = (E)EL::sat(f[k]);
+                            o[k] = (E)f[k];
                         }
                     }
                     *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(v4) + lane_el) = o;
