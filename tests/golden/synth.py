@@ -66,10 +66,10 @@ def augment_input():
     return synth_tensor("augment.x", AUGMENT_SHAPE).astype(np.float32)
 
 
-def chain_cubes(hw=128, bands=31):
+def chain_cubes(hw=128, bands=31, draw=0):
     """(hr, sr) float32 [1, bands, hw, hw] in [0, 1] for the full-size chain golden (chain.npz): hr = a band- and space-smoothed
     uniform cube, sr = its 7x7 box blur (a stand-in for the bicubic-degraded input; only its range and smoothness matter)."""
-    rng = np.random.Generator(np.random.PCG64(20))
+    rng = np.random.Generator(np.random.PCG64(20 + draw))
     c = rng.random((bands + 2, hw + 8, hw + 8)).astype(np.float64)
     c = (c[:-2] + c[1:-1] + c[2:]) / 3.0
 
@@ -92,3 +92,53 @@ CHAIN_T = 20          # the reference's shipped chain length (config/sr_sr3_16_1
 def chain_noise(group, k, shape=(1, 3, 128, 128)):
     """Noise tensor k of spectral group `group` in the chain golden: k = 0 is x_T, k = 1..T-1 the per-step draws in loop order."""
     return synth_tensor("chain.noise.g%d.k%d" % (group, k), shape)
+
+
+# ---- the chain fixture SET (tests/golden/chains/, make_golden_chains.py): weight set x noise draw x chain length
+CHAIN_SET = (("synth", 0, 20), ("orth", 0, 20), ("orth", 1, 20), ("synth", 1, 20))      # T = 20: the shipped validation setting
+CHAIN_LONG = ("orth", 2, 1000)                                                           # BASELINE.json's metric: the 1000-step loop
+CHAIN_TUNED_ON = ("synth", 0, 20)       # the ONE fixture precision policies may be selected on; the others are hold-outs
+
+
+def chain_cubes_draw(draw):
+    return chain_cubes(draw=draw)
+
+
+def chain_noise_draw(draw, group, k, shape=(1, 3, 128, 128)):
+    """Noise tensor k of spectral group `group` in draw `draw` (draw 0 = chain_noise, the draws of chain.npz)."""
+    return synth_tensor("chain.noise.g%d.k%d" % (group, k), shape, seed=draw)
+
+
+def weight_probe(key, w):
+    """Three float64 numbers that pin a parameter tensor without storing it: its norm and two fixed random projections."""
+    v = np.asarray(w, dtype=np.float64).ravel()
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(("probe." + key).encode())))
+    p = rng.standard_normal((2, v.size))
+    return [float(np.sqrt((v * v).sum())), float(p[0] @ v), float(p[1] @ v)]
+
+
+def orth_state_dict(keys, shapes, seed=0):
+    """The reference's own initialisation (model/networks.py:45-57,110-112: orthogonal_ with gain 1 on every Conv / Linear weight
+    in module order, zero biases; GroupNorm stays at 1 / 0) rebuilt from torch's RNG stream: `keys` in the reference's state_dict
+    order (stored in the fixture), `shapes` {key: shape}.  The fixture's w_probe rows check the result (chain_weights_check)."""
+    import torch
+    torch.manual_seed(seed)
+    sd = {}
+    for k in keys:
+        shp = tuple(shapes[k])
+        if len(shp) >= 2:
+            sd[k] = torch.nn.init.orthogonal_(torch.empty(shp), gain=1)
+        else:
+            sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+    return sd
+
+
+def chain_weights_check(sd, keys, probes, tol=1e-5):
+    """Largest deviation of the rebuilt tensors' probes from the fixture's, relative to the tensor norm."""
+    worst = 0.0
+    for k, want in zip(keys, probes):
+        got = weight_probe(k, sd[k].numpy())
+        nrm = max(want[0], 1e-30) * max(1.0, np.sqrt(sd[k].numel()) / 16)       # a projection of a unit-norm error is ~1
+        worst = max(worst, abs(got[0] - want[0]) / max(want[0], 1e-30), abs(got[1] - want[1]) / nrm, abs(got[2] - want[2]) / nrm)
+    assert worst < tol, "orthogonal weights were not reproduced: %g" % worst
+    return worst

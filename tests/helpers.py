@@ -37,3 +37,28 @@ def max_abs(a, b):
 
 def jload(arr):
     return json.loads(str(arr))
+
+
+FULL_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8], attn_res=[16],
+                 res_blocks=2, image_size=128)
+_ORTH = {}
+
+
+def chain_fixture(weights, draw, steps):
+    """One member of the chain fixture set (tests/golden/make_golden_chain.py, make_golden_chains.py): returns
+    (g, sd, hr, sr, noise) with g the stored reference outputs, sd the UNet's state dict as torch tensors (rebuilt, and for the
+    orthogonal set CHECKED against the fixture's probes), (hr, sr) the cubes and noise(group, k) the draws."""
+    from oracle import sr3_unet
+    from synth import chain_cubes_draw, chain_noise_draw, chain_weights_check, orth_state_dict
+    g = load_npz("chain.npz" if (weights, draw, steps) == ("synth", 0, 20) else "chains/%s_n%d_T%d.npz" % (weights, draw, steps))
+    shapes = sr3_unet.unet_param_shapes(FULL_UNET)
+    if weights == "synth":
+        sd = synth_sd(shapes, "unet_full.")
+    else:
+        if "sd" not in _ORTH:
+            keys = [str(k) for k in g["w_keys"]]
+            _ORTH["sd"] = orth_state_dict(keys, shapes)
+            chain_weights_check(_ORTH["sd"], keys, g["w_probe"])
+        sd = _ORTH["sd"]
+    hr, sr = chain_cubes_draw(draw)
+    return g, sd, hr, sr, (lambda gi, k: chain_noise_draw(draw, gi, k))

@@ -239,15 +239,21 @@ def unet_forward(m, sd, cfg, x, gamma):
 _REF = {}
 
 
-def run(spec, steps=CHAIN_T, seed=0):
+def run(spec, steps=CHAIN_T, seed=0, fixture=None):
     """seed = 0: the committed chain (reference outputs from chain.npz); other seeds: other noise draws, checked against the
-    fp32 oracle run on the same draws (the oracle matches the reference to 6e-7 on the committed chain)."""
+    fp32 oracle run on the same draws (the oracle matches the reference to 6e-7 on the committed chain).
+    fixture = (weights, draw, T): a member of the chain fixture set (reference outputs; tests/helpers.py: chain_fixture)."""
     m = Mode(spec)
-    cn = (lambda gi, k: chain_noise(gi, k)) if seed == 0 else (lambda gi, k: synth_tensor("chain.noise.g%d.k%d" % (gi, k), (1, 3, 128, 128), seed=seed))
-    g = np.load(os.path.join(HERE, "golden", "chain.npz"))
-    hr, sr = chain_cubes()
-    shapes = sr3_unet.unet_param_shapes(FULL)
-    sd = {k: torch.from_numpy(synth_param("unet_full." + k, s)) for k, s in shapes.items()}
+    if fixture is not None:
+        from helpers import chain_fixture
+        g, sd, hr, sr, cn = chain_fixture(*fixture)
+        seed = 0
+    else:
+        cn = (lambda gi, k: chain_noise(gi, k)) if seed == 0 else (lambda gi, k: synth_tensor("chain.noise.g%d.k%d" % (gi, k), (1, 3, 128, 128), seed=seed))
+        g = np.load(os.path.join(HERE, "golden", "chain.npz"))
+        hr, sr = chain_cubes()
+        shapes = sr3_unet.unet_param_shapes(FULL)
+        sd = {k: torch.from_numpy(synth_param("unet_full." + k, s)) for k, s in shapes.items()}
     gsd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "golden", "gae_cav_state.npz")).items()}
     sched = diffusion.noise_schedule(dict(schedule="cosine", n_timestep=CHAIN_T, linear_start=1e-6, linear_end=1e-2))
     ngr = g["x0"].shape[0]
@@ -288,11 +294,16 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())
     args = sys.argv[1:]
     seeds = [0]
+    fixtures = [None]
     if args and args[0].startswith("--seeds="):
         seeds = [int(v) for v in args.pop(0)[8:].split(",")]
-    for seed, spec in [(sd_, sp) for sd_ in seeds for sp in (["fp32"] if sd_ else []) + args]:
+    if args and args[0].startswith("--fixtures="):          # --fixtures=synth:0:20,orth:0:20,...
+        fixtures = [(a, int(b), int(c)) for a, b, c in (v.split(":") for v in args.pop(0)[11:].split(","))]
+    for fx, seed, spec in [(fx_, sd_, sp) for fx_ in fixtures for sd_ in seeds for sp in (["fp32"] if sd_ else []) + args]:
         t0 = time.time()
-        r = run(spec, seed=seed)
+        r = run(spec, seed=seed, fixture=fx)
+        if fx:
+            r["fixture"] = "%s:%d:%d" % fx
         r.pop("_y", None), r.pop("_lat", None)
         r["seconds"] = round(time.time() - t0, 1)
         print(json.dumps(r), flush=True)
