@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..precision import resolve_precision, step_precision
 from .unet import UNet
 
 
@@ -86,12 +87,21 @@ class ReverseRun:
         self.t_ptr = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
         self.cond = None if cond is None else cond.to(dev, torch.float32).contiguous()
         self.fused = isinstance(gd.denoise_fn, UNet)
-        self.graph = None
+        # precision schedule along the chain (precision.step_precision): mode of the step at t = T-1-k, k = 0..T-1; the host
+        # mirrors the device-side step counter (steps_done), so the choice costs no read-back
+        base = resolve_precision(precision if precision is not None else getattr(gd.denoise_fn, "precision", None)) if self.fused else precision
+        self.modes = [step_precision(base, float(gd._run_eps_gain[T - 1 - k])) if self.fused else base for k in range(T)]
+        self.graphs, self._eager_done = {}, set()
         self.steps_done = 0
 
-    def _enqueue(self):
+    @property
+    def graph(self):
+        """The captured step of the chain's base mode (None until captured)."""
+        return self.graphs.get(self.modes[-1])
+
+    def _enqueue(self, precision=None):
         gd = self.gd
-        eps = gd._denoise(self.cond, self.x, self.t_ptr, self.precision)
+        eps = gd._denoise(self.cond, self.x, self.t_ptr, self.modes[-1] if precision is None else precision)
         if self.zbuf is not None:
             self.zbuf.normal_()
         ops.p_sample_update(self.x, eps.contiguous(), gd._run_coef, self.t_ptr, self.T,
@@ -102,17 +112,20 @@ class ReverseRun:
     def step(self):
         if not self.wrap and self.steps_done >= self.T:
             raise RuntimeError("hsidm: the chain has run its %d steps (t would be -1); make a new run or use wrap=True" % self.T)
+        mode = self.modes[self.steps_done % self.T]
         if not (self.fused and self.gd.use_graph):
-            self._enqueue()
-        elif self.steps_done == 0:
-            self._enqueue()                              # eager first step: packs weights, warms the allocator
+            self._enqueue(mode)
+        elif mode not in self._eager_done:
+            self._enqueue(mode)                          # eager first step of a mode: packs weights, warms the allocator
+            self._eager_done.add(mode)
         else:
-            if self.graph is None:
+            g = self.graphs.get(mode)
+            if g is None:
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._enqueue()                      # recorded, not executed
-            self.graph.replay()
+                g = self.graphs[mode] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue(mode)                  # recorded, not executed
+            g.replay()
         self.steps_done += 1
 
     def run_all(self):
@@ -194,6 +207,9 @@ class GaussianDiffusion(nn.Module):
         }
         for name, val in table.items():
             self.register_buffer(name, torch.tensor(val, dtype=torch.float32, device=device))
+        # host float64 copy of the update kernel's coefficient columns (sqrt_recip, sqrt_recipm1, coef1, coef2, log variance)
+        self._coef_host = np.stack([table["sqrt_recip_alphas_cumprod"], table["sqrt_recipm1_alphas_cumprod"], table["posterior_mean_coef1"],
+                                    table["posterior_mean_coef2"], table["posterior_log_variance_clipped"]], axis=1)
         # device tables read by the kernels (not part of the reference state_dict -> non-persistent)
         coef = torch.stack([self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
                             self.posterior_mean_coef1, self.posterior_mean_coef2,
@@ -217,6 +233,7 @@ class GaussianDiffusion(nn.Module):
         if kind == "ddpm":
             self._run_T, self._run_coef, self._run_level = self.num_timesteps, self._coef, self._level
             self._run_level_host = self.sqrt_alphas_cumprod_prev
+            self._run_eps_gain = np.abs(self._coef_host[:, 2] * self._coef_host[:, 1])
         elif kind == "ddim":
             T = self.num_timesteps
             K = T if steps is None else int(steps)
@@ -233,6 +250,7 @@ class GaussianDiffusion(nn.Module):
             table = np.stack([np.sqrt(1.0 / a_t), np.sqrt(1.0 / a_t - 1), np.sqrt(a_prev) - c_xt * np.sqrt(a_t), c_xt,
                               np.log(np.maximum(sigma2, 1e-20))], axis=1)
             self._run_T = K
+            self._run_eps_gain = np.abs(table[:, 2] * table[:, 1])
             self._run_coef = torch.tensor(table, dtype=torch.float32, device=dev).contiguous()
             self._run_level_host = np.sqrt(np.append(1.0, a_t))
             self._run_level = torch.tensor(self._run_level_host, dtype=torch.float32, device=dev)

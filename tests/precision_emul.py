@@ -98,6 +98,8 @@ class Mode:
         self.cur = ""
         self.phase = 0                                             # step of the chain (w=dK)
         self.sm = kv.get("sm", "")
+        self.fs = int(kv.get("fs", 0))                             # fs=K: the LAST K steps of the chain (t < K) on the exact UNet
+        self.first = int(kv.get("is", 0))                          # is=K: the FIRST K steps of the chain on the exact UNet
 
     def _ovr(self, k, hw):
         return k not in self.lvl or hw in self.lvl[k]
@@ -257,20 +259,24 @@ def run(spec, steps=CHAIN_T, seed=0, fixture=None):
     gsd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "golden", "gae_cav_state.npz")).items()}
     sched = diffusion.noise_schedule(dict(schedule="cosine", n_timestep=CHAIN_T, linear_start=1e-6, linear_end=1e-2))
     ngr = g["x0"].shape[0]
+    nfull = ngr
+    ngr = min(ngr, int(os.environ.get("EMUL_GROUPS", ngr)))                           # EMUL_GROUPS=1: a quick look on one group (latents only)
     with torch.no_grad():
-        z = torch.from_numpy(g["z"])                                                  # the reference's own encoder output
+        z = torch.from_numpy(g["z"][:ngr])                                            # the reference's own encoder output
         x = torch.from_numpy(np.concatenate([cn(gi, 0) for gi in range(ngr)]))
-        den = (lambda xc, gam: sr3_unet.unet_forward(sd, FULL, xc, gam)) if spec == "fp32" else \
-              (lambda xc, gam: unet_forward(m, sd, FULL, xc, gam))
+        exact = lambda xc, gam: sr3_unet.unet_forward(sd, FULL, xc, gam)
+        den = exact if spec == "fp32" else (lambda xc, gam: unet_forward(m, sd, FULL, xc, gam))
         for i in reversed(range(CHAIN_T)):
             zn = torch.from_numpy(np.concatenate([cn(gi, CHAIN_T - i) for gi in range(ngr)])) if i > 0 else None
             m.phase = CHAIN_T - 1 - i
-            x = diffusion.p_sample_step(den, sched, x, z, i, zn)
+            x = diffusion.p_sample_step(exact if (i < m.fs or i >= CHAIN_T - m.first) else den, sched, x, z, i, zn)
             if CHAIN_T - i >= steps:
                 break
         lat = x.numpy()
         out = {"mode": spec}
-        if steps >= CHAIN_T:
+        if ngr < nfull:
+            out.update(groups=ngr, latents_rel=float(np.linalg.norm(lat.astype(np.float64) - g["x0"][:ngr]) / np.linalg.norm(g["x0"][:ngr].astype(np.float64))))
+        elif steps >= CHAIN_T:
             y = gae.gae_decode(gsd, 31, [x[i:i + 1] for i in range(ngr)], 8, 2).clamp(0, 1).numpy()
             a = hr[0].transpose(1, 2, 0)
             if seed == 0:
@@ -291,7 +297,7 @@ def run(spec, steps=CHAIN_T, seed=0, fixture=None):
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("EMUL_THREADS", os.cpu_count())))
     args = sys.argv[1:]
     seeds = [0]
     fixtures = [None]

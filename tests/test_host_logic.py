@@ -383,3 +383,24 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
     assert not pk1.wide and pk1.w_v2_lo is None and pk1.w_lo is not None      # (the LDS-tiled fallback always has both halves)
     pk32 = ops.PackedConv(w, None, "fp32")
     assert pk32.w_v2 is not None and pk32.w_v2_lo is not None and pk32.w_v2.dtype == torch.bfloat16 and pk32.w_hi.shape[2] == 32
+
+
+def test_precision_schedule_along_the_chain():
+    """precision.step_precision: in the fp16 family the steps whose update multiplies the denoiser's output error by >= 0.5 run in
+    the fp32 mode - with the reference's cosine schedule the first FOUR steps of a chain of any length (gains 31.6 - beta clamped at
+    0.999, reference diffusion.py:46 - then 1.50, 0.83, 0.58: near t = T the schedule's alpha-bar is ~ (T - t)^2, whatever T);
+    bf16 and fp32 chains are uniform."""
+    from hsi_dmgasr_amd import precision
+    from hsi_dmgasr_amd.sr3_modules import diffusion
+    gd = diffusion.GaussianDiffusion(torch.nn.Identity(), image_size=16, channels=3, conditional=True)
+    for T, wide in ((20, [19, 18, 17, 16]), (1000, [999, 998, 997, 996]), (100, [99, 98, 97, 96])):
+        gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2), "cpu")
+        gain = gd._run_eps_gain
+        assert gain.shape == (T,) and abs(gain[T - 1] - 31.59) < 0.01
+        np.testing.assert_allclose(gain, np.abs(gd.posterior_mean_coef1.double().numpy() * gd.sqrt_recipm1_alphas_cumprod.double().numpy()), rtol=1e-5)
+        for mode in ("fp16", "fp16x1", "fp16x2"):
+            assert [t for t in reversed(range(T)) if precision.step_precision(mode, gain[t]) == "fp32"] == wide, (T, mode)
+        for mode in ("bf16", "fp32"):
+            assert all(precision.step_precision(mode, gain[t]) == mode for t in range(T))
+    gd.set_sampler("ddim", steps=10, eta=0.0)                   # the strided sampler carries its own gains
+    assert gd._run_eps_gain.shape == (10,) and gd._run_eps_gain[9] > 1.0
