@@ -91,7 +91,7 @@ class Mode:
                     self.lvl[k] = [int(u) for u in lv.split("+")]
             setattr(self, k, v)
         self.gn = kv.get("gn", "fp32")
-        self.sk = kv.get("sk", "shra")
+        self.sk = kv.get("sk", "sSuhra")
         self.wl = kv["wl"].split("+") if "wl" in kv else None      # wl=final+ups.18: hi + lo weights on these units only
         self.stl = kv["stl"].split("+") if "stl" in kv else []     # stl=ups.18+ups.17: fp32 storage for the tensors of these units
         self.gnx = kv["gnx"].split("+") if "gnx" in kv else []     # gnx=final_conv: fp32 GroupNorm pairs in these units
@@ -105,11 +105,14 @@ class Mode:
         return k not in self.lvl or hw in self.lvl[k]
 
     def store(self, x, kind="s"):
-        """kind: s = residual stream (block2 / attention / stem / up / down outputs), h = block1 output, r = projection
-        output, a = attention internals (qkv, core output)."""
+        """kind: S = residual stream behind an identity skip (block2 of a Cin = Cout unit, attention output), s = behind a projection,
+        u = stem / up / down conv outputs, h = block1 output, r = projection output, a = attention internals (qkv, core output)."""
         if self.stl and any(self.cur.startswith(q) for q in self.stl) and kind in self.sk:
             return x
         if self.st and kind in self.sk and self._ovr("st", x.shape[-1]):
+            if self.st == "ctr":                            # rounded about its per-(image, channel) mean (diagnostic)
+                mu = x.mean(dim=(2, 3), keepdim=True)
+                return rnd(x - mu, self.t) + mu
             return x if self.st == "fp32" else split2(x, self.t)
         return rnd(x, self.t)
 
@@ -187,7 +190,8 @@ def resnet_block(m, sd, p, x, t_emb, groups):
         r = m.store(F.conv2d(m.conv_in(x), m.weight(sd[p + "res_conv.weight"], x.shape[-1]), sd[p + "res_conv.bias"]), "r")
     else:
         r = x
-    return block(m, sd, p + "block2.", h, groups, res=r)
+    # kind S: the stream leaves a block whose residual operand IS the stream (identity skip); s: behind a projection
+    return block(m, sd, p + "block2.", h, groups, res=r, kind="s" if (p + "res_conv.weight") in sd else "S")
 
 
 def self_attention(m, sd, p, x, groups):
@@ -198,7 +202,7 @@ def self_attention(m, sd, p, x, groups):
     score = torch.softmax(torch.einsum("bci,bcj->bij", q, k) / math.sqrt(c), dim=-1)
     o = m.store(torch.einsum("bij,bcj->bci", m.prob(score), v).reshape(b, c, hh, ww), "a")
     o = F.conv2d(o, m.weight(sd[p + "out.weight"], hh), sd[p + "out.bias"])
-    return m.store(o + x)
+    return m.store(o + x, "S")
 
 
 def unet_forward(m, sd, cfg, x, gamma):
@@ -206,7 +210,7 @@ def unet_forward(m, sd, cfg, x, gamma):
     downs, mid, ups = sr3_unet.unet_layout(cfg["in_channel"], cfg["out_channel"], cfg["inner_channel"], cfg["channel_mults"],
                                            cfg["attn_res"], cfg["res_blocks"], cfg["image_size"])
     t_emb = sr3_unet.noise_level_mlp(sd, gamma, cfg["inner_channel"])
-    x = m.store(x)
+    x = m.store(x, "u")
     feats = []
 
     def unit(p, e, x):
@@ -218,11 +222,11 @@ def unet_forward(m, sd, cfg, x, gamma):
         p = "downs.%d." % i
         m.cur = p
         if e[0] == "conv":
-            x = m.store(F.conv2d(x, m.weight(sd[p + "weight"], x.shape[-1]), sd[p + "bias"], padding=1))
+            x = m.store(F.conv2d(x, m.weight(sd[p + "weight"], x.shape[-1]), sd[p + "bias"], padding=1), "u")
         elif e[0] == "res":
             x = unit(p, e, x)
         else:
-            x = m.store(F.conv2d(m.conv_in(x), m.weight(sd[p + "conv.weight"], x.shape[-1]), sd[p + "conv.bias"], stride=2, padding=1))
+            x = m.store(F.conv2d(m.conv_in(x), m.weight(sd[p + "conv.weight"], x.shape[-1]), sd[p + "conv.bias"], stride=2, padding=1), "u")
         feats.append(x)
     for i, e in enumerate(mid):
         x = unit("mid.%d." % i, e, x)
@@ -233,7 +237,7 @@ def unet_forward(m, sd, cfg, x, gamma):
         else:
             m.cur = p
             x = F.interpolate(x, scale_factor=2, mode="nearest")
-            x = m.store(F.conv2d(m.conv_in(x), m.weight(sd[p + "conv.weight"], x.shape[-1]), sd[p + "conv.bias"], padding=1))
+            x = m.store(F.conv2d(m.conv_in(x), m.weight(sd[p + "conv.weight"], x.shape[-1]), sd[p + "conv.bias"], padding=1), "u")
     m.cur = "final_conv."
     return block(m, sd, "final_conv.", x, groups, last=True)
 

@@ -9,6 +9,16 @@ from hsi_dmgasr_amd import _lib
 from helpers import jload, load_npz, sub_shapes, synth_sd, synth_tensor
 
 pytestmark = pytest.mark.gpu
+
+# ONE forward of a whole UNet on the fp16 KERNELS (fp16 storage and operands, hi + lo weights on Cout <= 128) measures 1.07e-3 ...
+# 1.16e-3 against the reference (tiny / mid / full / non-square): 11-bit storage of ~70 tensors, of which the residual stream's
+# is the largest part (tests/precision_emul.py on the full-size forward: stream tensors in fp32 -27 %, fp32 GroupNorm pairs -10 %,
+# fp32 projection outputs -10 %, centred rounding -5 %).  That number is NOT one of north_star's quantities - those are the chain's
+# latents, cube, PSNR and SAM, gated at 1e-3 / 0.01 dB / 0.001 deg on five reference chains in tests/test_gpu_chain.py (fp16 mode:
+# 5.8e-4 worst) - because in the fp16 mode every step whose update passes more than half of the UNet's output error on to the
+# state runs on the fp32-mode kernels (precision.step_precision); a forward on the fp16 kernels never reaches an output with a
+# gain above 0.45.  The bound below is therefore a REGRESSION gate on the kernels (measured worst x 1.08), named as such.
+FWD_FP16 = 1.25e-3
 PRECS = ["fp32", "fp16", "bf16"]
 
 
@@ -168,7 +178,7 @@ def test_unet_forward_golden(dev, prec, name):
                   res_blocks=cfg["res_blocks"], dropout=0.2, image_size=cfg["image_size"], precision=prec).to(dev).eval()
     fill_synth(u, "unet_%s." % name)
     y = u(G(g[name + ".x"], dev), G(g[name + ".gamma"], dev))
-    check("unet_" + name, prec, y, g[name + ".y"], tol={"fp32": 1e-3, "fp16": 1.5e-3, "bf16": 6e-2}[prec])
+    check("unet_" + name, prec, y, g[name + ".y"], tol={"fp32": 1e-3, "fp16": FWD_FP16, "bf16": 6e-2}[prec])
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -182,7 +192,7 @@ def test_unet_full_size_golden(dev, prec):
     fill_synth(u, "unet_full.")
     x = G(synth_tensor("unet_full.x", (1, 6, 128, 128)), dev)
     y = u(x, G(g["full.gamma"], dev))
-    check("unet_full", prec, y, g["full.y"], tol={"fp32": 1e-3, "fp16": 1.5e-3, "bf16": 8e-2}[prec])
+    check("unet_full", prec, y, g["full.y"], tol={"fp32": 1e-3, "fp16": FWD_FP16, "bf16": 8e-2}[prec])
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -201,7 +211,7 @@ def test_unet_shipped_width_on_a_non_square_batch(dev, prec):
     gam = np.array([[0.8], [0.3], [0.02]], dtype=np.float32)
     y = u(G(x, dev), G(gam, dev))
     want = sr3_unet.unet_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(gam))
-    check("unet_wide_nonsquare", prec, y, want, tol={"fp32": 1e-3, "fp16": 1.5e-3, "bf16": 8e-2}[prec])
+    check("unet_wide_nonsquare", prec, y, want, tol={"fp32": 1e-3, "fp16": FWD_FP16, "bf16": 8e-2}[prec])
 
 
 def test_full_size_sampler_is_deterministic_and_finite(dev):
