@@ -265,6 +265,28 @@ def usable_cpus():
     return max(1, n)
 
 
+def gae_bytes(bands, n_subs, groups, esz, feats=64, tfeats=32, hw=128 * 128):
+    """HBM bytes of one patch through the group-autoencoder, two ways (these 64-channel maps are HBM-bound, 144-288 FLOP/B):
+    `unit` - the fused-unit minimum: every unit (head conv, ResBlock, ResAttentionBlock, final conv, overlap-average) reads its
+    input once and writes its output once, intermediates inside a unit do not count; `launch` - what this build's launches move
+    (a ResBlock is two 3x3 launches with h and the residual in between, a ResAttentionBlock two 1x1 launches + the scale /
+    residual pass that has to wait for the global average).  esz: bytes per stored activation (4 in the fp32 mode)."""
+    pad8 = lambda c: (c + 7) // 8 * 8
+    F, S = feats, esz
+
+    def branch(cin, f, nblk):            # head + nblk x (ResBlock + ResAttentionBlock), in stored elements per pixel: (unit, launch)
+        return (pad8(cin) + f) + nblk * 4 * f, (pad8(cin) + f) + nblk * 12 * f + f
+    eu, el = branch(n_subs, F, 3)
+    enc_unit = groups * hw * (n_subs * 4 + pad8(n_subs) * S + eu * S + F * S + 3 * 4)
+    enc_launch = groups * hw * (n_subs * 4 + pad8(n_subs) * S + el * S + F * S + 3 * 4)
+    du, dl = branch(3, F, 3)
+    tu, tl = branch(bands, tfeats, 2)
+    common = groups * hw * n_subs * 4 + hw * bands * 4 + hw * (bands * 4 + pad8(bands) * S) + hw * (tfeats * S + 2 * bands * 4)
+    dec_unit = groups * hw * (3 * 4 + 8 * S + du * S + F * S + n_subs * 4) + common + hw * tu * S
+    dec_launch = groups * hw * (3 * 4 + 8 * S + dl * S + F * S + n_subs * 4) + common + hw * tl * S
+    return dict(encode=dict(unit=enc_unit, launch=enc_launch), decode=dict(unit=dec_unit, launch=dec_launch))
+
+
 def gae_bench(dev, patches, reps=5, bands=31, n_subs=8, n_ovls=2, groups=5, flops=None):
     """Group-autoencoder encode / decode of `patches` cubes of `bands` x 128 x 128 (G spectral groups stacked on the batch axis),
     pretrained-checkpoint architecture (CAVE: n_subs 8, n_ovls 2; Chikusei: 16 / 4, G = 11; 64 features) in every
@@ -301,6 +323,12 @@ def gae_bench(dev, patches, reps=5, bands=31, n_subs=8, n_ovls=2, groups=5, flop
             rec[name + "_ms"] = best
             rec[name + "_tflops"] = tf
             rec[name + "_frac_of_mfma_peak"] = tf / MFMA_BF16_PEAK_TFLOPS
+            by = gae_bytes(bands, n_subs, groups, 4 if prec == "fp32" else 2)[name]
+            # HBM axis: algorithmic bytes under the fused-unit definition, and the bytes this build's launches move, per second
+            rec[name + "_hbm"] = dict(unit_bytes=by["unit"] * patches, launch_bytes=by["launch"] * patches,
+                                      unit_GBps=by["unit"] * patches / (best * 1e-3) / 1e9, launch_GBps=by["launch"] * patches / (best * 1e-3) / 1e9,
+                                      unit_frac_of_hbm=by["unit"] * patches / (best * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                      launch_frac_of_hbm=by["launch"] * patches / (best * 1e-3) / 1e9 / HBM_PEAK_GBPS)
         rec["dPSNR_dB_vs_fp32_mode"] = abs(float(q[0] - ref_q[0]))
         rec["dSAM_deg_vs_fp32_mode"] = abs(float(q[1] - ref_q[1]))
         rec["within_0.01dB_0.001deg"] = bool(rec["dPSNR_dB_vs_fp32_mode"] <= 0.01 and rec["dSAM_deg_vs_fp32_mode"] <= 1e-3)
