@@ -300,7 +300,7 @@ def gae_bench(dev, patches, reps=5, bands=31, n_subs=8, n_ovls=2, groups=5, flop
     x = ((x[:, :-2] + x[:, 1:-1] + x[:, 2:]) / 3.0 if bands > 2 else x)                    # smooth along the band axis
     x = torch.nn.functional.pad(x, (0, 0, 0, 0, 1, 1), mode="replicate")[:, :bands].contiguous().to(dev)
     sd, ref_q = None, None
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ("fp32", "fp16"):
         m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=n_subs, n_ovls=n_ovls, n_colors=bands, n_feats=64, precision=prec).to(dev).eval()
         if sd is None:
             sd = {k: v.clone() for k, v in m.state_dict().items()}

@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("film", _vp), ("film_stride", _i32), ("res", _vp), ("res_scale", _f32), ("out", _vp),
                 ("stats", _vp), ("B", _i32), ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32),
                 ("Cout", _i32), ("ksize", _i32), ("stride", _i32), ("ups", _i32), ("act", _i32),
-                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32), ("workspace", _vp), ("workspace_bytes", _i64), ("w_v2_lo", _vp)]
+                ("out_nchw", _i32), ("prec", _i32), ("bn", _i32), ("workspace", _vp), ("workspace_bytes", _i64), ("w_v2_lo", _vp),
+                ("w_v2_ls", _vp), ("w_v2_li", _vp)]
 
 
 class WgradItem(C.Structure):

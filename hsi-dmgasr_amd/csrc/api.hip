@@ -25,7 +25,7 @@ int conv_v2_run_f16w(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t
 int conv_v2_run_f32x3(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 int conv_v2_slots();
-int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, hipStream_t s);
+int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, int spl, hipStream_t s);
 void conv_v2_set_stamps(unsigned long long* p);
 int conv_sk_parts(int B, int H, int W, int Cout, int nchunks);
 int conv_sk_run(const bf16* src0, const bf16* src1, int C0, int C1, const float2* gn_ab, int silu, const bf16* w, const float* bias,
@@ -105,10 +105,11 @@ struct DebugTable {
         v[hsidm::DBG_V2_ABL] = env_int("HSIDM_V2_ABL", 0);
         v[hsidm::DBG_SK_MULT] = env_int("HSIDM_SK_MULT", 0);
         v[hsidm::DBG_NO_SPLIT_K] = getenv("HSIDM_NO_SPLIT_K") ? 1 : 0;
+        v[hsidm::DBG_NO_SPARSE_LO] = getenv("HSIDM_NO_SPARSE_LO") ? 1 : 0;
     }
 };
 DebugTable g_debug;          // constructed when the library is loaded
-const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K"};
+const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO"};
 }  // namespace
 int hsidm::debug_get(int key) { return g_debug.v[key].load(std::memory_order_relaxed); }
 
@@ -128,6 +129,7 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     if (!d) return HSIDM_E_BADARG;
     if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3 && d->prec != HSIDM_F16) return HSIDM_E_BADARG;
     if (d->w_v2_lo && (d->prec == HSIDM_BF16 || !d->w_v2)) return HSIDM_E_BADARG;
+    if ((d->w_v2_ls || d->w_v2_li) && (!d->w_v2_lo || !d->w_v2_ls || !d->w_v2_li || d->prec != HSIDM_F16)) return HSIDM_E_BADARG;
     if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
     if (d->ksize != 3 && d->ksize != 1) return HSIDM_E_BADARG;
     if (d->stride != 1 && d->stride != 2) return HSIDM_E_BADARG;
@@ -319,6 +321,8 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.C0 = p.ph[0].C0; v.C1 = p.ph[0].C1; v.nchunks = p.ph[0].nchunks;
         v.w = reinterpret_cast<const bf16*>(d->w_v2);
         v.w_lo = reinterpret_cast<const bf16*>(d->w_v2_lo);
+        v.w_ls = reinterpret_cast<const bf16*>(d->w_v2_ls);
+        v.w_li = reinterpret_cast<const int*>(d->w_v2_li);
         const int np = d->w_v2_lo ? 2 : 1;
         auto v2_run = [&](int tk, int bn_, int xf_) {
             if (d->prec == HSIDM_F32X3) return conv_v2_run_f32x3(tk, bn_, xf_, v, s);
@@ -332,7 +336,9 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
         if (path == PATH_V3) {
             v.steps_per_item = steps;
-            return conv_v3_run(v, d->out_nchw, elem, np, s);
+            // the second weight pass as a 2:4 structured-sparse one when the caller packed it (HSIDM_NO_SPARSE_LO=1: diagnostic A/B switch)
+            const int spl = np == 2 && d->w_v2_ls && d->w_v2_li && !d->out_nchw && !debug_get(DBG_NO_SPARSE_LO);
+            return conv_v3_run(v, d->out_nchw, elem, np, spl, s);
         }
         const bool dn4 = d->stride == 2;
         if (dn4) v.nchunks = 4 * p.ph[0].nchunks;

@@ -43,7 +43,9 @@ struct ConvV2Params {
     const f32x4* gn_ab;     // [B][Ctot/2] = (scale, shift) pairs of two channels, or null
     int C0, C1, nchunks;
     const bf16* w;          // packed [step][Cout_pad/32][kk 4][lane 64][8], step = chunk*9 + tap
-    const bf16* w_lo;       // NP = 2 kernels: the low halves of the weights (w + w_lo ~ 22 significant bits), same layout; else null
+    const bf16* w_lo;       // NP = 2 kernels: the low halves of the weights (w + w_lo: an absolute granularity of 6e-8 - the low halves are fp16 subnormals - i.e. ~18-19 significant bits at |w| ~ 0.03), same layout; else null
+    const bf16* w_ls;       // sparse-lo kernels (conv_v3.hip, SPL): the low halves 2:4-compressed, [step][Cout_pad/32][2][64][8] (include/hsidm.h, w_v2_ls)
+    const int* w_li;        // ... and their index words [step][Cout_pad/32][64]
     const float* bias;
     const float* film;
     int film_stride;

@@ -47,14 +47,25 @@ static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 //   residual or statistics) - the last launch of a bf16 step that ran on the generic kernel (415 us at batch 240).
 // E: element type (bf16 | fp16); NP = 2: a second MFMA pass on the weights' low halves (conv_v2.h, V2Cfg) - these layers run the
 // matrix pipe a third of the time, so the pass is nearly free and the weights of the level whose output IS the network's output
-// carry ~22 bits; the weight ring is then 6 (high, low) fragment pairs fetched five k-slices ahead (the same registers).
-template <int WN_, bool NCHW_, typename E = bf16, int NP = 1>
+// carry ~18-19 significant bits (subnormal low halves, 6e-8 granularity); the weight ring is then 6 (high, low) fragment pairs fetched five k-slices ahead (the same registers).
+// SPL (fp16, NP = 2, WN = 2): the second weight pass on v_smfmac_f32_16x16x64_f16 with the low halves 2:4-compressed (hsidm.h: w_v2_ls /
+// w_v2_li).  The sparse operand is the instruction's A side, so in this form the WEIGHTS are the A operand of both passes and the
+// accumulators come out transposed: lane (c = pixel column, g) holds couts 16 nh + 4g .. + 3 of its pixel.  One sparse instruction
+// covers the 64 channels of a tap (both 32-channel slices: its dense operand is simply the two activation fragments of the tap side by
+// side) at ~1.2x the cycles of one dense 16x16x32 (tools/ubench/smfmac_rate.hip) - the second pass costs ~0.6 of its dense form, and
+// the low halves lose the smaller two of every four values: 20 % of their energy, i.e. of a 2^-12 correction (tests/precision_emul.py,
+// w=x2s: the 20-step chain moves from 5.38e-4 to 5.50e-4).  Sub-steps run in the order (tap, row r, slice q): the tap's four dense
+// weight fragments stay in registers for both rows; two register sets alternate between taps, one tap of lookahead.
+typedef _Float16 f16x16v __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int WN_, bool NCHW_, typename E = bf16, int NP = 1, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using namespace v3;
     using EL = Elem<E>;
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
-    constexpr bool FRG = NP == 2;
+    static_assert(!SPL || (NP == 2 && WN_ == 2 && !NCHW_ && !__is_same(E, bf16)), "sparse low halves: fp16, two passes, the 64-cout form");
+    constexpr bool FRG = NP == 2 && !SPL;
     constexpr int FS = 6, FL = 4;                               // a k-slice pair keeps its two fragments for both row halves: FL <= FS - 2
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -88,9 +99,20 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + wl_off;
     auto frag_off = [](int e) __attribute__((always_inline)) -> int { return (e >> 1) * (2 * 64 * 8) + (e & 1) * (16 * 8); };
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
-    x8 ring[FRG ? 1 : 3][4];
+    x8 ring[(FRG || SPL) ? 1 : 3][4];
     x8 fring[FRG ? FS : 1], fring_lo[FRG ? FS : 1];
+    // SPL: register sets (tap & 1): four dense fragments e = 2q + nh, the two sparse halves, one index word (low / high 16 bits = cout half)
+    x8 whi[SPL ? 8 : 1], wls[SPL ? 4 : 1];
+    int wli[SPL ? 2 : 1];
+    const E* lsp = reinterpret_cast<const E*>(SPL ? p.w_ls : p.w) + ((size_t)wn * 2 * 64 + lane) * 8;
+    const int* lip = (SPL ? p.w_li : reinterpret_cast<const int*>(p.w)) + (size_t)wn * 64 + lane;
     int wnext = 0;
+    auto s_issue = [&](int set, int part) __attribute__((always_inline)) {      // part 0..3 of weight step wnext into register set `set`
+        whi[SPL ? set * 4 + part : 0] = *reinterpret_cast<const x8*>(wlane + (size_t)wnext * wstep_stride + frag_off(part));
+        if (part < 2) wls[SPL ? set * 2 + part : 0] = *reinterpret_cast<const x8*>(lsp + ((size_t)wnext * nsw * 2 + part) * (64 * 8));
+        if (part == 2) wli[SPL ? set : 0] = lip[(size_t)wnext * nsw * 64];
+        if (part == 3) wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
+    };
     auto b_issue = [&](x8 (&dst)[4]) __attribute__((always_inline)) {
         const E* src = wlane + (size_t)wnext * wstep_stride;
 #pragma unroll
@@ -216,7 +238,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 
 
     // prologue: two weight steps in flight, raw vectors of (first item, chunk 0) requested
-    if (!FRG) {
+    if constexpr (SPL) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) s_issue(0, f);
+    } else if (!FRG) {
         b_issue(ring[0]);
         b_issue(ring[1]);
     } else {
@@ -236,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int tile = tile_of(item);
         const int b = div_tpi(tile);
         float ep_add[2] = {0.f, 0.f}, ep_bias[2] = {0.f, 0.f};  // FiLM / bias of the lane's couts [16-cout half]: loaded in the last chunk
+        f32x4 ep4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // SPL: bias + FiLM of couts 16 nh + 4g .. + 3, loaded in the epilogue
 
         for (int chunk = 0; chunk < nch; ++chunk) {
             commit_all();                                       // hreg holds (item, chunk): transform -> LDS
@@ -257,6 +283,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 // late at the mercy of the allocator: a spill or a select on it reads it too early.  In-box A/B: equal time.)
                 int lane_s = lane_id_now();
                 asm volatile("" : "+v"(lane_s));
+                if constexpr (SPL) {
+                    // (the eight per-cout values of this form are loaded at the start of the epilogue instead: sixteen registers held
+                    // through the last chunk's matrix phase made the allocator spill inside it)
+                } else {
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     const int n_raw = wn * 32 + 16 * nh + (lane_s & 15);
@@ -264,10 +294,63 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     if (p.film) ep_add[nh] = p.film[(size_t)b * p.film_stride + n_s];
                     if (p.bias) ep_bias[nh] = p.bias[n_s];
                 }
+                }
             }
             HSIDM_SETPRIO(1);
             // A operands: ring over the 36 sub-steps w = 4 tap + 2 q + r of the chunk (q: 32-channel slice of the tap, r: row of the
             // tile-row pair); sub-step w runs 2 MR (x NP) MFMAs - both 16-cout halves on the slice's two weight fragments 4 tap + 2 q + n
+            if constexpr (SPL) {
+                // sub-step w = 4 tap + 2 r + q; activations: three-deep ring, fetched one sub-step ahead (the sparse instruction of
+                // (r, q = 1) still reads the fragment of (r, q = 0) while the fragment of the next sub-step arrives)
+                x8 a[3][MR];
+                auto a_fetch = [&](int w) __attribute__((always_inline)) {
+                    const int tp = w >> 2;
+                    const int off = (tp / 3 + ((w >> 1) & 1)) * RP + (tp % 3) * PSTR + (w & 1) * 32;
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr) a[w % 3][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
+                };
+                a_fetch(0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int set = tap & 1;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int w = tap * 4 + kk, r = kk >> 1, q = kk & 1;
+                        if (w + 1 < 36) a_fetch(w + 1);
+                        s_issue(tap == 8 ? 1 : set ^ 1, kk);       // the next tap's weights (tap 8: the next chunk's first tap, moved to set 0 below)
+                        if (q == 0 && tap == 0 && chunk == 0) {   // first use of these accumulators: C = 0 as the inline constant (uniform branch)
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int mr = 0; mr < MR; ++mr) acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + nh : 0], a[w % 3][mr], zero);
+                        } else {
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int mr = 0; mr < MR; ++mr)
+                                    acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + 2 * q + nh : 0], a[w % 3][mr], acc[mr][r][nh]);
+                        }
+                        if (q == 1) {                             // the tap's 64 channels of row r against the sparse low halves
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int mr = 0; mr < MR; ++mr) {
+                                    const f16x16v bb = __builtin_shufflevector(a[(w + 2) % 3][mr], a[w % 3][mr], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                                    if (nh == 0) acc[mr][r][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 : 0], bb, acc[mr][r][0], wli[SPL ? set : 0], 0, 0);
+                                    else         acc[mr][r][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 + 1 : 0], bb, acc[mr][r][1], wli[SPL ? set : 0], 0, 1);
+                                }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // nine taps per chunk: the prefetch of tap 8 went to set 1, where tap 0 of the next chunk expects set 0
+#pragma unroll
+                for (int f = 0; f < 4; ++f) whi[f] = whi[SPL ? 4 + f : 0];
+                wls[0] = wls[SPL ? 2 : 0];
+                wls[SPL ? 1 : 0] = wls[SPL ? 3 : 0];
+                wli[0] = wli[SPL ? 1 : 0];
+            } else {
             constexpr int AD = NP == 2 ? 2 : 3;                 // (conv_v2.h: one sub-step of lookahead when it carries twice the MFMAs)
             x8 a[AD][MR];
             auto a_fetch = [&](int w) __attribute__((always_inline)) {
@@ -310,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            }
             HSIDM_SETPRIO(0);
             if (chunk == 0) HSIDM_STAMP(it, 4);
             lds_barrier();                                      // every wave is done reading: the tile may be overwritten
@@ -323,6 +407,16 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         const int oy0 = try_e * TH, ox0 = (tr - try_e * p.tiles_x) * TW;
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) ep_add[nh] += ep_bias[nh];
+        if constexpr (SPL) {                                    // four consecutive couts per half: one 16-byte load each
+            int lane_s = lane_id_now();
+            asm volatile("" : "+v"(lane_s));
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int n4 = wn * 32 + 16 * nh + 4 * (lane_s >> 4);
+                if (p.film) ep4[nh] = *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n4);
+                if (p.bias) ep4[nh] += *reinterpret_cast<const f32x4*>(p.bias + n4);
+            }
+        }
         if constexpr (NCHW_) {
             // fp32 NCHW straight from the accumulator layout: lane = cout 16 nh + lane % 16 (3 live lanes), the four registers of
             // an accumulator = pixel columns 4 (lane / 16) .. + 3 of one tile row: one 16-byte store each
@@ -380,6 +474,26 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                     for (int v4 = 0; v4 < 2; ++v4) rv[v4] = *reinterpret_cast<const x8*>(reinterpret_cast<const E*>(p.res) + vec_base(v4) + lane_el);
                 }
+                if constexpr (SPL) {
+                    // transposed accumulators: the lane holds couts 16 nh + 4 lg .. + 3 of pixel column lc -> ONE 8-byte patch write per
+                    // (row, cout half) instead of four 2-byte ones
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) {
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v[j] = fmaf(acc[g][r][nh][j], kLn2, ep4[nh][j]);
+                                if (LEAKY) v[j] = v[j] > 0.f ? v[j] : 0.01f * v[j];
+                            }
+                            const x2 p0 = cvt_pair_hw<E>(v[0], v[1]), p1 = cvt_pair_hw<E>(v[2], v[3]);
+                            u32x2 pk;
+                            pk[0] = __builtin_bit_cast(unsigned, p0);
+                            pk[1] = __builtin_bit_cast(unsigned, p1);
+                            *reinterpret_cast<u32x2*>(scr + (16 * r + lc_e) * SCR_STR + 16 * nh + 4 * lg_e) = pk;
+                        }
+                } else {
                 // patch row = 16 (row of the pair) + pixel column; the lane holds columns 4 lg .. + 3 of couts 16 nh + lc
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
@@ -399,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                             scr[at] = pr[0];
                             scr[at + SCR_STR] = pr[1];
                         }
+                }
 #pragma unroll
                 for (int v4 = 0; v4 < 2; ++v4) {
                     const x8 raw = *reinterpret_cast<const x8*>(scr + (pl0 + 16 * v4) * SCR_STR + cq * 8);
@@ -414,13 +529,13 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         }
                     }
                     *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(v4) + lane_el) = o;
-                    if (RES) {
+                    if (RES || SPL) {                                           // (SPL: a lane of the accumulator layout holds eight couts - the vector domain is cheaper)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
                     }
                 }
             }
-            if (p.stats && !RES) {
+            if (p.stats && !RES && !SPL) {
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {                                    // the four lanes lg = 0..3 of a cout hold its column quarters
                     float a = as1[nh] + lane_xor<16>(as1[nh], lane_e), d = as2[nh] + lane_xor<16>(as2[nh], lane_e);
@@ -430,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         p.stats[((size_t)b * (tiles_per_img * WM) + tr * WM + wm) * p.Cout + wn * 32 + 16 * nh + lc_e] = make_float2(a, d);
                 }
             }
-            if (p.stats && RES) {                                                   // one entry per (image, tile, pixel half)
+            if (p.stats && (RES || SPL)) {                                          // one entry per (image, tile, pixel half)
                 const bool hi0 = (lane_e & 4) != 0, hi1 = (lane_e & 8) != 0, hi2 = (lane_e & 16) != 0, hi3 = (lane_e & 32) != 0;
                 float a8[8], a4[4], a2[2];
 #pragma unroll
@@ -456,16 +571,16 @@ extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds
 
 // Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller); nchw = 0: Cout == 64, NHWC bf16 out;
 // nchw = 1: Cout <= 32 (one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
-template <int WN_, bool NCHW_, typename E, int NP>
+template <int WN_, bool NCHW_, typename E, int NP, bool SPL = false>
 static int launch_v3(ConvV2Params& p, int G, hipStream_t s) {
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_, E, NP>, v3::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_, E, NP>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
+    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_, E, NP, SPL>, v3::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_, E, NP, SPL>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
-// elem: 0 bf16, 1 fp16; np = 2 (fp16 only): p.w_lo holds the weights' low halves
-int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, hipStream_t s) {
+// elem: 0 bf16, 1 fp16; np = 2 (fp16 only): p.w_lo holds the weights' low halves; spl (np = 2, NHWC form): p.w_ls / p.w_li hold them 2:4-compressed
+int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, int spl, hipStream_t s) {
     const int g3_slots = 2 * device_cus();
     p.tiles_x = p.Wout / v3::TW;
     p.tiles_y = p.Hout / v3::TH;
@@ -484,6 +599,7 @@ int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, hipStream_t s) {
     if (G == 0) G = p.total_items;
     if (elem == 0 && np == 1) return nchw ? launch_v3<1, true, bf16, 1>(p, G, s) : launch_v3<2, false, bf16, 1>(p, G, s);
     if (elem == 1 && np == 1) return nchw ? launch_v3<1, true, f16, 1>(p, G, s) : launch_v3<2, false, f16, 1>(p, G, s);
+    if (elem == 1 && np == 2 && spl && !nchw) return launch_v3<2, false, f16, 2, true>(p, G, s);
     if (elem == 1 && np == 2) return nchw ? launch_v3<1, true, f16, 2>(p, G, s) : launch_v3<2, false, f16, 2>(p, G, s);
     return HSIDM_E_UNSUPPORTED;
 }

@@ -127,6 +127,12 @@ class PackedConv:
             hi = None if t is None else t.to(et).contiguous()
             setattr(self, name, hi)
             setattr(self, name + "_lo", (t - hi.float()).to(et).contiguous() if (hi is not None and self.wide) else None)
+        # fp16 hi + lo layers on the plain 3x3 schedule: the low halves once more, 2:4 structured-sparse, for the kernels that run the
+        # second pass on v_smfmac (include/hsidm.h: w_v2_ls / w_v2_li; today conv_v3's 64-cout form)
+        self.w_v2_ls = self.w_v2_li = None
+        if (self.prec == _lib.F16 and self.wide and self.w_v2_lo is not None and self.ksize == 3 and proj_weight is None and
+                not out_nchw and not self.tap_major and self.cin % 64 == 0):
+            self.w_v2_ls, self.w_v2_li = PackedConv._sparse_lo(w - self.w_hi.float(), meta["cpad"])
 
     def _set_meta(self, meta, precision, out_nchw):
         self.ksize, self.cin, self.cout, self.bn = meta["ksize"], meta["cin"], meta["cout"], meta["bn"]
@@ -141,6 +147,7 @@ class PackedConv:
         self.w_hi, self.w_lo, self.w_v2, self.w_up4, self.w_dn4, self.bias = w_hi, w_lo, w_v2, None, w_dn4, bias
         # fp32 mode: the low halves of the register-streaming layouts (the persistent kernel's fp32 form reads both)
         self.wide, self.w_v2_lo, self.w_up4_lo, self.w_dn4_lo = w_v2_lo is not None, w_v2_lo, None, w_dn4_lo
+        self.w_v2_ls = self.w_v2_li = None
         return self
 
     @staticmethod
@@ -148,6 +155,26 @@ class PackedConv:
         """[step][Cout_pad][64] -> [step][Cout_pad/32][kk 4][lane = (k-half, cout r)][8]: one wave-load per MFMA B fragment."""
         st = w_steps.shape[0]
         return w_steps.reshape(st, cpad // 32, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+
+    @staticmethod
+    def _sparse_lo(lo, cpad):
+        """[step][Cout_pad][64] fp32 low halves -> (values fp16 [step][Cout_pad/32][half 2][lane 64][8], index words int32
+        [step][Cout_pad/32][lane 64]): of every four consecutive input channels the two of larger magnitude, in the operand order of
+        v_smfmac_f32_16x16x64_f16's A side (include/hsidm.h: w_v2_ls; measured by tools/ubench/smfmac_probe.hip): lane 16 * kgroup +
+        cout % 16 holds channels 16 * kgroup .. + 15; its stored slots 2m, 2m + 1 are the kept values of channels 16 * kgroup + 4m .. + 3
+        in ascending position, bits [2s+1 : 2s] of the index half-word the position of slot s; low half-word = first 16-cout half."""
+        st = lo.shape[0]
+        g = lo.reshape(st, cpad, 16, 4)
+        pos = g.abs().topk(2, dim=3).indices.sort(dim=3).values                     # [st, cpad, 16 groups, 2] positions, ascending
+        vals = g.gather(3, pos)
+        # cout = 32 * slice + 16 * half + i; group index = 4 * kgroup + m; slot = 2 * m + s
+        vals = vals.reshape(st, cpad // 32, 2, 16, 4, 4, 2).permute(0, 1, 2, 4, 3, 5, 6).reshape(st, cpad // 32, 2, 64, 8)
+        shifts = (2 * (2 * torch.arange(4, device=lo.device).view(4, 1) + torch.arange(2, device=lo.device).view(1, 2))).to(torch.int64)   # [m, s]
+        word = (pos.reshape(st, cpad // 32, 2, 16, 4, 4, 2).to(torch.int64) << shifts).sum(dim=(5, 6))       # [st, slice, half, i, kgroup] 16-bit words
+        word = word.permute(0, 1, 2, 4, 3).reshape(st, cpad // 32, 2, 64)
+        idx = (word[:, :, 0] | (word[:, :, 1] << 16))
+        idx = torch.where(idx >= 2 ** 31, idx - 2 ** 32, idx).to(torch.int32)
+        return vals.to(torch.float16).contiguous(), idx.contiguous()
 
     @staticmethod
     def _steps(w, cpad, bk):
@@ -206,6 +233,8 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     if stride == 2:
         d.w_v2, w_v2_lo = (_lib.ptr(pw.w_dn4), pw.w_dn4_lo) if planes else (None, None)
     d.w_v2_lo = _lib.ptr(w_v2_lo) if d.w_v2 else None
+    plain = d.w_v2 and not folded and stride == 1 and getattr(pw, "w_v2_ls", None) is not None and w_v2_lo is pw.w_v2_lo
+    d.w_v2_ls, d.w_v2_li = (_lib.ptr(pw.w_v2_ls), _lib.ptr(pw.w_v2_li)) if plain else (None, None)
     if film is not None:          # a column slice of the [B, F] FiLM table
         assert film.stride(1) == 1 and film.shape == (B, pw.cout)
         d.film, d.film_stride = film.data_ptr(), film.stride(0)

@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ops
 from .._lib import act_dtype
-from ..precision import is_16bit, resolve_precision
+from ..precision import is_16bit, resolve_precision, wide_weights
 
 
 def exists(x):
@@ -205,7 +205,10 @@ class ResnetBlock(_HipModule):
                 # Few pixel tiles and a long contraction (one or two CAVE images per GPU on the 32x32 ... 8x8 levels): block2 runs in
                 # its split-K form, where the projection is a few more one-tap chunks of the same launch.
                 B, H, W, _ = h.shape
-                if is_16bit(precision) and B * H * W <= 16384 and h.shape[3] % 128 == 0 and h.shape[3] >= 256:
+                # (not for a layer with hi + lo weights: the split-K kernel has no second weight pass and refuses the descriptor,
+                # so the offer would only pack dead layouts and pay a workspace query per forward)
+                if is_16bit(precision) and B * H * W <= 16384 and h.shape[3] % 128 == 0 and h.shape[3] >= 256 and \
+                        not wide_weights(precision, h.shape[3], h.shape[3], 3):
                     out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, sk_only=True)
                     if out is not None:
                         return out

@@ -47,7 +47,7 @@ extern "C" {
 int hsidm_version(void);
 const char* hsidm_error_string(int code);
 /* Diagnostic dispatch switches for A/B measurements and tests: "NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1",
- * "V2_ABL", "SK_MULT", "NO_SPLIT_K".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
+ * "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
  * reads the environment.  Returns the previous value (>= 0) or HSIDM_E_BADARG for an unknown name. */
 int hsidm_debug_switch(const char* name, int value);
 
@@ -124,9 +124,17 @@ typedef struct hsidm_conv_desc {
                                  hsidm_conv_workspace_bytes first, 0 = launch the projection separately         */
     int64_t workspace_bytes;
     const void*  w_v2_lo;     /* optional (HSIDM_F16 with w_v2): fp16(W - fp16(W)) in the layout of w_v2 - the weights then carry
-                                 ~22 significant bits for twice the matrix instructions (the weight rounding
+                                 ~18-19 significant bits (the low halves are fp16 subnormals for |w| < 0.125: absolute granularity 6e-8) for twice the matrix instructions (the weight rounding
                                  is the one systematic error of a 16-bit mode; the pass is nearly free on layers bound by the
                                  staging transform).  Not taken by the split-K form and the 256-cout items                        */
+    const void*  w_v2_ls;     /* optional (with w_v2_lo, plain 3x3): the low halves again, 2:4 structured-sparse - of every four consecutive
+                                 input channels (per cout and tap) the two of larger magnitude - as the A operand of
+                                 v_smfmac_f32_16x16x64_f16: fp16 [step][Cout_pad/32][half 2][lane 64][8]; lane = 16 * kgroup + cout % 16 of the
+                                 16-cout half holds channels 16 * kgroup .. + 15 of the step's 64: stored slots 2m, 2m + 1 = the kept values of
+                                 channels 16 * kgroup + 4m .. + 3 (measured semantics: tools/ubench/smfmac_probe.hip).  A kernel that takes it
+                                 runs the second weight pass at ~0.6 of its dense cost on 80 % of the low halves' energy                  */
+    const void*  w_v2_li;     /* with w_v2_ls: int32 [step][Cout_pad/32][lane 64]: bits [2s+1 : 2s] of the low (high) 16 bits = position, within
+                                 its group of four channels, of stored slot s of the first (second) 16-cout half                         */
 } hsidm_conv_desc;
 
 int hsidm_conv2d(const hsidm_conv_desc* d, void* stream);

@@ -133,6 +133,16 @@ class Mode:
             return w
         if self.w == "x2" and self._ovr("w", hw):
             return split2(w, self.t)
+        if self.w == "x2s" and self._ovr("w", hw):          # hi + a 2:4 structured-sparse lo: of every four consecutive input channels
+            hi = rnd(w, self.t)                             # (per cout and tap) the two larger low halves are kept (v_smfmac operand)
+            lo = w - hi
+            co, ci = lo.shape[0], lo.shape[1]
+            if ci % 4:
+                return hi + rnd(lo, self.t)
+            g = lo.reshape(co, ci // 4, 4, -1)
+            keep = torch.zeros_like(g)
+            keep.scatter_(2, g.abs().topk(2, dim=2).indices, 1.0)
+            return hi + rnd((g * keep).reshape(lo.shape), self.t)
         if self.w == "ed" and self._ovr("w", hw):
             return round_zero_sum(w, self.t)
         if self.w.startswith("d") and self._ovr("w", hw):

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from gpu_util import assert_stats, check, log_err
+from helpers import rel_err
 from hsi_dmgasr_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -125,6 +126,29 @@ def test_low_weight_halves_reach_the_matrix_pipe(dev):
         errs[mode] = float(d.abs().max())
         log_err("low_weight_halves_" + mode, mode, errs[mode])
     assert errs["fp16x2"] < 0.25 * errs["fp16x1"] + 2e-6, errs
+
+
+@pytest.mark.parametrize("mode", ["fp16x1", "fp16x2"])
+def test_subnormal_only_weights_are_multiplied(dev, mode):
+    """Every weight an fp16 SUBNORMAL (|w| <= 4e-5 < 6.1e-5; in the two-pass form the low halves are multiples of 6e-8): a matrix
+    pipe that flushed subnormal operands would return bias only.  Activations exactly representable and large (so that the outputs
+    are ordinary fp16 numbers): the result must be the fp32 convolution of the ROUNDED weights to the store's 2^-11, and in the
+    one-pass form it IS what the subnormal high halves alone give."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Ci, Co = 2, 32, 32, 64, 64
+    w = (torch.rand(Co, Ci, 3, 3, generator=g) * 2 - 1) * 4e-5
+    assert float(w.abs().max()) < 6.1e-5
+    x = (torch.randint(-64, 65, (B, H, W, Ci), generator=g).float() * 16).to(torch.float16).to(dev)
+    pk = ops.PackedConv(w.to(dev), None, mode)
+    y = ops.conv2d(x, pk)
+    torch.cuda.synchronize()
+    hi = w.to(torch.float16)
+    w_eff = hi.double() + ((w - hi.float()).to(torch.float16).double() if mode == "fp16x2" else 0.0)
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w_eff, padding=1).permute(0, 2, 3, 1)
+    e = rel_err(y.double().cpu().numpy(), ref.numpy())
+    log_err("subnormal_only_weights", mode, e)
+    assert float(ref.abs().mean()) > 0.1 and e < 6e-4, (e, float(ref.abs().mean()))
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])

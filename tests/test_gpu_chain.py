@@ -323,8 +323,9 @@ def test_bench_line_carries_every_object():
     assert d["fp32_mode"]["value"] > 0 and d["fp32_mode"]["roofline"]["mfma_passes_per_product"] == 3
     assert set(d["small_batches"]) == {"40_latents", "5_latents"} and all(v["value"] > 0 for v in d["small_batches"].values())
     for key in ("gae", "gae_chikusei"):
-        for mode in ("fp32", "fp16", "bf16"):
+        for mode in ("fp32", "fp16"):
             assert d[key][mode]["encode_ms"] > 0 and "dPSNR_dB_vs_fp32_mode" in d[key][mode]
+            assert 0 < d[key][mode]["encode_hbm"]["unit_frac_of_hbm"] < d[key][mode]["encode_hbm"]["launch_frac_of_hbm"] < 1
         assert d[key]["fp16"]["within_0.01dB_0.001deg"] is True
     assert d["gae_chikusei"]["cube"] == "128x128x128, G=11"
     assert d["train_step"]["bf16"]["graph_ms_per_step"] > 0

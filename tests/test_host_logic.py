@@ -39,7 +39,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     assert rows[1] == [P.src0.offset, P.src1.offset, P.gn_ab.offset, P.C0.offset, P.C1.offset, P.transform.offset, P.ntaps.offset]
     assert rows[2] == [D.nphase.offset, D.w_hi.offset, D.w_lo.offset, D.bias.offset, D.film.offset, D.film_stride.offset,
                        D.res.offset, D.res_scale.offset, D.out.offset, D.stats.offset, D.B.offset, D.ksize.offset,
-                       D.prec.offset, D.bn.offset, D.workspace.offset, D.workspace_bytes.offset, D.w_v2_lo.offset]
+                       D.prec.offset, D.bn.offset, D.workspace.offset, D.workspace_bytes.offset, D.w_v2_lo.offset, D.w_v2_ls.offset, D.w_v2_li.offset]
 
 
 def test_clean_tree_build_produces_a_loadable_library(tmp_path):

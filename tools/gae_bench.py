@@ -33,14 +33,25 @@ def timed(fn, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--cubes", type=int, default=0, help="only this: encode / decode of N CAVE cubes 31x128x128 (bench.py's `gae` object at its "
+                                                         "batch) a few times - the run to put under rocprofv3 for a per-kernel table / FETCH-WRITE passes")
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     out = {}
     g = torch.Generator().manual_seed(3)
+    if args.cubes:
+        m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision=args.precision).to(dev).eval()
+        x = torch.rand(args.cubes, 31, 128, 128, generator=g).to(dev)
+        z = m.encode_batched(x)
+        print(json.dumps(dict(cubes=args.cubes, precision=args.precision, encode_ms=timed(lambda: m.encode_batched(x), args.reps),
+                              decode_ms=timed(lambda: m.decode_batched(z, 31), args.reps))))
+        return
     for name, (ns, no, nc, hw, b) in {"cave_31x64x64": (8, 2, 31, 64, 1), "cave_31x128x128": (8, 2, 31, 128, 1),
                                       "cave_31x128x128_b8": (8, 2, 31, 128, 8),
                                       "chikusei_128x128x128": (16, 4, 128, 128, 1)}.items():
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "fp16"):
             m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=ns, n_ovls=no, n_colors=nc, n_feats=64, precision=prec).to(dev).eval()
             x = torch.rand(b, nc, hw, hw, generator=g).to(dev)
             z = m.encode_batched(x)
