@@ -321,8 +321,9 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.C0 = p.ph[0].C0; v.C1 = p.ph[0].C1; v.nchunks = p.ph[0].nchunks;
         v.w = reinterpret_cast<const bf16*>(d->w_v2);
         v.w_lo = reinterpret_cast<const bf16*>(d->w_v2_lo);
-        v.w_ls = reinterpret_cast<const bf16*>(d->w_v2_ls);
-        v.w_li = reinterpret_cast<const int*>(d->w_v2_li);
+        const bool sparse_ok = d->w_v2_ls && d->w_v2_li && !debug_get(DBG_NO_SPARSE_LO);      // HSIDM_NO_SPARSE_LO=1: diagnostic A/B switch
+        v.w_ls = sparse_ok ? reinterpret_cast<const bf16*>(d->w_v2_ls) : nullptr;
+        v.w_li = sparse_ok ? reinterpret_cast<const int*>(d->w_v2_li) : nullptr;
         const int np = d->w_v2_lo ? 2 : 1;
         auto v2_run = [&](int tk, int bn_, int xf_) {
             if (d->prec == HSIDM_F32X3) return conv_v2_run_f32x3(tk, bn_, xf_, v, s);
@@ -337,7 +338,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         if (path == PATH_V3) {
             v.steps_per_item = steps;
             // the second weight pass as a 2:4 structured-sparse one when the caller packed it (HSIDM_NO_SPARSE_LO=1: diagnostic A/B switch)
-            const int spl = np == 2 && d->w_v2_ls && d->w_v2_li && !d->out_nchw && !debug_get(DBG_NO_SPARSE_LO);
+            const int spl = np == 2 && sparse_ok && !d->out_nchw;
             return conv_v3_run(v, d->out_nchw, elem, np, spl, s);
         }
         const bool dn4 = d->stride == 2;

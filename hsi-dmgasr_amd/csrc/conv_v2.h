@@ -87,10 +87,19 @@ struct ConvV2Params {
 // staged pixel-vector, fp32 GroupNorm pairs, a 4-byte epilogue patch, fp32 stores); every staged value is split into bf16 hi + lo
 // into TWO halo tiles per buffer and every product is three MFMAs, lo*hi + hi*lo + hi*hi (conv_igemm.h's arithmetic, ~2^-17 per
 // product).  Four halo tiles are 113 KB: one workgroup per CU, up to 512 registers per wave.
-template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4, typename E_ = bf16, int NP_ = 1, typename S_ = E_, int AP_ = 1>
+//
+// SPL_ (fp16, NP_ = 2; the one-image 8x16 tile on four waves, stride-1 3x3): the second weight pass on v_smfmac_f32_16x16x64_f16 with the low
+// halves 2:4-compressed (ConvV2Params::w_ls / w_li; conv_v3.hip has the same form and the reasoning): the weights are the A operand of
+// both passes, the accumulators come out transposed (a lane holds couts 16 nh + 4 g .. + 3 of one pixel), sub-steps run in the order
+// (tap, 16-pixel half r, 32-channel slice q) with the tap's dense fragments held for both halves - two register sets alternating
+// between taps, one tap of lookahead - and one sparse instruction per (r, 32-pixel group, cout half) after slice q = 1.
+template <int BN_, int TH_, int TW_, int NI_, int XF_, int SP_ = 0, int NW_ = 4, typename E_ = bf16, int NP_ = 1, typename S_ = E_, int AP_ = 1,
+          bool SPL_ = false>
 struct V2Cfg {
     using E = E_;
     using S = S_;                                               // storage type of activations in HBM
+    static constexpr bool SPL = SPL_;
+    static_assert(!SPL_ || (NP_ == 2 && AP_ == 1 && sizeof(S_) == 2 && NI_ == 1 && NW_ == 4 && SP_ == 0 && TW_ == 16), "sparse low halves: see above");
     static constexpr int NP = NP_, AP = AP_;
     static constexpr bool F32 = sizeof(S_) == 4;
     static constexpr int SV = F32 ? 2 : 1;                      // 16-byte vectors per staged 8-channel pixel-vector
@@ -103,7 +112,7 @@ struct V2Cfg {
     static constexpr bool UP4 = SP_ == 1, DN4 = SP_ == 2;
     static constexpr bool FR = SP_ != 0;                        // 4-tap chunks, fragment-granular weight ring
     static constexpr int NT = FR ? 4 : 9;                       // taps per channel chunk
-    static constexpr bool FRG = FR || NP_ == 2;                 // weights through the fragment ring (else the 3-step ring)
+    static constexpr bool FRG = (FR || NP_ == 2) && !SPL_;      // weights through the fragment ring (else the 3-step ring; SPL: tap sets)
     // ring slots / lookahead in k-slices; the slot count divides the k-slices of a chunk (16 | 36) so that every index is static
     // (a 32-channel slice keeps its two fragments through both of its sub-steps: FL <= FS - 2)
     // (the fp32 form has one workgroup per CU and registers to spare: a deeper ring, ten / six fragments ahead)
@@ -139,7 +148,7 @@ struct V2Cfg {
     // depth of the A-operand ring in sub-steps (kernel: a_fetch).  Two where a sub-step carries twice the MFMAs (NP = 2) and on the
     // two-image 128-cout GroupNorm form, where the third set made the allocator spill 37 registers (per-image FiLM / statistics
     // registers on top of MR = 4)
-    static constexpr int AD = (NP_ == 2 || (NI_ == 2 && XF_ != 0 && BN_ == 128 && NW_ == 4)) ? 2 : 3;
+    static constexpr int AD = (SPL_ || NP_ == 2 || (NI_ == 2 && XF_ != 0 && BN_ == 128 && NW_ == 4)) ? 2 : 3;
     // statistics sub-entries per spatial tile and image (see epilogue)
     static constexpr int SUBS = (NI == 1) ? WM : (WM >= 2 ? WM / 2 : 1);
 };
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     constexpr bool UP4 = C::UP4, DN4 = C::DN4, FR = C::FR;
     constexpr int NTHR = C::NTHR;
     constexpr int NP = C::NP, FS = C::FS, FL = C::FL;
-    constexpr bool FRG = C::FRG;
+    constexpr bool FRG = C::FRG, SPL = C::SPL;
     using E = typename C::E;
     using S = typename C::S;
     constexpr int AP = C::AP, SV = C::SV;
@@ -264,7 +273,12 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     const E* wlane = reinterpret_cast<const E*>(p.w) + wlane_off;
     const E* wlane_lo = reinterpret_cast<const E*>(NP == 2 ? p.w_lo : p.w) + wlane_off;
     const size_t wstep_stride = (size_t)nsw * 4 * 64 * 8;
-    x8 ring[FRG ? 1 : 3][4];
+    x8 ring[(FRG || SPL) ? 1 : 3][4];
+    // SPL: register sets (tap & 1): four dense fragments e = 2q + nh, the two sparse halves, one index word (low / high half = cout half)
+    x8 whi[SPL ? 8 : 1], wls[SPL ? 4 : 1];
+    int wli[SPL ? 2 : 1];
+    const E* lsp = reinterpret_cast<const E*>(SPL ? p.w_ls : p.w) + ((size_t)(ns * WN + wn) * 2 * 64 + lane) * 8;
+    const int* lip = (SPL ? p.w_li : reinterpret_cast<const int*>(p.w)) + (size_t)(ns * WN + wn) * 64 + lane;
     // item -> (pixel tile, output parity).  UP4 with up_m > 0: the four parities of one input tile are consecutive work
     // of ONE XCD (blocks b, b+8, b+16, b+24), so its L2 fetches the tile once.
     // (divisions by run-time values are ~20 scalar instructions each and an item needs some twenty of them: shifts whenever the
@@ -301,6 +315,12 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
             for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + frag_off(kk));
         }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
+    };
+    auto s_issue = [&](int set, int part) __attribute__((always_inline)) {      // SPL: part 0..3 of weight step wnext into register set `set`
+        whi[SPL ? set * 4 + part : 0] = *reinterpret_cast<const x8*>(wlane + (size_t)wnext * wstep_stride + frag_off(part));
+        if (part < 2) wls[SPL ? set * 2 + part : 0] = *reinterpret_cast<const x8*>(lsp + ((size_t)wnext * nsw * 2 + part) * (64 * 8));
+        if (part == 2) wli[SPL ? set : 0] = lip[(size_t)wnext * nsw * 64];
+        if (part == 3) wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
     // UP4: 16 fragments per chunk do not keep a 3-step ring in phase (4 taps), so the ring holds single fragments:
     // 8 slots, fetched six sub-steps (24 MFMAs) ahead.  NP = 2: (high, low) fragment pairs, FS slots, FL sub-steps ahead.
@@ -501,7 +521,10 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     };
 
     // prologue: first two weight steps, first halo tile (synchronously)
-    if (!FRG) {
+    if constexpr (SPL) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) s_issue(0, f);
+    } else if (!FRG) {
         b_issue(ring[0]);
         b_issue(ring[1]);
     } else {
@@ -553,23 +576,29 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
             x8 a[AD][MR], a_lo[AP == 2 ? AD : 1][MR];
             auto a_fetch = [&](int u) __attribute__((always_inline)) {
                 const int tp = u >> 2;
-                const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) + ((u >> 1) & 1) * 32 + (u & 1) * RHALF;
+                const int off = (FR ? (tp >> 1) * RP + (tp & 1) * PSTR : (tp / 3) * RP + (tp % 3) * PSTR) +
+                                (SPL ? (u & 1) * 32 + ((u >> 1) & 1) * RHALF : ((u >> 1) & 1) * 32 + (u & 1) * RHALF);   // SPL: u = 4 tap + 2 r + q
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     a[u % AD][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + off);
                     if constexpr (AP == 2) a_lo[u % AD][mr] = *reinterpret_cast<const x8*>(hb + C::HALO_ELEMS + abase[mr] + off);
                 }
             };
+            // SPL: the sparse instructions of a (q = 1) sub-step read BOTH slots of the two-deep ring, so the fragment of the next sub-step
+            // is requested behind them; a (q = 0) sub-step requests its successor's up front.  (A third slot kept the lookahead but cost
+            // sixteen registers the kernel does not have: the halo addresses were spilled INTO the matrix phase, each reload an
+            // in-order vmcnt wait behind the weight prefetch.)
+            constexpr int AL = AD - 1;
             a_fetch(0);
-            if (AD == 3) a_fetch(1);
+            if (AL == 2) a_fetch(1);
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) {
-                if (!FRG) b_issue(ring[(tap + 2) % 3]);        // weights two K steps ahead
+                if (!FRG && !SPL) b_issue(ring[(tap + 2) % 3]);        // weights two K steps ahead
                 if (st_valid && tap == 0) {                    // staging of the next chunk, one vector per tap
                     if (st_chunk == 0) describe(st_item);
                     halo_begin(st_chunk);
                 }
-                if (tap == 0 && chunk == nch - 1) {            // FiLM + bias for the epilogue (see above)
+                if (!SPL && tap == 0 && chunk == nch - 1) {    // FiLM + bias for the epilogue (see above; SPL: loaded in the epilogue itself)
                     // the lane's channels are recomputed from the hardware lane id here: kept as loop-invariant 64-bit addresses
                     // (p.film + n, p.bias + n) they were spilled
                     int lane_s = lane_id_now();
@@ -600,9 +629,10 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int u = tap * 4 + kk, q = kk >> 1, r = kk & 1;
-                    if (u + AD - 1 < 4 * NT) a_fetch(u + AD - 1);
+                    const int u = tap * 4 + kk, q = SPL ? (kk & 1) : (kk >> 1), r = SPL ? (kk >> 1) : (kk & 1);
+                    if ((!SPL || q == 0) && u + AL < 4 * NT) a_fetch(u + AL);
                     if (FRG) f_issue((u + FL) % FS, (u + FL) % 4);       // weights FL fragments ahead
+                    if constexpr (SPL) s_issue(tap == NT - 1 ? 1 : (tap & 1) ^ 1, kk);   // the next tap's weights (last tap: the next chunk's first, moved to set 0 below)
                     if (!(HSIDM_ABL(16))) {
                         if (!FR) {                             // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, sub-steps 2-3)
                             if (tap >= 3 && tap - 3 < MAXHV) halo_commit_part(tap - 3, cur ^ 1, kk);
@@ -610,6 +640,46 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                             halo_commit_one((tap - 2) * 4 + kk, cur ^ 1);
                         }
                     }
+                    if constexpr (SPL) {
+                        const int set = tap & 1;
+                        if (q == 0 && tap == 0 && chunk == 0) {       // first use of these accumulators: C = 0 as the inline constant (uniform branch)
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                                for (int nh = 0; nh < 2; ++nh) acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + nh : 0], a[u % AD][mr], zero);
+                        } else {
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                                for (int nh = 0; nh < 2; ++nh)
+                                    acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + 2 * q + nh : 0], a[u % AD][mr], acc[mr][r][nh]);
+                        }
+                        if (q == 1) {                              // the tap's 64 channels of half r against the sparse low halves
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr) {
+                                typedef _Float16 f16x16v __attribute__((ext_vector_type(16)));
+                                const f16x16v bb = __builtin_shufflevector(a[(u + AD - 1) % AD][mr], a[u % AD][mr], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                                acc[mr][r][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 : 0], bb, acc[mr][r][0], wli[SPL ? set : 0], 0, 0);
+                                acc[mr][r][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 + 1 : 0], bb, acc[mr][r][1], wli[SPL ? set : 0], 0, 1);
+                            }
+                            if (u + 1 < 4 * NT) a_fetch(u + 1);
+                        }
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    // 2 MFMAs (one operand, both cout halves)
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // 1 LDS read (next sub-step's operand)
+                            if (q == 1) __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 3 : 1, 0);   // a slice of the staging VALU
+                            else        __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 6 : 2, 0);
+                        }
+                        if (q == 1) {
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 3 : 1, 0);
+                            }
+                        }
+                    } else {
                     // first sub-steps of the item: C = 0 as the MFMA's inline constant instead of 16*MR v_mov per lane and item (behind a
                     // uniform branch: a select between the constant and the accumulator would cost a v_cndmask per register)
                     if (u < 2 && chunk == 0) {
@@ -655,9 +725,17 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                             __builtin_amdgcn_sched_group_barrier(0x002, C::XF != XF_NONE ? 3 : 1, 0);
                         }
                     }
+                    }
                     __builtin_amdgcn_sched_barrier(0);         // keep the two-sub-step LDS lookahead the source expresses
                 }
                 if (!FR && tap == 8 && MAXHV == 7 && !(HSIDM_ABL(16))) halo_commit_one(6, cur ^ 1);
+            }
+            if constexpr (SPL && (NT & 1)) {                   // nine taps per chunk: the prefetch of the last tap went to set 1, the next chunk starts on set 0
+#pragma unroll
+                for (int f = 0; f < 4; ++f) whi[f] = whi[SPL ? 4 + f : 0];
+                wls[0] = wls[SPL ? 2 : 0];
+                wls[SPL ? 1 : 0] = wls[SPL ? 3 : 0];
+                wli[0] = wli[SPL ? 1 : 0];
             }
             HSIDM_STAMP(it, 10);                               // (last chunk's) MFMAs + commits issued
             lds_barrier();                                     // next halo tile complete; this one free for re-use
@@ -683,7 +761,18 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
         for (int q = 0; q < NI; ++q)
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) ep_add[q][nh] = nok[nh] ? ep_add[q][nh] + ep_bias[nh] : 0.f;
-        const bool full = oy0 + TH <= lim_h && ox0 + TW <= lim_w && b0 + NI <= p.B && n0 + BN <= p.Cout;
+        f32x4 ep4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};          // SPL: bias + FiLM of couts 16 nh + 4 g .. + 3 (the dispatcher only
+        if constexpr (SPL) {                                                  // sends whole tiles and whole cout slices this way)
+            int lane_s = lane_id_now();
+            asm volatile("" : "+v"(lane_s));
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int n4 = n0 + wn * 32 + 16 * nh + 4 * (lane_s >> 4);
+                if (p.film) ep4[nh] = *reinterpret_cast<const f32x4*>(p.film + (size_t)b0 * p.film_stride + n4);
+                if (p.bias) ep4[nh] += *reinterpret_cast<const f32x4*>(p.bias + n4);
+            }
+        }
+        const bool full = SPL || (oy0 + TH <= lim_h && ox0 + TW <= lim_w && b0 + NI <= p.B && n0 + BN <= p.Cout);
         if (full) {
             // Whole tile inside the image.  2-byte stores straight from the accumulator layout cost ~200 cycles each
             // (in-kernel stamps: the epilogue took as long as 9 K steps), so the wave transposes its 64-pixel x 32-cout
@@ -735,6 +824,27 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         if (m2 >= nm) break;
+                        if constexpr (SPL) {
+                            // transposed accumulators: the lane holds couts 16 nh + 4 lg .. + 3 of pixel lc of the half -> one 8-byte patch write
+#pragma unroll
+                            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                                for (int nh = 0; nh < 2; ++nh) {
+                                    float v[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        v[j] = C::XF != XF_NONE ? fmaf(acc[g + m2][r][nh][j], kLn2, ep4[nh][j]) : acc[g + m2][r][nh][j] + ep4[nh][j];
+                                        if (LEAKY) v[j] = v[j] > 0.f ? v[j] : 0.01f * v[j];
+                                    }
+                                    const x2 p0 = cvt_pair_hw<E>(v[0], v[1]), p1 = cvt_pair_hw<E>(v[2], v[3]);
+                                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                    u32x2 pk;
+                                    pk[0] = __builtin_bit_cast(unsigned, p0);
+                                    pk[1] = __builtin_bit_cast(unsigned, p1);
+                                    *reinterpret_cast<u32x2*>(reinterpret_cast<E*>(scr) + (m2 * 32 + 16 * r + lc_e) * SCR_STR + 16 * nh + 4 * lg_e) = pk;
+                                }
+                            continue;
+                        }
                         // patch row = 32 m2 + 16 (half r) + pixel of the half; the lane holds pixels 4 lg .. + 3 of couts 16 nh + lc
 #pragma unroll
                         for (int r = 0; r < 2; ++r)
@@ -801,13 +911,13 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                         }
                         if (!HSIDM_ABL(1)) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(g, v4) + lane_el) = o;
                         }
-                        if (RES) {
+                        if (RES || SPL) {                                      // (SPL: a lane of the accumulator layout holds eight couts)
 #pragma unroll
                             for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
                         }
                     }
                     HSIDM_STAMP(it, 11);
-                    if (RES && p.stats && (NI == 2 || g + 2 >= MR)) {
+                    if ((RES || SPL) && p.stats && (NI == 2 || g + 2 >= MR)) {
                         // Lanes with equal (lane & 3) hold the same 8 couts: fold the 16 of them together with a halving
                         // butterfly -- at every level a lane hands the half of its values its partner keeps and receives
                         // the half it keeps itself: 8+4+2+1 = 15 cross-lane moves instead of 4*16, and every lane ends
@@ -869,7 +979,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                     }
         }
         }
-        if (p.stats && (!full || !p.res)) {
+        if (!SPL && p.stats && (!full || !p.res)) {
             // wave partial over its pixels: combine the four lane quarters (lg), lanes 0..15 write one entry per cout half
 #pragma unroll
             for (int q = 0; q < NI; ++q) {

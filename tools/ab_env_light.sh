@@ -1,0 +1,10 @@
+#!/bin/bash
+# In-box A/B of an environment switch on the timed region only:  STEPS=300 ROUNDS=3 bash tools/ab_env_light.sh HSIDM_NO_SPARSE_LO=1
+steps=${STEPS:-300}; rounds=${ROUNDS:-3}
+for r in $(seq $rounds); do
+  for v in "" "$@"; do
+    if [ -z "$v" ]; then tag=default; run() { python bench.py --steps $steps --warmup 10 --no-cpu-baseline --no-roofline --no-modes --no-parity --no-gae --no-train --no-small 2>/dev/null; }
+    else tag=$v; run() { env "$v" python bench.py --steps $steps --warmup 10 --no-cpu-baseline --no-roofline --no-modes --no-parity --no-gae --no-train --no-small 2>/dev/null; }; fi
+    run | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('$tag', round(d['ms_per_step'],3), 'ms/step', round(d['value'],1))"
+  done
+done
