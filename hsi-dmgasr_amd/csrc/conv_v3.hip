@@ -300,14 +300,15 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             // A operands: ring over the 36 sub-steps w = 4 tap + 2 q + r of the chunk (q: 32-channel slice of the tap, r: row of the
             // tile-row pair); sub-step w runs 2 MR (x NP) MFMAs - both 16-cout halves on the slice's two weight fragments 4 tap + 2 q + n
             if constexpr (SPL) {
-                // sub-step w = 4 tap + 2 r + q; activations: three-deep ring, fetched one sub-step ahead (the sparse instruction of
-                // (r, q = 1) still reads the fragment of (r, q = 0) while the fragment of the next sub-step arrives)
-                x8 a[3][MR];
+                // sub-step w = 4 tap + 2 r + q; activations: two-deep ring.  The sparse instructions of a (q = 1) sub-step read BOTH slots,
+                // so the fragment of the next sub-step is requested behind them; a (q = 0) sub-step requests its successor's up front
+                // (conv_v2.h, SPL: a third slot costs sixteen registers and the allocator then spills around the chunk barrier)
+                x8 a[2][MR];
                 auto a_fetch = [&](int w) __attribute__((always_inline)) {
                     const int tp = w >> 2;
                     const int off = (tp / 3 + ((w >> 1) & 1)) * RP + (tp % 3) * PSTR + (w & 1) * 32;
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) a[w % 3][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
+                    for (int mr = 0; mr < MR; ++mr) a[w % 2][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
                 };
                 a_fetch(0);
 #pragma unroll
@@ -316,30 +317,31 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const int w = tap * 4 + kk, r = kk >> 1, q = kk & 1;
-                        if (w + 1 < 36) a_fetch(w + 1);
+                        if (q == 0) a_fetch(w + 1);
                         s_issue(tap == 8 ? 1 : set ^ 1, kk);       // the next tap's weights (tap 8: the next chunk's first tap, moved to set 0 below)
                         if (q == 0 && tap == 0 && chunk == 0) {   // first use of these accumulators: C = 0 as the inline constant (uniform branch)
                             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                                for (int mr = 0; mr < MR; ++mr) acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + nh : 0], a[w % 3][mr], zero);
+                                for (int mr = 0; mr < MR; ++mr) acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + nh : 0], a[w % 2][mr], zero);
                         } else {
 #pragma unroll
                             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                                 for (int mr = 0; mr < MR; ++mr)
-                                    acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + 2 * q + nh : 0], a[w % 3][mr], acc[mr][r][nh]);
+                                    acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + 2 * q + nh : 0], a[w % 2][mr], acc[mr][r][nh]);
                         }
                         if (q == 1) {                             // the tap's 64 channels of row r against the sparse low halves
 #pragma unroll
                             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                                 for (int mr = 0; mr < MR; ++mr) {
-                                    const f16x16v bb = __builtin_shufflevector(a[(w + 2) % 3][mr], a[w % 3][mr], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                                    const f16x16v bb = __builtin_shufflevector(a[(w + 1) % 2][mr], a[w % 2][mr], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                                     if (nh == 0) acc[mr][r][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 : 0], bb, acc[mr][r][0], wli[SPL ? set : 0], 0, 0);
                                     else         acc[mr][r][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 + 1 : 0], bb, acc[mr][r][1], wli[SPL ? set : 0], 0, 1);
                                 }
+                            if (w + 1 < 36) a_fetch(w + 1);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
