@@ -54,6 +54,11 @@ template <> struct Elem<f16> {
 // +-65504 instead of an infinity (a true infinity stays one; probed on gfx950 for v_cvt_pk_f16_f32 and v_cvt_f16_f32).  A wave that
 // called fp16_saturating_stores() converts with cvt_pair_hw / a plain cast - without the v_med3 of Elem<f16>::sat, 64 ... 128 vector
 // instructions per lane and work item in the convolution epilogues.  (hwreg(MODE, offset 23, size 1) = 1473.)
+// CONTRACT: cvt_pair_hw / a plain (f16) cast saturate ONLY in a kernel that called fp16_saturating_stores() at entry (the compiler does not
+// model the mode bit; every fp16 kernel with such conversions does so in its first statements, and tests/test_gpu_anchor.py::
+// test_fp16_stores_saturate_instead_of_overflowing drives every store path of every one of them past 65 504).  A kernel without the call
+// must convert with cvt_pair (v_med3 clamp).  Difference to the clamp: a TRUE +-inf or NaN accumulator passes through unchanged here (the
+// clamp would turn +-inf into +-65 504) - such a value can only come from non-finite inputs, which the path does not produce.
 __device__ __forceinline__ void fp16_saturating_stores() { __builtin_amdgcn_s_setreg(1473, 1); }
 template <typename E>
 __device__ __forceinline__ typename Elem<E>::x2 cvt_pair_hw(float a, float b) {

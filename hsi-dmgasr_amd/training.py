@@ -32,6 +32,9 @@ from .precision import resolve_precision
 from .sr3_modules.unet import Block, Downsample, ResnetBlocWithAttn, UNet, Upsample
 
 
+_NOTICE_DONE = False
+
+
 class Trainer:
     def __init__(self, gd, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, precision=None, dropout_seed=0, bucket_bytes=64 << 20):
         net = gd.denoise_fn
@@ -52,6 +55,13 @@ class Trainer:
                 raise NotImplementedError("hsidm: the training step runs in the bf16 or the fp32 mode (got %r)" % self.precision)
             # A network built in an inference-only mode (the fp16 family, the package default) and no mode asked for: train as the
             # reference trains - in fp32 arithmetic (gradients within 1e-5 of autograd); Trainer(gd, precision="bf16") is the fast form.
+            global _NOTICE_DONE
+            if not _NOTICE_DONE:
+                import sys
+                print("hsidm: the network's precision mode %r is an inference mode; this Trainer runs the training step in the fp32 mode "
+                      "(about 1.7x the bf16 step's time; pass Trainer(gd, precision=\"bf16\") / gd.trainer(precision=\"bf16\") for the fast form)"
+                      % self.precision, file=sys.stderr)
+                _NOTICE_DONE = True
             self.precision = "fp32"
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.dropout_seed = int(dropout_seed)
@@ -610,7 +620,7 @@ class Trainer:
         extra = sd.get("hsidm", {})
         self._iter = int(extra.get("iter", self.step_count))
         self.dropout_seed = int(extra.get("dropout_seed", self.dropout_seed))
-        self._g = None                                          # (a captured step bakes nothing of this in, but start clean)
+        self._g = None          # REQUIRED: a captured step has Adam's betas / eps baked in as kernel scalars - the next call re-captures
 
     def save_network(self, prefix, epoch, iter_step):
         """DDPM.save_network (model/model.py:125-145): ``<prefix>_gen.pth`` = the GaussianDiffusion's state_dict on the host,
@@ -642,8 +652,9 @@ class Trainer:
     def optimize_parameters(self, data, use_graph=True, **kw):
         """model/model.py:49-59.  -> l_pix (0-dim device tensor; the reference logs .item()).
 
-        use_graph (and no injected noise / t / gamma, one rank): from the third call on the whole step - forward, backward,
-        Adam, re-pack: ~1 500 launches - is ONE hipGraph replay.  What changes per iteration lives in device memory the host
+        use_graph (and no injected noise / t / gamma, one rank): from the SECOND call at a batch shape on (the first one runs eagerly and
+        sizes every workspace; the second captures and replays) the whole step - forward, backward, Adam, re-pack: ~850 launches at
+        B = 4 - is ONE hipGraph replay.  What changes per iteration lives in device memory the host
         refreshes before the replay: the batch, the drawn noise levels, the dropout key and Adam's bias corrections; the noise
         comes from torch's graph-safe generator."""
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1

@@ -10,7 +10,9 @@ python bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-modes --no-parity --no-gae --no-train --no-small > $out/stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  HSIDM_NO_GRAPH=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-modes --no-parity --no-gae --no-train --no-small > $out/pmc_$c.log 2>&1
+  # (HSIDM_NO_STEP_SCHEDULE=1: the sampled steps are a chain's FIRST ones, which the fp16 mode runs on the fp32-mode kernels - the
+  # counters are wanted for the kernels of the other 996)
+  HSIDM_NO_STEP_SCHEDULE=1 HSIDM_NO_GRAPH=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-modes --no-parity --no-gae --no-train --no-small > $out/pmc_$c.log 2>&1
 done
 cp $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $out/fetch.csv
 cp $(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $out/write.csv
