@@ -128,6 +128,44 @@ def test_low_weight_halves_reach_the_matrix_pipe(dev):
     assert errs["fp16x2"] < 0.25 * errs["fp16x1"] + 2e-6, errs
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 32, 32), (128, 128, 16, 32), (192, 64, 32, 32)], ids=["v3_64", "v2_128", "v3_192"])
+def test_sparse_second_weight_pass_removes_the_weight_bias(dev, shape):
+    """The GroupNorm + SiLU forms with the second weight pass on v_smfmac (conv_v3's 64-cout form, conv_v2's 128-cout form; low halves
+    2:4-compressed, operand semantics measured by tools/ubench/smfmac_probe.hip) against the same convolution with the DENSE second pass
+    (HSIDM_NO_SPARSE_LO switch) and with none: the three kernels stage identical operands, so their outputs differ by the weights alone.
+    Per output channel, the MEAN over all pixels of (sparse - dense) - the contribution of the dropped smaller halves - must be well
+    below that of (one pass - dense) - the contribution of ALL low halves.  A wrong index word, slot order or k-group mapping would make
+    the sparse pass add an error of the low halves' full size instead."""
+    from hsi_dmgasr_amd import ops
+    Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    B = 4
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    x = (torch.rand(B, H, W, Ci, generator=g) * 2).to(torch.float16)
+    ab = ops.gn_table(torch.stack([torch.ones(B, Ci), torch.zeros(B, Ci)], dim=2).contiguous().to(dev))
+    out = {}
+    for tag, mode, dense in (("one", "fp16x1", 0), ("dense", "fp16x2", 1), ("sparse", "fp16x2", 0)):
+        old = _lib.lib().hsidm_debug_switch(b"NO_SPARSE_LO", dense)
+        try:
+            recs = []
+            ops.set_conv_probe(recs)
+            y = ops.conv2d(x.to(dev), ops.PackedConv(w.to(dev), None, mode), gn_ab=ab, transform=ops.XF_AFFINE_SILU)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_conv_probe(None)
+            _lib.lib().hsidm_debug_switch(b"NO_SPARSE_LO", old)
+        assert ("conv_v3" if Co == 64 else "conv_v2 bn128") in recs[0]["kernel"], recs[0]["kernel"]
+        out[tag] = y.double().cpu()
+    scale = float(out["dense"].abs().mean())
+    all_lo = float((out["one"] - out["dense"]).mean(dim=(0, 1, 2)).abs().mean()) / scale
+    dropped = float((out["sparse"] - out["dense"]).mean(dim=(0, 1, 2)).abs().mean()) / scale
+    log_err("sparse_lo_mean_shift_all_low_halves_%dx%d" % (Ci, Co), "fp16x1", all_lo)
+    log_err("sparse_lo_mean_shift_dropped_halves_%dx%d" % (Ci, Co), "fp16x2", dropped)
+    assert all_lo > 2e-5, all_lo                                # the low halves are visible in the channel means at all
+    assert dropped < 0.6 * all_lo, (dropped, all_lo)
+    assert rel_err(out["sparse"].numpy(), out["dense"].numpy()) < 3e-4
+
+
 @pytest.mark.parametrize("mode", ["fp16x1", "fp16x2"])
 def test_subnormal_only_weights_are_multiplied(dev, mode):
     """Every weight an fp16 SUBNORMAL (|w| <= 4e-5 < 6.1e-5; in the two-pass form the low halves are multiples of 6e-8): a matrix

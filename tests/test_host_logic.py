@@ -404,3 +404,35 @@ def test_precision_schedule_along_the_chain():
             assert all(precision.step_precision(mode, gain[t]) == mode for t in range(T))
     gd.set_sampler("ddim", steps=10, eta=0.0)                   # the strided sampler carries its own gains
     assert gd._run_eps_gain.shape == (10,) and gd._run_eps_gain[9] > 1.0
+
+
+def test_sparse_low_half_packing_matches_the_measured_operand_semantics():
+    """ops.PackedConv._sparse_lo against a direct model of v_smfmac_f32_16x16x64_f16's A operand as measured on gfx950
+    (tools/ubench/smfmac_probe.hip): lane 16 * kgroup + i of a 16-cout half holds channels 16 * kgroup .. + 15; stored slot s with index
+    field v (bits [2s+1 : 2s] of the half-word: low = first half) multiplies channel 16 * kgroup + 4 * (s >> 1) + v.  Expanding the packed
+    (values, index words) by that model must give the low halves with the smaller two of every four channels zeroed."""
+    from hsi_dmgasr_amd.ops import PackedConv
+    g = torch.Generator().manual_seed(3)
+    st, cpad = 2, 64
+    lo = torch.randn(st, cpad, 64, generator=g) * 1e-5
+    vals, idx = PackedConv._sparse_lo(lo, cpad)
+    assert vals.shape == (st, cpad // 32, 2, 64, 8) and vals.dtype == torch.float16 and idx.shape == (st, cpad // 32, 64) and idx.dtype == torch.int32
+    dense = torch.zeros(st, cpad, 64, dtype=torch.float64)
+    for s_ in range(st):
+        for sl in range(cpad // 32):
+            for h in range(2):
+                for lane in range(64):
+                    kg, i = lane >> 4, lane & 15
+                    w16 = (int(idx[s_, sl, lane]) >> (16 * h)) & 0xFFFF
+                    for sa in range(8):
+                        v = (w16 >> (2 * sa)) & 3
+                        dense[s_, 32 * sl + 16 * h + i, 16 * kg + 4 * (sa >> 1) + v] += float(vals[s_, sl, h, lane, sa])
+                    # the two kept positions of a group are distinct and ascending
+                    for m in range(4):
+                        f0, f1 = (w16 >> (4 * m)) & 3, (w16 >> (4 * m + 2)) & 3
+                        assert f0 < f1
+    grp = lo.reshape(st, cpad, 16, 4)
+    keep = torch.zeros_like(grp).scatter_(3, grp.abs().topk(2, dim=3).indices, 1.0)
+    want = (grp * keep).reshape(st, cpad, 64).to(torch.float16).double()
+    assert torch.equal(dense, want)
+    assert float((want ** 2).sum() / (lo.double() ** 2).sum()) > 0.8          # the kept pairs carry most of the low halves' energy
