@@ -88,7 +88,7 @@ struct ConvV2Params {
 // into TWO halo tiles per buffer and every product is three MFMAs, lo*hi + hi*lo + hi*hi (conv_igemm.h's arithmetic, ~2^-17 per
 // product).  Four halo tiles are 113 KB: one workgroup per CU, up to 512 registers per wave.
 //
-// SPL_ (fp16, NP_ = 2; the one-image 8x16 tile on four waves, stride-1 3x3): the second weight pass on v_smfmac_f32_16x16x64_f16 with the low
+// SPL_ (fp16, NP_ = 2; the one-image 8x16 tile on four waves: stride-1 3x3 and the folded up / down-sampling forms): the second weight pass on v_smfmac_f32_16x16x64_f16 with the low
 // halves 2:4-compressed (ConvV2Params::w_ls / w_li; conv_v3.hip has the same form and the reasoning): the weights are the A operand of
 // both passes, the accumulators come out transposed (a lane holds couts 16 nh + 4 g .. + 3 of one pixel), sub-steps run in the order
 // (tap, 16-pixel half r, 32-channel slice q) with the tap's dense fragments held for both halves - two register sets alternating
@@ -99,7 +99,7 @@ struct V2Cfg {
     using E = E_;
     using S = S_;                                               // storage type of activations in HBM
     static constexpr bool SPL = SPL_;
-    static_assert(!SPL_ || (NP_ == 2 && AP_ == 1 && sizeof(S_) == 2 && NI_ == 1 && NW_ == 4 && SP_ == 0 && TW_ == 16), "sparse low halves: see above");
+    static_assert(!SPL_ || (NP_ == 2 && AP_ == 1 && sizeof(S_) == 2 && NI_ == 1 && NW_ == 4 && TW_ == 16), "sparse low halves: see above");
     static constexpr int NP = NP_, AP = AP_;
     static constexpr bool F32 = sizeof(S_) == 4;
     static constexpr int SV = F32 ? 2 : 1;                      // 16-byte vectors per staged 8-channel pixel-vector
@@ -316,12 +316,6 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
         }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
-    auto s_issue = [&](int set, int part) __attribute__((always_inline)) {      // SPL: part 0..3 of weight step wnext into register set `set`
-        whi[SPL ? set * 4 + part : 0] = *reinterpret_cast<const x8*>(wlane + (size_t)wnext * wstep_stride + frag_off(part));
-        if (part < 2) wls[SPL ? set * 2 + part : 0] = *reinterpret_cast<const x8*>(lsp + ((size_t)wnext * nsw * 2 + part) * (64 * 8));
-        if (part == 2) wli[SPL ? set : 0] = lip[(size_t)wnext * nsw * 64];
-        if (part == 3) wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
-    };
     // UP4: 16 fragments per chunk do not keep a 3-step ring in phase (4 taps), so the ring holds single fragments:
     // 8 slots, fetched six sub-steps (24 MFMAs) ahead.  NP = 2: (high, low) fragment pairs, FS slots, FL sub-steps ahead.
     x8 fring[FRG ? FS : 1], fring_lo[(FRG && NP == 2) ? FS : 1];
@@ -335,6 +329,19 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
             if (wnext + 1 == p.steps_per_item) {
                 wnext = 0;
                 w_base = w_base_nx;
+            } else wnext += 1;
+        }
+    };
+
+    auto s_issue = [&](int set, int part) __attribute__((always_inline)) {      // SPL: part 0..3 of weight step (w_base +) wnext into register set `set`
+        const size_t st = (size_t)(w_base + wnext);
+        whi[SPL ? set * 4 + part : 0] = *reinterpret_cast<const x8*>(wlane + st * wstep_stride + frag_off(part));
+        if (part < 2) wls[SPL ? set * 2 + part : 0] = *reinterpret_cast<const x8*>(lsp + (st * nsw * 2 + part) * (64 * 8));
+        if (part == 2) wli[SPL ? set : 0] = lip[st * nsw * 64];
+        if (part == 3) {
+            if (wnext + 1 == p.steps_per_item) {
+                wnext = 0;
+                w_base = w_base_nx;                             // (UP4: the next item's parity)
             } else wnext += 1;
         }
     };
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                     const int u = tap * 4 + kk, q = SPL ? (kk & 1) : (kk >> 1), r = SPL ? (kk >> 1) : (kk & 1);
                     if ((!SPL || q == 0) && u + AL < 4 * NT) a_fetch(u + AL);
                     if (FRG) f_issue((u + FL) % FS, (u + FL) % 4);       // weights FL fragments ahead
-                    if constexpr (SPL) s_issue(tap == NT - 1 ? 1 : (tap & 1) ^ 1, kk);   // the next tap's weights (last tap: the next chunk's first, moved to set 0 below)
+                    if constexpr (SPL) s_issue(((NT & 1) && tap == NT - 1) ? 1 : (tap & 1) ^ 1, kk);   // the next tap's weights (nine-tap chunks: the last tap's prefetch is the next chunk's first, moved to set 0 below)
                     if (!(HSIDM_ABL(16))) {
                         if (!FR) {                             // vector tap-3, slice kk (vector 6 of a 7-vector round: all of it at tap 8, sub-steps 2-3)
                             if (tap >= 3 && tap - 3 < MAXHV) halo_commit_part(tap - 3, cur ^ 1, kk);

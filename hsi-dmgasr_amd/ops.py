@@ -81,7 +81,8 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
                 f = torch.stack([torch.stack([sum(weight[:, :, dy, dx] for dy in rows[py][ty] for dx in rows[px][tx])
                                               for tx in (0, 1)], dim=-1) for ty in (0, 1)], dim=-2)
                 pars.append(PackedConv._steps(f, cpad, 64))
-        lay["w_up4"] = PackedConv._lanes(torch.cat(pars, dim=0).contiguous(), cpad)
+        lay["w_up4_steps"] = torch.cat(pars, dim=0).contiguous()            # [step][Cout_pad][64]: what the sparse low halves are cut from
+        lay["w_up4"] = PackedConv._lanes(lay["w_up4_steps"], cpad)
     # stride-2 conv over the four input-parity planes (include/hsidm.h, hsidm_conv_desc.stride)
     if fold_dn and lay["w_v2"] is not None and kh == 3 and bn in (64, 128):
         tapmap = {0: (None, 1), 1: (0, 2)}                      # plane parity -> 3x3 tap behind each of the two window taps
@@ -95,7 +96,8 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
                         if dy is not None and dx is not None:
                             f[:, :, ty, tx] = weight[:, :, dy, dx]
                 planes.append(PackedConv._steps(f, cpad, 64))
-        lay["w_dn4"] = PackedConv._lanes(torch.cat(planes, dim=0).contiguous(), cpad)
+        lay["w_dn4_steps"] = torch.cat(planes, dim=0).contiguous()
+        lay["w_dn4"] = PackedConv._lanes(lay["w_dn4_steps"], cpad)
     return lay, meta
 
 
@@ -129,10 +131,16 @@ class PackedConv:
             setattr(self, name + "_lo", (t - hi.float()).to(et).contiguous() if (hi is not None and self.wide) else None)
         # fp16 hi + lo layers on the plain 3x3 schedule: the low halves once more, 2:4 structured-sparse, for the kernels that run the
         # second pass on v_smfmac (include/hsidm.h: w_v2_ls / w_v2_li; today conv_v3's 64-cout form)
-        self.w_v2_ls = self.w_v2_li = None
+        self.w_v2_ls = self.w_v2_li = self.w_up4_ls = self.w_up4_li = self.w_dn4_ls = self.w_dn4_li = None
         if (self.prec == _lib.F16 and self.wide and self.w_v2_lo is not None and self.ksize == 3 and proj_weight is None and
                 not out_nchw and not self.tap_major and self.cin % 64 == 0):
             self.w_v2_ls, self.w_v2_li = PackedConv._sparse_lo(w - self.w_hi.float(), meta["cpad"])
+            for name in ("w_up4", "w_dn4"):                     # the folded up / down-sampling layouts (their own steps: summed / re-ordered taps)
+                st = lay.get(name + "_steps")
+                if st is not None and getattr(self, name + "_lo") is not None:
+                    ls, li = PackedConv._sparse_lo(st - st.to(et).float(), meta["cpad"])
+                    setattr(self, name + "_ls", ls)
+                    setattr(self, name + "_li", li)
 
     def _set_meta(self, meta, precision, out_nchw):
         self.ksize, self.cin, self.cout, self.bn = meta["ksize"], meta["cin"], meta["cout"], meta["bn"]
@@ -147,7 +155,7 @@ class PackedConv:
         self.w_hi, self.w_lo, self.w_v2, self.w_up4, self.w_dn4, self.bias = w_hi, w_lo, w_v2, None, w_dn4, bias
         # fp32 mode: the low halves of the register-streaming layouts (the persistent kernel's fp32 form reads both)
         self.wide, self.w_v2_lo, self.w_up4_lo, self.w_dn4_lo = w_v2_lo is not None, w_v2_lo, None, w_dn4_lo
-        self.w_v2_ls = self.w_v2_li = None
+        self.w_v2_ls = self.w_v2_li = self.w_up4_ls = self.w_up4_li = self.w_dn4_ls = self.w_dn4_li = None
         return self
 
     @staticmethod
@@ -233,8 +241,11 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     if stride == 2:
         d.w_v2, w_v2_lo = (_lib.ptr(pw.w_dn4), pw.w_dn4_lo) if planes else (None, None)
     d.w_v2_lo = _lib.ptr(w_v2_lo) if d.w_v2 else None
-    plain = d.w_v2 and not folded and stride == 1 and getattr(pw, "w_v2_ls", None) is not None and w_v2_lo is pw.w_v2_lo
-    d.w_v2_ls, d.w_v2_li = (_lib.ptr(pw.w_v2_ls), _lib.ptr(pw.w_v2_li)) if plain else (None, None)
+    ls = li = None                  # the low halves 2:4-compressed, in the steps of whichever register-streaming layout this launch reads
+    if d.w_v2 and d.w_v2_lo:
+        which = "w_up4" if folded else ("w_dn4" if stride == 2 else "w_v2")
+        ls, li = getattr(pw, which + "_ls", None), getattr(pw, which + "_li", None)
+    d.w_v2_ls, d.w_v2_li = (_lib.ptr(ls), _lib.ptr(li)) if ls is not None else (None, None)
     if film is not None:          # a column slice of the [B, F] FiLM table
         assert film.stride(1) == 1 and film.shape == (B, pw.cout)
         d.film, d.film_stride = film.data_ptr(), film.stride(0)
