@@ -233,6 +233,41 @@ def test_graph_replayed_philox_chain_at_batch_40_with_wrap(dev):
             run2.step()
 
 
+def test_precision_schedule_runs_the_high_gain_steps_on_the_fp32_kernels(dev):
+    """precision.step_precision in the reverse loop: a chain in the fp16 mode runs its first four steps (update gain 31.6, 1.5, 0.83,
+    0.58 on the cosine schedule) in the fp32 mode - after those four steps its state is BIT-IDENTICAL to a chain run in the fp32 mode on
+    the same Philox noise - and the rest on the fp16 kernels (the states then differ); one captured graph per mode; the schedule is a
+    property of the chain's position, so it repeats after a wrap."""
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision="fp16").to(dev).eval()
+    fill_synth(u, "unet_tiny.")
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+    gd.set_loss(dev)
+    T = 12
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2), dev)
+    gd.noise, gd.seed = "philox", 77
+    cond = G(synth_tensor("sched.cond", (3, 3, 16, 16)), dev)
+    a = gd.make_run(cond, wrap=True)                            # fp16 mode (the module's)
+    b = gd.make_run(cond, wrap=True, precision="fp32")
+    assert a.modes == ["fp32"] * 4 + ["fp16"] * (T - 4) and b.modes == ["fp32"] * T
+    with torch.no_grad():
+        for _ in range(4):
+            a.step(); b.step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.x, b.x)
+        for _ in range(T - 4):
+            a.step(); b.step()
+        torch.cuda.synchronize()
+        assert not torch.equal(a.x, b.x) and rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 2e-3
+        assert set(a.graphs) == {"fp16", "fp32"} and a.graph is a.graphs["fp16"] and int(a.t_ptr.item()) == T - 1      # wrapped
+        xa, xb = a.x.clone(), b.x.clone()
+        for _ in range(4):                                      # second lap: the four high-gain steps again on the fp32 kernels (graph replays)
+            a.step(); b.step()
+        torch.cuda.synchronize()
+    assert torch.isfinite(a.x).all() and a.steps_done == T + 4
+
+
 def test_sharded_driver_under_an_rccl_group_of_one(dev):
     """pipeline.super_resolve_sharded with the default process group initialised on RCCL ("nccl", world size 1): same
     cubes as super_resolve."""
