@@ -155,7 +155,7 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
     autoencoder runs in its default fp32 mode."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from synth import CHAIN_LONG, CHAIN_SET, chain_cubes_draw, chain_noise_draw, chain_weights_check, synth_param
+    from synth import CHAIN_CHIKUSEI, CHAIN_LONG, CHAIN_SET, chain_cubes_draw, chain_noise_draw, chain_weights_check, synth_param
     from hsi_dmgasr_amd import gae, metrics, pipeline
     from hsi_dmgasr_amd.init import init_weights_orthogonal
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
@@ -163,6 +163,10 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
     gold = os.path.join(ROOT, "tests", "golden")
     m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision="fp32").to(dev).eval()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(os.path.join(gold, "gae_cav_state.npz")).items()})
+    m_chi = None
+    if os.path.exists(os.path.join(gold, "gae_chi_state.npz")):      # BASELINE configs[2]: the pretrained Chikusei autoencoder (128 bands, G = 11)
+        m_chi = gae.GAE(gae.Encoder, gae.Decoder, n_subs=16, n_ovls=4, n_colors=128, n_feats=64, precision="fp32").to(dev).eval()
+        m_chi.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(os.path.join(gold, "gae_chi_state.npz")).items()})
     nets = {}
 
     def net(weights, g):
@@ -179,31 +183,36 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
 
     out = {"fixtures": "the reference's validation iteration (one CAVE image, 5 group latents 3x128x128, 97.8M UNet, pretrained CAVE "
                        "autoencoder, cosine schedule) as run by the imported reference: weights {synthetic, reference orthogonal init} x "
-                       "two draws at T=20, and T=1000 on the orthogonal weights; bounds 1e-3 relative / 0.01 dB / 0.001 deg (BASELINE.json north_star)"}
+                       "two draws at T=20, T=1000 on the orthogonal weights, and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
+                       "BASELINE configs[2]; every 4th band of its cube compared); bounds 1e-3 relative / 0.01 dB / 0.001 deg (BASELINE.json north_star)"}
     per = {p: {} for p in modes}
     with torch.no_grad():
-        for fx in tuple(CHAIN_SET) + ((CHAIN_LONG,) if long_modes else ()):
-            weights, draw, steps = fx
-            name = "chain.npz" if fx == ("synth", 0, 20) else os.path.join("chains", "%s_n%d_T%d.npz" % fx)
+        for fx in tuple(CHAIN_SET) + ((CHAIN_LONG,) if long_modes else ()) + ((("chi",) + tuple(CHAIN_CHIKUSEI),) if m_chi is not None else ()):
+            chi = fx[0] == "chi"
+            weights, draw, steps = fx[-3:]
+            name = "chain.npz" if fx == ("synth", 0, 20) else os.path.join("chains", ("chi_" if chi else "") + "%s_n%d_T%d.npz" % (weights, draw, steps))
             if not os.path.exists(os.path.join(gold, name)):
                 continue
             g = np.load(os.path.join(gold, name))
             gd = diffusion.GaussianDiffusion(net(weights, g), image_size=128, channels=3, conditional=True)
             gd.set_loss(dev)
             gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=steps, linear_start=1e-6, linear_end=1e-2), dev)
-            hr, sr = chain_cubes_draw(draw)
+            hr, sr = chain_cubes_draw(draw, 128 if chi else 31)
             ngr = g["x0"].shape[0]
             x_T = G(np.concatenate([chain_noise_draw(draw, gi, 0) for gi in range(ngr)]))
             noise = G(np.stack([np.concatenate([chain_noise_draw(draw, gi, k) for gi in range(ngr)]) for k in range(1, steps)]))
-            truth, ref_y, ref_lat = G(hr), G(g["y"]), G(g["x0"])
-            q_ref = metrics.quality_indices(truth, ref_y)[0]
-            for prec in (modes if steps <= 100 else [p for p in modes if p in long_modes]):
-                y, lat = pipeline.super_resolve(m, gd, G(sr), x_T=x_T, noise=noise, precision=prec)
+            truth, ref_lat = G(hr), G(g["x0"])
+            # (the Chikusei fixture stores every fourth band of the reference's cube and its indices of the whole cube)
+            ref_y = G(g["y_sub4"]) if chi else G(g["y"])
+            q_ref = (float(g["mpsnr_formula"]), float(g["sam_oracle"])) if chi else tuple(float(v) for v in metrics.quality_indices(truth, ref_y)[0][:2])
+            for prec in ([p for p in modes if p in long_modes] if (steps > 100 or chi) else modes):
+                y, lat = pipeline.super_resolve(m_chi if chi else m, gd, G(sr), x_T=x_T, noise=noise, precision=prec)
                 q = metrics.quality_indices(truth, y)[0]
                 e_lat = float((lat[0] - ref_lat).double().norm() / ref_lat.double().norm())
-                e_y = float((y - ref_y).double().norm() / ref_y.double().norm())
-                per[prec]["%s:n%d:T%d" % fx] = dict(latents_rel_err=e_lat, cube_rel_err=e_y, dPSNR_dB=abs(float(q[0] - q_ref[0])),
-                                                     dSAM_deg=abs(float(q[1] - q_ref[1])))
+                ys = y[:, ::4] if chi else y
+                e_y = float((ys - ref_y).double().norm() / ref_y.double().norm())
+                per[prec][":".join(str(v) for v in fx).replace(":%d:%d" % (draw, steps), ":n%d:T%d" % (draw, steps))] = dict(
+                    latents_rel_err=e_lat, cube_rel_err=e_y, dPSNR_dB=abs(float(q[0]) - q_ref[0]), dSAM_deg=abs(float(q[1]) - q_ref[1]))
             del noise, gd
     for prec in modes:
         rows = per[prec]
@@ -211,7 +220,7 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
         out[prec] = dict(worst, fixtures=rows, n_fixtures=len(rows),
                          meets_north_star=bool(worst["latents_rel_err"] <= 1e-3 and worst["cube_rel_err"] <= 1e-3 and
                                                worst["dPSNR_dB"] <= 0.01 and worst["dSAM_deg"] <= 1e-3))
-    del nets, m
+    del nets, m, m_chi
     torch.cuda.empty_cache()
     return out
 

@@ -16,7 +16,7 @@ import torch
 
 from gpu_util import check, fill_synth, log_err
 from helpers import chain_fixture, jload, load_npz, rel_err, synth_tensor
-from synth import CHAIN_LONG, CHAIN_SET, CHAIN_TUNED_ON
+from synth import CHAIN_CHIKUSEI, CHAIN_LONG, CHAIN_SET, CHAIN_TUNED_ON
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,46 @@ def test_full_size_T1000_chain_against_the_reference_run(dev, prec):
     e_lat, e_y, dpsnr, dsam = _run_chain(dev, prec, CHAIN_LONG)
     assert e_lat < LATENT_MAX[prec] and e_y < LATENT_MAX[prec], (prec, e_lat, e_y)
     assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, dpsnr, dsam, e_lat, e_y)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_chikusei_chain_against_the_reference_run(dev, prec):
+    """BASELINE configs[2]: Chikusei, 128 bands -> n_subs 16 / n_ovls 4 -> ELEVEN group latents through the 20-step chain on the shipped
+    UNet (the reference's orthogonal initialisation), encoded and decoded by the reference's PRETRAINED Chikusei autoencoder
+    (GAE_pretrained/GAE_4_Chi.pth, stored as data in tests/golden/gae_chi_state.npz), against the run of the imported reference
+    (tests/golden/chains/chi_orth_n3_T20.npz: the eleven latents, every fourth band of the decoded cube, the indices of the whole cube)."""
+    from hsi_dmgasr_amd import gae, pipeline
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import metrics
+    from synth import chain_cubes_draw, chain_noise_draw
+    weights, draw, steps = CHAIN_CHIKUSEI
+    g = load_npz("chains/chi_%s_n%d_T%d.npz" % CHAIN_CHIKUSEI)
+    _, sd, _, _, _ = chain_fixture("orth", 0, 20)              # the orthogonal weights (rebuilt once per session, checked against the probes)
+    u = unet.UNet(dropout=0.2, precision=prec, **FULL).to(dev).eval()
+    u.load_state_dict(sd)
+    gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=steps, linear_start=1e-6, linear_end=1e-2), dev)
+    m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=16, n_ovls=4, n_colors=128, n_feats=64, precision="fp32").to(dev).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in load_npz("gae_chi_state.npz").items()})
+    assert m.G == 11 == int(g["groups"][0])
+    hr, sr = chain_cubes_draw(draw, 128)
+    ngr = g["x0"].shape[0]
+    x_T = G(np.concatenate([chain_noise_draw(draw, gi, 0) for gi in range(ngr)]), dev)
+    noise = G(np.stack([np.concatenate([chain_noise_draw(draw, gi, k) for gi in range(ngr)]) for k in range(1, steps)]), dev)
+    y, lat = pipeline.super_resolve(m, gd, G(sr, dev), x_T=x_T, noise=noise, precision=prec)
+    torch.cuda.synchronize()
+    lat, y = lat[0].cpu().numpy(), y.cpu().numpy()
+    e_lat, e_y = rel_err(lat, g["x0"]), rel_err(y[:, ::4], g["y_sub4"])
+    a, got = hr[0].transpose(1, 2, 0), y[0].transpose(1, 2, 0)
+    dpsnr = abs(metrics.mpsnr(a, got) - float(g["mpsnr_formula"]))
+    dsam = abs(metrics.sam_degrees(a, got) - float(g["sam_oracle"]))
+    assert abs(float(g["sam_oracle"]) - float(g["sam"])) < 2e-3                        # the restatement against the reference's eval_hsi on its cube
+    log_err("chain_chikusei_T20_latents", prec, e_lat, {"cube_rel_err_every_4th_band": e_y, "dPSNR_dB": dpsnr, "dSAM_deg": dsam,
+                                                        "fixture": "chi:%s:%d:%d" % CHAIN_CHIKUSEI})
+    assert np.isfinite(lat).all() and np.isfinite(y).all()
+    assert e_lat < LATENT_MAX[prec] and e_y < LATENT_MAX[prec], (prec, e_lat, e_y)
+    assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, dpsnr, dsam)
 
 
 @pytest.mark.parametrize("prec", ["fp16x2", "fp16x1"])
