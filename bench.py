@@ -568,7 +568,9 @@ def main():
 
     allgather_ms = None
     with torch.no_grad():
-        for _ in range(max(args.warmup, 2)):               # >= 2: eager step, then graph capture + first replay
+        # >= 6: the chain's first four steps run in the fp32 mode (eager step, graph capture, two replays), then the fp16 mode's eager
+        # step and its capture - every later step, timed or not, is a graph replay of one of the two modes
+        for _ in range(max(args.warmup, 6)):
             run.step()
         torch.cuda.synchronize()
         log('warmup done')
@@ -616,7 +618,7 @@ def main():
         with torch.no_grad():
             r = gd.make_run(cond, wrap=True, precision=prec)
             n = max(10, min(50, args.steps // 20))
-            for _ in range(3):
+            for _ in range(6):                                  # (both modes of a scheduled chain captured before the clock starts)
                 r.step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -657,7 +659,7 @@ def main():
             for pp in (8, 1):
                 b = pp * GROUPS
                 r = gd.make_run(cond[:b].contiguous(), wrap=True)
-                for _ in range(3):
+                for _ in range(6):                              # the four fp32-mode steps of the chain's start, then the fp16 mode's eager step and capture
                     r.step()
                 torch.cuda.synchronize()
                 n = max(50, min(300, args.steps))
