@@ -96,8 +96,8 @@ def test_pipeline_golden(dev, prec):
     x_T = G(g["x_T"][:, 0], dev)                               # [G, 3, H, W]: batch entry = group
     noise = G(np.ascontiguousarray(g["noise"][:, :, 0].transpose(1, 0, 2, 3, 4)), dev)     # [T-1, G, 3, H, W]
     y, lat = pipeline.super_resolve(m, gd, G(g["sr"], dev), x_T=x_T, noise=noise)
-    check("pipeline_latents", prec, lat[0], g["x0"][:, 0], tol=2e-3)
-    check("pipeline_cube", prec, y, g["y"], tol=2e-3)
+    check("pipeline_latents", prec, lat[0], g["x0"][:, 0], tol=1e-3)         # north_star (measured 5e-5 / 9e-5)
+    check("pipeline_cube", prec, y, g["y"], tol=1e-3)
 
 
 def test_quality_indices_on_device(dev):
@@ -192,7 +192,7 @@ def test_validation_iteration_end_to_end(dev):
     nf = odiff.philox_noise_fn(5, tuple(z.shape))
     x0 = odiff.ddim_sample_loop(den, tab, z, nf(5), nf)
     y = ogae.gae_decode(gsd, 31, [x0[i:i + 1] for i in range(x0.shape[0])], 8, 2).clamp(0, 1)
-    check("evaluate_cube", "fp32", sr, y, tol=2e-3)
+    check("evaluate_cube", "fp32", sr, y, tol=1e-3)
     yy = y[0].numpy().transpose(1, 2, 0)
     got = dict(zip(("mpsnr", "sam", "ergas", "cc", "rmse"), idx[0].tolist()))
     assert abs(got["mpsnr"] - om.mpsnr(gt, yy)) < 0.01 and abs(got["sam"] - om.sam_degrees(gt, yy)) < 0.01
