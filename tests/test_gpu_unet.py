@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 # latents, cube, PSNR and SAM, gated at 1e-3 / 0.01 dB / 0.001 deg on five reference chains in tests/test_gpu_chain.py (fp16 mode:
 # 5.8e-4 worst) - because in the fp16 mode every step whose update passes more than half of the UNet's output error on to the
 # state runs on the fp32-mode kernels (precision.step_precision); a forward on the fp16 kernels never reaches an output with a
-# gain above 0.45.  The bound below is therefore a REGRESSION gate on the kernels (measured worst x 1.08), named as such.
+# gain above 0.45 (test_headline_mode_chain_on_the_other_networks holds the CHAIN outputs of the same networks to 1e-3: 4.3e-4 ... 4.8e-4).
+# The bound below is therefore a REGRESSION gate on the kernels (measured worst x 1.08), named as such.
 FWD_FP16 = 1.25e-3
 PRECS = ["fp32", "fp16", "bf16"]
 
@@ -212,6 +213,41 @@ def test_unet_shipped_width_on_a_non_square_batch(dev, prec):
     y = u(G(x, dev), G(gam, dev))
     want = sr3_unet.unet_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(gam))
     check("unet_wide_nonsquare", prec, y, want, tol={"fp32": 1e-3, "fp16": FWD_FP16, "bf16": 8e-2}[prec])
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid", "wide_nonsquare"])
+def test_headline_mode_chain_on_the_other_networks(dev, name):
+    """north_star's quantity - the OUTPUT of the reverse chain - in the headline (fp16) mode on the network configurations whose single
+    forward on the fp16 kernels sits at 1.07e-3 ... 1.17e-3 (FWD_FP16 above): a 20-step cosine chain (Philox noise; the mode's four
+    high-gain steps on the fp32-mode kernels, sixteen on the fp16 kernels) against the oracle's chain, held to 1e-3.  The oracle's
+    forward is pinned to the reference's for these configurations (unets.npz; the non-square one is the shipped channel plan)."""
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import diffusion as odiff, sr3_unet
+    if name == "wide_nonsquare":
+        cfg = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8], attn_res=[8], res_blocks=1, image_size=64)
+        prefix, shape = "unet_wide.", (2, 3, 64, 96)
+    else:
+        cfg = jload(load_npz("unets.npz")[name + ".cfg_json"])
+        prefix, shape = "unet_%s." % name, (3, 3, cfg["image_size"], cfg["image_size"])
+    u = unet.UNet(dropout=0.2, precision="fp16", **cfg).to(dev).eval()
+    sd = fill_synth(u, prefix)
+    T = 20
+    opt = dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2)
+    gd = diffusion.GaussianDiffusion(u, image_size=cfg["image_size"], channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(opt, dev)
+    gd.noise, gd.seed = "philox", 2024
+    cond = synth_tensor("headline_chain.%s.cond" % name, shape)
+    got = gd.p_sample_loop_batched(G(cond, dev))
+    torch.cuda.synchronize()
+    sched = odiff.noise_schedule(opt)
+    den = lambda x, gam: sr3_unet.unet_forward(sd, cfg, x, gam)
+    nf = odiff.philox_noise_fn(2024, shape)
+    xo = nf(T)
+    with torch.no_grad():
+        for i in reversed(range(T)):
+            xo = odiff.p_sample_step(den, sched, xo, torch.from_numpy(cond), i, nf(i) if i > 0 else None)
+    check("headline_chain_T20_" + name, "fp16", got, xo, tol=1e-3)
 
 
 def test_full_size_sampler_is_deterministic_and_finite(dev):
