@@ -170,6 +170,59 @@ def test_T20_chain_ab_forms_of_the_fp16_mode(dev, prec):
     assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, dpsnr, dsam, e_lat, e_y)
 
 
+def test_benchmark_batch_chain_against_the_reference_run(dev):
+    """The BENCHMARK's kernel dispatch - 240 latents per GPU: 256-cout items on 8 waves, multi-round persistent loops, the sparse second
+    weight pass over 30 rounds per launch, XCD tile remap - against the reference: the orthogonal-weights T = 20 chain (five group
+    latents by the imported reference) replicated 48 times into one batch of 240 in the headline mode; EVERY copy is held to north_star's
+    1e-3 on the latents, and the copies agree with each other (the path has no cross-sample arithmetic)."""
+    from hsi_dmgasr_amd import ops
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    fixture = ("orth", 0, 20)
+    g, sd, hr, sr, cn = chain_fixture(*fixture)
+    steps, copies = fixture[2], 48
+    u = unet.UNet(dropout=0.2, precision="fp16", **FULL).to(dev).eval()
+    u.load_state_dict(sd)
+    gd = diffusion.GaussianDiffusion(u, image_size=128, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=steps, linear_start=1e-6, linear_end=1e-2), dev)
+    ngr = g["x0"].shape[0]
+    rep = lambda a: G(a, dev).repeat(copies, 1, 1, 1)                                     # copy c = rows c*ngr .. c*ngr + ngr - 1
+    z = rep(g["z"])
+    x_T = rep(np.concatenate([cn(gi, 0) for gi in range(ngr)]))
+    noise = torch.stack([rep(np.concatenate([cn(gi, k) for gi in range(ngr)])) for k in range(1, steps)])
+    recs = []
+    ops.set_conv_probe(recs)
+    try:
+        run = gd.make_run(z, x_T=x_T, noise=noise, precision="fp16")
+        with torch.no_grad():
+            run.step()                                                                    # (the first step: fp32 mode, eager - probed)
+            for _ in range(4):
+                run.step()
+            torch.cuda.synchronize()
+            del recs[:]
+            run2_labels_from = len(recs)
+            gd.use_graph, keep = False, gd.use_graph                                      # one eager fp16 step under the probe: which kernels the batch takes
+            try:
+                run.step()
+            finally:
+                gd.use_graph = keep
+            labels = sorted({r["kernel"] for r in recs})
+            for _ in range(steps - 6):
+                run.step()
+            torch.cuda.synchronize()
+    finally:
+        ops.set_conv_probe(None)
+    for need in ("conv_v2 bn256 8x16", "conv_v3 bn64", "up4", "dn4", "conv1x1_g"):
+        assert any(need in l for l in labels), (need, labels)
+    assert not any(l.startswith("conv_igemm") for l in labels), labels
+    lat = run.x.cpu().numpy().reshape(copies, ngr, 3, 128, 128)
+    errs = [rel_err(lat[c], g["x0"]) for c in range(copies)]
+    spread = max(rel_err(lat[c], lat[0]) for c in range(1, copies))
+    log_err("chain_T20_batch240_worst_copy", "fp16", max(errs), {"best_copy": min(errs), "copy_to_copy": spread, "fixture": "%s:%d:%d" % fixture})
+    assert max(errs) < NORTH_STAR["latents"], (max(errs), min(errs))
+    assert spread < 1e-6, spread
+
+
 def test_benchmark_dispatch_forward_matches_the_oracle_at_batch_40(dev):
     """The launch set of the benchmark (bench.py at >= 8 patches per GPU) against the CPU oracle: shipped UNet, bf16 mode,
     B = 40, one forward; the probe labels prove which kernels ran."""
