@@ -106,10 +106,11 @@ struct DebugTable {
         v[hsidm::DBG_SK_MULT] = env_int("HSIDM_SK_MULT", 0);
         v[hsidm::DBG_NO_SPLIT_K] = getenv("HSIDM_NO_SPLIT_K") ? 1 : 0;
         v[hsidm::DBG_NO_SPARSE_LO] = getenv("HSIDM_NO_SPARSE_LO") ? 1 : 0;
+        v[hsidm::DBG_NO_FUSED_PROJ] = getenv("HSIDM_NO_FUSED_PROJ") ? 1 : 0;
     }
 };
 DebugTable g_debug;          // constructed when the library is loaded
-const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO"};
+const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ"};
 }  // namespace
 int hsidm::debug_get(int key) { return g_debug.v[key].load(std::memory_order_relaxed); }
 
@@ -163,6 +164,13 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     if (is16(d->prec) && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
         xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 32 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
         !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
+    // A fused 1x1 projection (nphase == 2) on a persistent kernel: the sparse-lo form of conv_v3 (fp16 hi + lo layers, 64 couts, whole
+    // 16x16 tiles) walks it as more one-tap chunks; everything else with a projection stays on the split-K or the LDS-tiled kernel
+    const bool v3_proj = d->nphase == 2 && d->prec == HSIDM_F16 && d->w_v2 && d->w_v2_lo && d->w_v2_ls && d->w_v2_li && !d->out_nchw &&
+                         d->stride == 1 && d->ksize == 3 && !d->ups && xf == HSIDM_XF_AFFINE_SILU && d->bn == 64 && d->Cout == 64 &&
+                         Hout % 16 == 0 && Wout % 16 == 0 && !d->res && (d->ph[0].C0 + d->ph[0].C1) % 64 == 0 &&
+                         !debug_get(DBG_NO_V3) && !debug_get(DBG_NO_SPARSE_LO) && !debug_get(DBG_NO_FUSED_PROJ);
+    if (v3_proj) path = PATH_V3;
     if (v2_mode(d) && d->w_v2 && !d->out_nchw && d->nphase == 1 && d->stride == 1) {
         if (d->ksize == 3 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE_SILU)) path = PATH_V2;
         // (fp32 mode: a shape its two persistent forms - this kernel and the 1x1 GEMM - do not take stays on the LDS-tiled kernel)
@@ -314,7 +322,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
                            d->stride, reinterpret_cast<float*>(d->workspace), elem, s);
     }
     if (use_v2) {
-        ConvV2Params v;
+        ConvV2Params v{};
         v.src0 = reinterpret_cast<const bf16*>(p.ph[0].src0);
         v.src1 = reinterpret_cast<const bf16*>(p.ph[0].src1);
         v.gn_ab = reinterpret_cast<const f32x4*>(p.ph[0].gn_ab);
@@ -335,6 +343,11 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         v.out = reinterpret_cast<bf16*>(d->out); v.stats = reinterpret_cast<float2*>(d->stats);
         v.B = d->B; v.Hin = d->Hin; v.Win = d->Win; v.Hout = Hout; v.Wout = Wout; v.Cout = d->Cout; v.Cout_pad = cout_pad;
         v.ups = d->ups; v.act = d->act; v.tiles_x = tiles_x; v.tiles_y = tiles_y;
+        if (d->nphase == 2) {                    // (conv_validate: only the forms that take a projection get here with one)
+            v.psrc0 = reinterpret_cast<const bf16*>(p.ph[1].src0);
+            v.psrc1 = reinterpret_cast<const bf16*>(p.ph[1].src1);
+            v.PC0 = p.ph[1].C0; v.PC1 = p.ph[1].C1; v.pchunks = p.ph[1].nchunks;
+        }
         if (path == PATH_V3) {
             v.steps_per_item = steps;
             // the second weight pass as a 2:4 structured-sparse one when the caller packed it (HSIDM_NO_SPARSE_LO=1: diagnostic A/B switch)

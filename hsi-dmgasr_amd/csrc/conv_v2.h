@@ -42,6 +42,10 @@ struct ConvV2Params {
     const bf16* src1;       // NHWC [B][Hin][Win][C1] or null (channel concat)
     const f32x4* gn_ab;     // [B][Ctot/2] = (scale, shift) pairs of two channels, or null
     int C0, C1, nchunks;
+    // fused 1x1 projection (PROJ kernels; hsidm_conv_desc.ph[1]): pchunks more 64-channel chunks of one tap, read raw from (psrc0 | psrc1)
+    const bf16* psrc0;
+    const bf16* psrc1;
+    int PC0, PC1, pchunks;
     const bf16* w;          // packed [step][Cout_pad/32][kk 4][lane 64][8], step = chunk*9 + tap
     const bf16* w_lo;       // NP = 2 kernels: the low halves of the weights (w + w_lo: an absolute granularity of 6e-8 - the low halves are fp16 subnormals - i.e. ~18-19 significant bits at |w| ~ 0.03), same layout; else null
     const bf16* w_ls;       // sparse-lo kernels (conv_v3.hip, SPL): the low halves 2:4-compressed, [step][Cout_pad/32][2][64][8] (include/hsidm.h, w_v2_ls)

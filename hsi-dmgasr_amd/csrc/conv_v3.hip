@@ -58,13 +58,14 @@ static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 // weight fragments stay in registers for both rows; two register sets alternate between taps, one tap of lookahead.
 typedef _Float16 f16x16v __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <int WN_, bool NCHW_, typename E = bf16, int NP = 1, bool SPL = false>
+template <int WN_, bool NCHW_, typename E = bf16, int NP = 1, bool SPL = false, bool PROJ = false>
 __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using namespace v3;
     using EL = Elem<E>;
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
     static_assert(!SPL || (NP == 2 && WN_ == 2 && !NCHW_ && !__is_same(E, bf16)), "sparse low halves: fp16, two passes, the 64-cout form");
+    static_assert(!PROJ || SPL, "fused 1x1 projection: built for the sparse-lo form");
     constexpr bool FRG = NP == 2 && !SPL;
     constexpr int FS = 6, FL = 4;                               // a k-slice pair keeps its two fragments for both row halves: FL <= FS - 2
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
@@ -86,6 +87,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     auto div_tx = [&](int x) __attribute__((always_inline)) -> int { return p.tx_shift >= 0 ? x >> p.tx_shift : x / p.tiles_x; };
     const int ctot = p.C0 + p.C1;
     const int nch = p.nchunks;
+    // PROJ: p.pchunks more chunks of ONE tap each - the 1x1 projection of a second input (ResnetBlock.res_conv, reference unet.py:102-103,110)
+    // accumulated into the same tile: staged raw (no GroupNorm / SiLU), multiplied at the centre tap by weight steps 9 nch .. (the host
+    // scales them by log2(e): the epilogue undoes the factor the SiLU staging carries on EVERY product)
+    const int nct = nch + (PROJ ? p.pchunks : 0);
 
     int item = blockIdx.x;                                      // one cout slice: item = pixel tile
     const int n_items_blk = (p.total_items - item + G - 1) / G;
@@ -164,6 +169,27 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         }
     };
     auto issue_all = [&](int chunk) __attribute__((always_inline)) {
+        if (PROJ && chunk >= nch) {                             // workgroup-uniform
+            // projection chunk: only the tile's own 16 x 16 pixels, 2048 vectors = eight per thread: vector i = pixel (row 2 i + tid / 128,
+            // column (tid / 8) % 16), channels 8 (tid % 8) .. of the chunk - addresses a row pair apart, no halo table, no bounds
+            const int c = (chunk - nch) * BK + cv * 8;
+            st_cok = c < p.PC0 + p.PC1;
+            const int cc = st_cok ? c : 0;
+            const E* src;
+            int cs;
+            if (cc < p.PC0) { src = reinterpret_cast<const E*>(p.psrc0) + cc; cs = p.PC0; }
+            else            { src = reinterpret_cast<const E*>(p.psrc1) + (cc - p.PC0); cs = p.PC1; }
+            const int it = tile_of(st_item);
+            const int b = div_tpi(it);
+            const int tr = it - b * tiles_per_img;
+            const int try_ = div_tx(tr);
+            const int oy0 = try_ * TH, ox0 = (tr - try_ * p.tiles_x) * TW;
+            const E* base = src + (size_t)((b * p.Hin + oy0 + (tid >> 7)) * p.Win + ox0 + ((tid >> 3) & 15)) * cs;
+            const size_t pair = (size_t)2 * p.Win * cs;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hreg[i] = *reinterpret_cast<const u32x4*>(base + i * pair);
+            return;
+        }
         const int c = chunk * BK + cv * 8;
         st_cok = c < ctot;
         const int cc = st_cok ? c : 0;
@@ -186,7 +212,20 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     // dead slots of the last (partial) vector round store into the row padding instead of being branched around, so the
     // eleven transforms form one basic block the scheduler can interleave (conv_v2.h: dead_off)
     const int dead_off = (tid / HCOLS) * RP + (tid % HCOLS) * PSTR + BK;      // (the padding of halo pixel `tid`)
-    auto commit_all = [&]() __attribute__((always_inline)) {
+    auto commit_all = [&](bool pj) __attribute__((always_inline)) {
+        if (PROJ && pj) {
+            // projection chunk: the tile's own pixels, raw, stored ONE halo row and column further in than their place in the halo tile
+            // (the matrix phase then reads them with the offsets of tap 8); vector i of issue_all -> rows 2 i apart: immediate offsets
+            E* dst = halo + ((tid >> 7) + 2) * RP + (((tid >> 3) & 15) + 2) * PSTR + cv * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u32x4 ou = hreg[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ou[k] = st_cok ? ou[k] : 0u;
+                *reinterpret_cast<u32x4*>(dst + i * 2 * RP) = ou;
+            }
+            return;
+        }
         int posv[MAXHV];                                        // table reads before the first halo store (they may alias for the compiler)
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * 256 + tid];
@@ -251,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     describe(item);
     issue_all(0);
     auto stage_advance = [&]() __attribute__((always_inline)) {
-        if (st_chunk + 1 < nch) st_chunk += 1;
+        if (st_chunk + 1 < nct) st_chunk += 1;
         else { st_chunk = 0; st_item += G; }
         st_valid = st_item < p.total_items;
     };
@@ -263,17 +302,20 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         float ep_add[2] = {0.f, 0.f}, ep_bias[2] = {0.f, 0.f};  // FiLM / bias of the lane's couts [16-cout half]: loaded in the last chunk
         f32x4 ep4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // SPL: bias + FiLM of couts 16 nh + 4g .. + 3, loaded in the epilogue
 
-        for (int chunk = 0; chunk < nch; ++chunk) {
-            commit_all();                                       // hreg holds (item, chunk): transform -> LDS
+        for (int chunk = 0; chunk < nct; ++chunk) {
+            commit_all(chunk >= nch);                           // hreg holds (item, chunk): transform -> LDS
             if (chunk == 0) HSIDM_STAMP(it, 1);
+            if (PROJ && chunk == nch) HSIDM_STAMP(it, 6);
             stage_advance();
             if (st_valid) {                                     // request the next chunk's raw vectors; they fly during the MFMAs
                 if (st_chunk == 0) describe(st_item);
                 issue_all(st_chunk);
             }
             if (chunk == 0) HSIDM_STAMP(it, 2);
+            if (PROJ && chunk == nch) HSIDM_STAMP(it, 7);
             lds_barrier();
             if (chunk == 0) HSIDM_STAMP(it, 3);
+            if (PROJ && chunk == nch) HSIDM_STAMP(it, 8);
             if (chunk == nch - 1) {
                 // FiLM + bias of the lane's two couts, needed by the epilogue: ordinary (compiler-tracked) loads issued HERE, ahead of
                 // the last chunk's MFMA phase.  vmcnt retires in order and the phase issues 36+ weight loads behind them, so the
@@ -310,6 +352,53 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) a[w % 2][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
                 };
+                if constexpr (PROJ) {
+                    // A projection chunk's raw pixels were committed one halo row and column further in (commit_all), so that tap 8 - offset
+                    // (2, 2) - reads the tile's own pixels: the chunk is the LAST tap of this same loop (register set 0, next weights into set 1)
+                    const bool pj = chunk >= nch;
+                    auto tap_run = [&](int tap) __attribute__((always_inline)) {
+                    const int set = tap & 1;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int w = tap * 4 + kk, r = kk >> 1, q = kk & 1;
+                        if (q == 0) a_fetch(w + 1);
+                        s_issue(tap == 8 ? 1 : set ^ 1, kk);       // the next tap's weights (tap 8: the next chunk's first tap, moved to set 0 below)
+                        if (q == 0 && tap == 0 && chunk == 0) {   // first use of these accumulators: C = 0 as the inline constant (uniform branch)
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int mr = 0; mr < MR; ++mr) acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + nh : 0], a[w % 2][mr], zero);
+                        } else {
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int mr = 0; mr < MR; ++mr)
+                                    acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + 2 * q + nh : 0], a[w % 2][mr], acc[mr][r][nh]);
+                        }
+                        if (q == 1) {                             // the tap's 64 channels of row r against the sparse low halves
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int mr = 0; mr < MR; ++mr) {
+                                    const f16x16v bb = __builtin_shufflevector(a[(w + 1) % 2][mr], a[w % 2][mr], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                                    if (nh == 0) acc[mr][r][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 : 0], bb, acc[mr][r][0], wli[SPL ? set : 0], 0, 0);
+                                    else         acc[mr][r][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 + 1 : 0], bb, acc[mr][r][1], wli[SPL ? set : 0], 0, 1);
+                                }
+                            if (w + 1 < 36) a_fetch(w + 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    };
+                    if (!pj) {
+                        a_fetch(0);
+#pragma unroll
+                        for (int tap = 0; tap < 8; ++tap) tap_run(tap);
+                    } else {
+                        a_fetch(32);
+                    }
+                    tap_run(8);
+                } else {            // (the plain form keeps the loop the allocator was tuned on: at 256 registers any change of shape moves the spills)
                 a_fetch(0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -345,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                }
                 }
                 // nine taps per chunk: the prefetch of tap 8 went to set 1, where tap 0 of the next chunk expects set 0
 #pragma unroll
@@ -398,8 +488,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             }
             HSIDM_SETPRIO(0);
             if (chunk == 0) HSIDM_STAMP(it, 4);
+            if (PROJ && chunk == nch) HSIDM_STAMP(it, 9);
             lds_barrier();                                      // every wave is done reading: the tile may be overwritten
             if (chunk == 0) HSIDM_STAMP(it, 5);
+            if (PROJ && chunk == nch) HSIDM_STAMP(it, 10);
         }
         HSIDM_STAMP(it, 12);
 
@@ -573,11 +665,11 @@ extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds
 
 // Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller); nchw = 0: Cout == 64, NHWC bf16 out;
 // nchw = 1: Cout <= 32 (one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
-template <int WN_, bool NCHW_, typename E, int NP, bool SPL = false>
+template <int WN_, bool NCHW_, typename E, int NP, bool SPL = false, bool PROJ = false>
 static int launch_v3(ConvV2Params& p, int G, hipStream_t s) {
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_, E, NP, SPL>, v3::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_, E, NP, SPL>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
+    if (int rc = raise_lds_cap(once, &conv_v3_kernel<WN_, NCHW_, E, NP, SPL, PROJ>, v3::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_v3_kernel<WN_, NCHW_, E, NP, SPL, PROJ>), dim3(G), dim3(256), v3::LDS_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
@@ -601,6 +693,10 @@ int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, int spl, hipStream_
     if (G == 0) G = p.total_items;
     if (elem == 0 && np == 1) return nchw ? launch_v3<1, true, bf16, 1>(p, G, s) : launch_v3<2, false, bf16, 1>(p, G, s);
     if (elem == 1 && np == 1) return nchw ? launch_v3<1, true, f16, 1>(p, G, s) : launch_v3<2, false, f16, 1>(p, G, s);
+    if (p.pchunks > 0) {        // fused 1x1 projection: the sparse-lo form only (api.hip: conv_v3_takes_proj)
+        if (elem == 1 && np == 2 && spl && !nchw) return launch_v3<2, false, f16, 2, true, true>(p, G, s);
+        return HSIDM_E_UNSUPPORTED;
+    }
     if (elem == 1 && np == 2 && spl && !nchw) return launch_v3<2, false, f16, 2, true>(p, G, s);
     if (elem == 1 && np == 2) return nchw ? launch_v3<1, true, f16, 2>(p, G, s) : launch_v3<2, false, f16, 2>(p, G, s);
     return HSIDM_E_UNSUPPORTED;

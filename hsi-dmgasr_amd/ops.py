@@ -25,7 +25,10 @@ def pick_bn(cout, out_nchw=False):
     return 128
 
 
-def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=False, fold_dn=False):
+LOG2E = 1.4426950408889634
+
+
+def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=False, fold_dn=False, proj_scale=1.0):
     """The packed layouts of one convolution as tensors of `weight`'s dtype (values are only moved, or - for the folded
     upsample kernels - summed): {"w": [step][Cout_pad][BK], "w_v2": ..., "w_up4": ..., "w_dn4": ...} plus the meta data
     PackedConv carries.  Called with the real fp32 weights (PackedConv) and with float64 index-valued tensors
@@ -52,8 +55,13 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     meta = dict(ksize=kh, cin=cin, cout=cout, bn=bn, cpad=cpad, proj_cin=proj_cin, prec=prec, tap_major=False)
     # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
     # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
-    if b16 and proj_weight is not None and kh == 3 and not out_nchw and bn == 128:
-        lay["w_v2"] = PackedConv._lanes(lay["w"], cpad)         # read by the split-K kernel only (conv_sk.hip: projection chunks)
+    # proj_scale != 1 (PackedConv: fp16 hi + lo layers): the projection steps of the register-streaming order carry log2(e) - the
+    # persistent kernels stage log2(e) * silu(.) and undo the factor on the accumulators, i.e. on the projection's products too
+    # (conv_v3.hip, PROJ); the "w" order, which the LDS-tiled kernel reads, stays unscaled
+    if b16 and proj_weight is not None and kh == 3 and not out_nchw and (bn == 128 or (bn == 64 and proj_scale != 1.0)):
+        steps = lay["w"] if proj_scale == 1.0 else torch.cat([parts[0], parts[1] * proj_scale], dim=0).contiguous()
+        lay["w_v2_steps"] = steps
+        lay["w_v2"] = PackedConv._lanes(steps, cpad)            # read by the split-K kernel (conv_sk.hip: projection chunks) or conv_v3's PROJ form
     # fp32 mode: the persistent 3x3 kernel has an fp32 form too (conv_v2.h, AP = 2: fp32 storage, hi + lo operands); it reads the same
     # register-streaming order with 64-channel steps
     f32_v2 = (not b16) and proj_weight is None and not out_nchw and bn in (64, 128) and (kh == 3 or cout % bn == 0)
@@ -110,8 +118,10 @@ class PackedConv:
 
     def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False, fold_ups=False, fold_dn=False):
         dev = weight.device
+        cout, cin, ksz = weight.shape[0], weight.shape[1], weight.shape[2]
+        wide16 = _lib.prec_id(precision) == _lib.F16 and wide_weights(precision, cout, cin + (-cin) % 8, ksz)
         lay, meta = pack_layouts(weight.detach().float(), precision, None if proj_weight is None else proj_weight.detach().float(),
-                                 out_nchw, fold_ups, fold_dn)
+                                 out_nchw, fold_ups, fold_dn, proj_scale=LOG2E if (wide16 and proj_weight is not None) else 1.0)
         self._set_meta(meta, precision, out_nchw)
         b = None if bias is None else bias.detach().float().clone()
         if proj_weight is not None and proj_bias is not None:
@@ -132,9 +142,10 @@ class PackedConv:
         # fp16 hi + lo layers on the plain 3x3 schedule: the low halves once more, 2:4 structured-sparse, for the kernels that run the
         # second pass on v_smfmac (include/hsidm.h: w_v2_ls / w_v2_li; today conv_v3's 64-cout form)
         self.w_v2_ls = self.w_v2_li = self.w_up4_ls = self.w_up4_li = self.w_dn4_ls = self.w_dn4_li = None
-        if (self.prec == _lib.F16 and self.wide and self.w_v2_lo is not None and self.ksize == 3 and proj_weight is None and
+        if (self.prec == _lib.F16 and self.wide and self.w_v2_lo is not None and self.ksize == 3 and
                 not out_nchw and not self.tap_major and self.cin % 64 == 0):
-            self.w_v2_ls, self.w_v2_li = PackedConv._sparse_lo(w - self.w_hi.float(), meta["cpad"])
+            st = w if proj_weight is None else lay["w_v2_steps"]          # (with a projection: its steps scaled, see pack_layouts)
+            self.w_v2_ls, self.w_v2_li = PackedConv._sparse_lo(st - st.to(et).float(), meta["cpad"])
             for name in ("w_up4", "w_dn4"):                     # the folded up / down-sampling layouts (their own steps: summed / re-ordered taps)
                 st = lay.get(name + "_steps")
                 if st is not None and getattr(self, name + "_lo") is not None:
@@ -197,11 +208,12 @@ class PackedConv:
 
 # ------------------------------------------------------------------------------------------- kernels
 def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=None, res_scale=1.0,
-           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=False, sk_only=False):
+           act=ACT_NONE, stride=1, ups=False, proj_x0=None, proj_x1=None, stats=False, sk_only=False, fused_only=False):
     """out = res_scale * act(conv(T(cat(x0, x1))) [+ proj(cat(proj_x0, proj_x1))] + bias + film) + res.
 
     sk_only: launch only if the dispatch takes its split-K form (few pixel tiles, long contraction), else return None - how a
-    ResnetBlock offers its fused-projection descriptor, which no other bf16 kernel of the throughput mode accepts.
+    ResnetBlock offers its fused-projection descriptor to the kernels of the throughput modes that accept one; fused_only: likewise
+    for the persistent kernel's projection form (fp16 hi + lo layers: conv_v3.hip, PROJ).
 
     stats=True: the kernel also writes per-(image, tile part, channel) sums of `out`; they ride on the returned
     tensor as ``out._hsidm_stats = (slab [B, nsplit, C, 2], nsplit)`` and feed gn_scale_shift / ca_vector."""
@@ -263,6 +275,10 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
             d.workspace, d.workspace_bytes = _lib.ptr(ws), ws.numel()
     if sk_only and nb <= 0:
         return None
+    if fused_only:              # launch only if a persistent kernel takes the projection as part of its own contraction (today: conv_v3, PROJ)
+        kid = _lib.lib().hsidm_conv_kernel_id(C.byref(d))
+        if kid < 0 or (kid & 15) != 4:
+            return None
     if stats and not pw.out_nchw:
         nsplit = _lib.lib().hsidm_conv_stats_nsplit(C.byref(d))
         if nsplit <= 0:
@@ -322,6 +338,19 @@ _conv_probe = None
 _use_v2 = True          # set False to force the v1 kernel everywhere (A/B measurements)
 _fold_ups = True        # set False to run upsample convs with HSIDM_UPS_ADDRESS (A/B measurements)
 UPS_FOLDED = 2          # include/hsidm.h HSIDM_UPS_FOLDED
+
+
+_fused_proj = True      # set False to keep every residual projection a launch of its own (A/B measurements)
+
+
+def set_fused_proj(flag):
+    global _fused_proj
+    _fused_proj = bool(flag)
+
+
+def use_fused_proj():
+    import os
+    return _fused_proj and not os.environ.get("HSIDM_NO_FUSED_PROJ")
 
 
 def set_fold_ups(flag):

@@ -166,12 +166,13 @@ class Block(_HipModule):
             proj_weight=None if proj is None else proj.weight, proj_bias=None if proj is None else proj.bias,
             out_nchw=out_nchw))
 
-    def _run(self, x0, precision, x1=None, film=None, res=None, proj=None, proj_x0=None, proj_x1=None, out_nchw=False, sk_only=False):
+    def _run(self, x0, precision, x1=None, film=None, res=None, proj=None, proj_x0=None, proj_x1=None, out_nchw=False, sk_only=False,
+             fused_only=False):
         _need_eval(self, self._dropout)
         gn = self.block[0]
         ab = ops.gn_scale_shift(x0, x1, gn.weight, gn.bias, gn.num_groups, precision, gn.eps)
         return ops.conv2d(x0, self._packed(precision, out_nchw, proj), x1=x1, gn_ab=ab, transform=ops.XF_AFFINE_SILU,
-                          film=film, res=res, proj_x0=proj_x0, proj_x1=proj_x1, stats=not out_nchw, sk_only=sk_only)
+                          film=film, res=res, proj_x0=proj_x0, proj_x1=proj_x1, stats=not out_nchw, sk_only=sk_only, fused_only=fused_only)
 
     def forward(self, x):
         self._check_input(x)
@@ -210,6 +211,13 @@ class ResnetBlock(_HipModule):
                 if is_16bit(precision) and B * H * W <= 16384 and h.shape[3] % 128 == 0 and h.shape[3] >= 256 and \
                         not wide_weights(precision, h.shape[3], h.shape[3], 3):
                     out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, sk_only=True)
+                    if out is not None:
+                        return out
+                # fp16 hi + lo layers on whole 16x16 tiles (the 128x128 level): the projection as one-tap chunks of block2's own launch
+                # (conv_v3.hip, PROJ) - no second pass over x for a separate GEMM, no round trip of its result through HBM
+                if precision in ("fp16", "fp16x2") and h.shape[3] == 64 and H % 16 == 0 and W % 16 == 0 and ops.use_fused_proj() and \
+                        wide_weights(precision, h.shape[3], h.shape[3], 3):
+                    out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, fused_only=True)
                     if out is not None:
                         return out
                 rc = self.res_conv

@@ -47,7 +47,7 @@ extern "C" {
 int hsidm_version(void);
 const char* hsidm_error_string(int code);
 /* Diagnostic dispatch switches for A/B measurements and tests: "NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1",
- * "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
+ * "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
  * reads the environment.  Returns the previous value (>= 0) or HSIDM_E_BADARG for an unknown name. */
 int hsidm_debug_switch(const char* name, int value);
 
@@ -120,8 +120,12 @@ typedef struct hsidm_conv_desc {
                                  (csrc/conv_sk.hip) for launches with few pixel tiles and a long contraction -
                                  the 8x8 / 16x16 levels at small batches; NULL: the persistent kernels only.
                                  With nphase == 2 and w_v2 (its steps: 9 per chunk of phase 0, then 1 per chunk of
-                                 phase 1) the split form is the only w_v2 kernel that applies: ask
-                                 hsidm_conv_workspace_bytes first, 0 = launch the projection separately         */
+                                 phase 1) two w_v2 kernels apply: the split form - ask hsidm_conv_workspace_bytes first -
+                                 and, for HSIDM_F16 descriptors with w_v2_lo + w_v2_ls / w_v2_li, Cout == 64, GN + SiLU on
+                                 phase 0, whole 16x16 tiles and no residual, the persistent kernel's projection form
+                                 (csrc/conv_v3.hip, PROJ: hsidm_conv_kernel_id(d) & 15 == 4); its phase-1 steps of w_v2 /
+                                 w_v2_lo / w_v2_ls carry the projection's weights times log2(e) (the kernel removes the
+                                 factor its SiLU staging leaves on every product).  Neither: launch the projection separately */
     int64_t workspace_bytes;
     const void*  w_v2_lo;     /* optional (HSIDM_F16 with w_v2): fp16(W - fp16(W)) in the layout of w_v2 - the weights then carry
                                  ~18-19 significant bits (the low halves are fp16 subnormals for |w| < 0.125: absolute granularity 6e-8) for twice the matrix instructions (the weight rounding

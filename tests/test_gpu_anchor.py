@@ -166,6 +166,55 @@ def test_sparse_second_weight_pass_removes_the_weight_bias(dev, shape):
     assert rel_err(out["sparse"].numpy(), out["dense"].numpy()) < 3e-4
 
 
+@pytest.mark.parametrize("shape", [(64, 128, 64, 2, 32, 48), (64, 64, 0, 3, 16, 16), (128, 64, 8, 2, 32, 32)],
+                         ids=["cat_192", "single_64", "ragged_72"])
+def test_projection_fused_into_the_persistent_kernel(dev, shape):
+    """ResnetBlock's tail, h2 = conv3x3(silu(GN(h))) + conv1x1(cat(x0, x1)) + biases (reference unet.py:105-111), on the fp16 hi + lo
+    64-cout layers: the projection as one-tap chunks of the 3x3 launch (conv_v3.hip, PROJ: raw staging, centre tap, projection
+    weights scaled by log2(e) on the host, sparse low halves) against fp32 torch on the host and against the two-launch form (1x1 GEMM,
+    then the 3x3 kernel with its result as the residual).  Projection widths: 192 = two tensors, 64, and 72 (a last chunk of 8 live
+    channels: the staging zeroes the rest)."""
+    from hsi_dmgasr_amd import ops
+    Ci, P0, P1, B, H, W = shape
+    g = torch.Generator().manual_seed(Ci + P0 + P1)
+    Co = 64
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    b = 0.1 * torch.randn(Co, generator=g)
+    wp = torch.randn(Co, P0 + P1, 1, 1, generator=g) / (P0 + P1) ** 0.5
+    bp = 0.1 * torch.randn(Co, generator=g)
+    h = torch.randn(B, H, W, Ci, generator=g).to(torch.float16).to(dev)
+    x0 = torch.randn(B, H, W, P0, generator=g).to(torch.float16).to(dev)
+    x1 = torch.randn(B, H, W, P1, generator=g).to(torch.float16).to(dev) if P1 else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, Ci, generator=g), 0.2 * torch.randn(B, Ci, generator=g)], 2).contiguous().to(dev)
+    tab = ops.gn_table(ab)
+    want = _reference(h, None, ab, True, w, b, None, None) + _reference(x0, x1, None, False, wp, bp, None, None, ksize=1)
+    for mode in ("fp16", "fp16x2"):
+        pk = ops.PackedConv(w.to(dev), b.to(dev), mode, proj_weight=wp.to(dev), proj_bias=bp.to(dev))
+        recs = []
+        ops.set_conv_probe(recs)
+        try:
+            y = ops.conv2d(h, pk, gn_ab=tab, transform=ops.XF_AFFINE_SILU, proj_x0=x0, proj_x1=x1, stats=True, fused_only=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_conv_probe(None)
+        assert y is not None and "conv_v3" in recs[-1]["kernel"], recs
+        assert_stats(y._hsidm_stats[0], y, "proj_fused")
+        check("anchor_proj_fused_%d_%d" % (Ci, P0 + P1), mode, y, want, tol=TOL["fp16x2"])
+        # the two-launch form on the same operands
+        r = ops.conv2d(x0, ops.PackedConv(wp.to(dev), bp.to(dev), mode), x1=x1)
+        y2 = ops.conv2d(h, ops.PackedConv(w.to(dev), b.to(dev), mode), gn_ab=tab, transform=ops.XF_AFFINE_SILU, res=r)
+        torch.cuda.synchronize()
+        e1, e2 = rel_err(y.float().cpu().numpy(), want.numpy()), rel_err(y2.float().cpu().numpy(), want.numpy())
+        log_err("proj_two_launch_%d_%d" % (Ci, P0 + P1), mode, e2)
+        assert e1 < 1.1 * e2 + 2e-5, (e1, e2)          # (the fused form skips one fp16 rounding of the projection's result)
+    # the switch: with it the descriptor is not taken by a persistent kernel and the caller keeps its two launches
+    old = _lib.lib().hsidm_debug_switch(b"NO_FUSED_PROJ", 1)
+    try:
+        assert ops.conv2d(h, pk, gn_ab=tab, transform=ops.XF_AFFINE_SILU, proj_x0=x0, proj_x1=x1, fused_only=True) is None
+    finally:
+        _lib.lib().hsidm_debug_switch(b"NO_FUSED_PROJ", old)
+
+
 @pytest.mark.parametrize("mode", ["fp16x1", "fp16x2"])
 def test_subnormal_only_weights_are_multiplied(dev, mode):
     """Every weight an fp16 SUBNORMAL (|w| <= 4e-5 < 6.1e-5; in the two-pass form the low halves are multiples of 6e-8): a matrix

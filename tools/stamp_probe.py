@@ -29,9 +29,12 @@ def main():
     w = torch.randn(Co, C0 + C1, ks, ks, generator=g) / (9 * (C0 + C1)) ** 0.5
     prec = os.environ.get("HSIDM_PROBE_PREC", "bf16")            # bf16 | fp16 (hi + lo weights where the policy says) | fp16x1
     adt = torch.bfloat16 if prec == "bf16" else torch.float16
-    pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), prec)
+    pjc = [int(v) for v in os.environ.get("HSIDM_PROBE_PROJ", "").split(",") if v]        # "128,64": a fused 1x1 projection of cat(128, 64) channels
+    wp = torch.randn(Co, sum(pjc), 1, 1, generator=g) / max(sum(pjc), 1) ** 0.5 if pjc else None
+    pk = ops.PackedConv(w.to(dev), torch.zeros(Co, device=dev), prec, proj_weight=None if wp is None else wp.to(dev))
     x0 = torch.randn(B, H, H, C0, generator=g).to(dev, adt)
     x1 = torch.randn(B, H, H, C1, generator=g).to(dev, adt) if C1 else None
+    px = [torch.randn(B, H, H, c, generator=g).to(dev, adt) for c in pjc]
     ab = ops.gn_table(torch.stack([torch.ones(B, C0 + C1), torch.zeros(B, C0 + C1)], dim=2).contiguous().to(dev))
     xf = ops.XF_AFFINE_SILU if not up else ops.XF_NONE
     stamps = torch.zeros(512 * 4 * 8 * 16, dtype=torch.int64, device=dev)
@@ -41,7 +44,9 @@ def main():
     for rep in range(3):
         stamps.zero_()
         L.hsidm_debug_set_stamps(stamps.data_ptr())
-        y = ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=xf, ups=bool(up), stats=True)
+        y = ops.conv2d(x0, pk, x1=x1, gn_ab=ab if xf else None, transform=xf, ups=bool(up), stats=True,
+                       proj_x0=px[0] if pjc else None, proj_x1=px[1] if len(pjc) > 1 else None, fused_only=bool(pjc))
+        assert y is not None
         torch.cuda.synchronize()
     L.hsidm_debug_set_stamps(None)
     s = stamps.cpu().numpy().reshape(512, 4, 8, 16).astype(np.float64)
@@ -63,6 +68,10 @@ def main():
             print("item %d: commit=%6.0f issue=%6.0f bar1=%6.0f mfma=%6.0f bar2=%6.0f | epilogue=%6.0f bar3=%6.0f | total=%6.0f" % (
                 it, np.median(e(1) - e(0)), np.median(e(2) - e(1)), np.median(e(3) - e(2)), np.median(e(4) - e(3)),
                 np.median(e(5) - e(4)), np.median(e(14) - e(12)), np.median(e(13) - e(14)), np.median(e(13) - e(0))))
+            if pjc:         # first projection chunk (slots 6..10) and whatever lies between it and the epilogue (further projection chunks)
+                print("        proj chunk 1: commit=%6.0f issue=%6.0f bar1=%6.0f mfma=%6.0f bar2=%6.0f | further chunks=%6.0f" % (
+                    np.median(e(6) - e(5)), np.median(e(7) - e(6)), np.median(e(8) - e(7)), np.median(e(9) - e(8)), np.median(e(10) - e(9)),
+                    np.median(e(12) - e(10))))
             continue
         line = "item %d: n=%4d  start@%8.0f  loop=%7.0f  (last pre-barrier->barrier %6.0f)  epilogue=%7.0f" % (
             it, ok.sum(), np.median(start - t0), np.median(ep0 - start), np.median(ep0 - pre), np.median(ep1 - ep0))
