@@ -141,7 +141,12 @@ def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1, mode
                 best_launch=dict(cin=top["cin"], cout=top["cout"], hw=list(top["hw"]), us=top["ms"] * 1e3,
                                  tflops=top["flops"] / (top["ms"] * 1e-3) / 1e12),
                 all_conv_kernels=dict(launches=len(best), flops_per_step=all_fl, ms_per_step=all_ms,
-                                      tflops=all_fl / (all_ms * 1e-3) / 1e12))
+                                      tflops=all_fl / (all_ms * 1e-3) / 1e12),
+                # every kernel instance of the conv family, largest first: the dominant one above is simply the first row
+                # ("+proj": the launches that carry a ResnetBlock's 1x1 projection as one-tap chunks; its FLOPs are counted)
+                kernels=[dict(kernel=k, launches=g["n"], ms_per_step=g["ms"], avg_launch_us=g["ms"] / g["n"] * 1e3,
+                              tflops=g["flops"] / (g["ms"] * 1e-3) / 1e12, frac=g["flops"] / (g["ms"] * 1e-3) / 1e12 / peak)
+                         for k, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])][:8])
 
 
 def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32")):

@@ -303,7 +303,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
                                             ("8x16", "8x8x2", "8x8")[(kid >> 4) & 3], pw.ksize, stride,
                                             " gn+silu" if transform == XF_AFFINE_SILU else (" gn" if transform == XF_AFFINE else "") +
                                             (" up4" if folded else (" ups" if ups else (" dn4" if planes else ""))),
-                                            " nchw" if pw.out_nchw else "")
+                                            (" nchw" if pw.out_nchw else "") + (" +proj" if pw.proj_cin else ""))
         _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize, kernel=label,
                                 bytes=(B * H * W * (C0 + C1) + B * Ho * Wo * pw.cout) * x0.element_size() + pw.w_hi.numel() * 2,
                                 stride=stride, ups=bool(ups), cin=pw.cin, cout=pw.cout, hw=(Ho, Wo),
