@@ -436,3 +436,38 @@ def test_sparse_low_half_packing_matches_the_measured_operand_semantics():
     want = (grp * keep).reshape(st, cpad, 64).to(torch.float16).double()
     assert torch.equal(dense, want)
     assert float((want ** 2).sum() / (lo.double() ** 2).sum()) > 0.8          # the kept pairs carry most of the low halves' energy
+
+
+def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent_kernel():
+    """A ResnetBlock's block2 conv packed together with its 1x1 res_conv (reference unet.py:102-103,110) for an fp16 hi + lo layer: the
+    register-streaming order gets 9 steps per 64-channel chunk of the 3x3 conv followed by ONE step per chunk of the projection, and the
+    projection's steps carry log2(e) (conv_v3.hip, PROJ: the SiLU staging leaves that factor on every product of the launch and the
+    epilogue removes it from the accumulators); hi + lo + the 2:4-sparse low halves describe the same scaled weights; the order the
+    LDS-tiled kernel reads stays unscaled; the biases are summed.  A layer without hi + lo weights (bf16) is packed unscaled."""
+    from hsi_dmgasr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    co, ci, pc = 64, 64, 72                       # 72 projection channels: two chunks, the second with 8 live channels
+    w = torch.randn(co, ci, 3, 3, generator=g) * 0.05
+    wp = torch.randn(co, pc, 1, 1, generator=g) * 0.1
+    b, bp = torch.randn(co, generator=g), torch.randn(co, generator=g)
+    pk = ops.PackedConv(w, b, "fp16", proj_weight=wp, proj_bias=bp)
+    assert pk.wide and pk.proj_cin == pc and torch.allclose(pk.bias, b + bp)
+    nst = 9 * 1 + 2
+    assert pk.w_v2.shape[0] == nst and pk.w_v2_lo.shape == pk.w_v2.shape and pk.w_v2_ls.shape[0] == nst and pk.w_v2_li.shape[0] == nst
+    # undo _lanes: [step][cout/32][kk][h][r][8] -> [step][cout][64]
+    def unlane(t):
+        st = t.shape[0]
+        return t.reshape(st, co // 32, 4, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(st, co, 64)
+    both = unlane(pk.w_v2.double() + pk.w_v2_lo.double())
+    want3 = w.double().reshape(co, ci, 9).permute(2, 0, 1)                          # [tap][cout][cin]
+    assert float((both[:9] - want3).abs().max()) < 1e-7
+    wpad = torch.zeros(co, 128, dtype=torch.float64)
+    wpad[:, :pc] = wp.double().reshape(co, pc) * ops.LOG2E
+    wantp = wpad.reshape(co, 2, 64).permute(1, 0, 2)                                # [chunk][cout][64]
+    assert float((both[9:] - wantp).abs().max()) < 2e-7
+    assert float(both[10, :, 8:].abs().max()) == 0.0                                # zero weights behind the 72nd channel
+    # the LDS-tiled kernel's order: unscaled
+    raw = pk.w_hi.double() + pk.w_lo.double()                                       # [step][cout_pad][64]
+    assert float((raw[9, :, :64] - wp.double().reshape(co, pc)[:, :64]).abs().max()) < 1e-7
+    pk16 = ops.PackedConv(w, b, "bf16", proj_weight=wp, proj_bias=bp)
+    assert not pk16.wide and pk16.w_v2 is None                                      # (64 couts: no split-K form, nothing reads a w_v2 with projection steps)
