@@ -160,7 +160,7 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
     autoencoder runs in its default fp32 mode."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from synth import CHAIN_CHIKUSEI, CHAIN_LONG, CHAIN_SET, chain_cubes_draw, chain_noise_draw, chain_weights_check, synth_param
+    from synth import CHAIN_CHIKUSEI, CHAIN_LONG_SET, CHAIN_SET, chain_cubes_draw, chain_noise_draw, chain_weights_check, synth_param
     from hsi_dmgasr_amd import gae, metrics, pipeline
     from hsi_dmgasr_amd.init import init_weights_orthogonal
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
@@ -188,11 +188,11 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
 
     out = {"fixtures": "the reference's validation iteration (one CAVE image, 5 group latents 3x128x128, 97.8M UNet, pretrained CAVE "
                        "autoencoder, cosine schedule) as run by the imported reference: weights {synthetic, reference orthogonal init} x "
-                       "two draws at T=20, T=1000 on the orthogonal weights, and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
+                       "two draws at T=20, two 1000-step chains (one per weight set), and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
                        "BASELINE configs[2]; every 4th band of its cube compared); bounds 1e-3 relative / 0.01 dB / 0.001 deg (BASELINE.json north_star)"}
     per = {p: {} for p in modes}
     with torch.no_grad():
-        for fx in tuple(CHAIN_SET) + ((CHAIN_LONG,) if long_modes else ()) + ((("chi",) + tuple(CHAIN_CHIKUSEI),) if m_chi is not None else ()):
+        for fx in tuple(CHAIN_SET) + (tuple(CHAIN_LONG_SET) if long_modes else ()) + ((("chi",) + tuple(CHAIN_CHIKUSEI),) if m_chi is not None else ()):
             chi = fx[0] == "chi"
             weights, draw, steps = fx[-3:]
             name = "chain.npz" if fx == ("synth", 0, 20) else os.path.join("chains", ("chi_" if chi else "") + "%s_n%d_T%d.npz" % (weights, draw, steps))

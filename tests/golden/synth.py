@@ -97,6 +97,7 @@ def chain_noise(group, k, shape=(1, 3, 128, 128)):
 # ---- the chain fixture SET (tests/golden/chains/, make_golden_chains.py): weight set x noise draw x chain length
 CHAIN_SET = (("synth", 0, 20), ("orth", 0, 20), ("orth", 1, 20), ("synth", 1, 20))      # T = 20: the shipped validation setting
 CHAIN_LONG = ("orth", 2, 1000)                                                           # BASELINE.json's metric: the 1000-step loop
+CHAIN_LONG_SET = (CHAIN_LONG, ("synth", 3, 1000))                                        # ... and a second one: the other weight set, another draw
 CHAIN_CHIKUSEI = ("orth", 3, 20)                                                         # configs[2]: 128 bands, 11 groups, pretrained GAE_4_Chi
 CHAIN_TUNED_ON = ("synth", 0, 20)       # the ONE fixture precision policies may be selected on; the others are hold-outs
 

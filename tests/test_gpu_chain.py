@@ -16,7 +16,7 @@ import torch
 
 from gpu_util import check, fill_synth, log_err
 from helpers import chain_fixture, jload, load_npz, rel_err, synth_tensor
-from synth import CHAIN_CHIKUSEI, CHAIN_LONG, CHAIN_SET, CHAIN_TUNED_ON
+from synth import CHAIN_CHIKUSEI, CHAIN_LONG_SET, CHAIN_SET, CHAIN_TUNED_ON
 
 pytestmark = pytest.mark.gpu
 
@@ -112,12 +112,14 @@ def test_full_size_T20_chain_against_the_reference_run(dev, prec, fixture):
     assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, fixture, dpsnr, dsam, e_lat, e_y)
 
 
+@pytest.mark.parametrize("fixture", CHAIN_LONG_SET, ids=lambda f: "%s-n%d-T%d" % f)
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
-def test_full_size_T1000_chain_against_the_reference_run(dev, prec):
+def test_full_size_T1000_chain_against_the_reference_run(dev, prec, fixture):
     """BASELINE.json's metric is the 1000-step p_sample_loop (reference diffusion.py:177-201): one CAVE image through all 1000
-    steps of the cosine chain with the reference's own orthogonal initialisation (the weights bench.py times), against the run of
-    the imported reference (tests/golden/chains/orth_n2_T1000.npz, make_golden_chains.py; 999 stored noise draws per group)."""
-    e_lat, e_y, dpsnr, dsam = _run_chain(dev, prec, CHAIN_LONG)
+    steps of the cosine chain against the run of the imported reference (tests/golden/chains/*_T1000.npz, make_golden_chains.py;
+    999 stored noise draws per group) - with the reference's own orthogonal initialisation (the weights bench.py times) and, a second
+    image and draw, with the synthetic weight set."""
+    e_lat, e_y, dpsnr, dsam = _run_chain(dev, prec, fixture)
     assert e_lat < LATENT_MAX[prec] and e_y < LATENT_MAX[prec], (prec, e_lat, e_y)
     assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, dpsnr, dsam, e_lat, e_y)
 
