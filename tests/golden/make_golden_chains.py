@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The chain fixture SET (chains/<weights>_n<draw>_T<steps>.npz) by IMPORTING THE REFERENCE (build container only):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_chains.py orth:0:20 orth:1:20 synth:1:20 orth:2:1000 chi:orth:3:20
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_chains.py orth:0:20 orth:1:20 synth:1:20 orth:2:1000 synth:3:1000 chi:orth:3:20
 
 Same run as make_golden_chain.py (chain.npz = "synth:0:20", kept as it is) - the reference's validation iteration,
 sr_gae.py:436-474, at the shipped configuration on one CAVE image - over

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 # 1.16e-3 against the reference (tiny / mid / full / non-square): 11-bit storage of ~70 tensors, of which the residual stream's
 # is the largest part (tests/precision_emul.py on the full-size forward: stream tensors in fp32 -27 %, fp32 GroupNorm pairs -10 %,
 # fp32 projection outputs -10 %, centred rounding -5 %).  That number is NOT one of north_star's quantities - those are the chain's
-# latents, cube, PSNR and SAM, gated at 1e-3 / 0.01 dB / 0.001 deg on five reference chains in tests/test_gpu_chain.py (fp16 mode:
+# latents, cube, PSNR and SAM, gated at 1e-3 / 0.01 dB / 0.001 deg on seven reference chains in tests/test_gpu_chain.py (fp16 mode:
 # 5.8e-4 worst) - because in the fp16 mode every step whose update passes more than half of the UNet's output error on to the
 # state runs on the fp32-mode kernels (precision.step_precision); a forward on the fp16 kernels never reaches an output with a
 # gain above 0.45 (test_headline_mode_chain_on_the_other_networks holds the CHAIN outputs of the same networks to 1e-3: 4.3e-4 ... 4.8e-4).
