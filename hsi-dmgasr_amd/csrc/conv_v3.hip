@@ -56,6 +56,9 @@ static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 // the low halves lose the smaller two of every four values: 20 % of their energy, i.e. of a 2^-12 correction (tests/precision_emul.py,
 // w=x2s: the 20-step chain moves from 5.38e-4 to 5.50e-4).  Sub-steps run in the order (tap, row r, slice q): the tap's four dense
 // weight fragments stay in registers for both rows; two register sets alternate between taps, one tap of lookahead.
+// PROJ (with SPL): the launch also carries a ResnetBlock's 1x1 residual projection (hsidm_conv_desc.ph[1]; reference unet.py:102-103,110) as
+// pchunks more 64-channel chunks of ONE tap accumulated into the same tile - see "PROJ" at issue_all / commit_all / the matrix phase.  In-box
+// A/B and the in-kernel stamps of the projection chunks: profiles/r04_final/ab_fused_proj.txt, stamps_v3_proj.txt.
 typedef _Float16 f16x16v __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int WN_, bool NCHW_, typename E = bf16, int NP = 1, bool SPL = false, bool PROJ = false>
