@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the denoising hot path: SR3 UNet p_sample steps over GAE-latent batches on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (+ --detail for the secondary legs)
 
 N > 1 from a plain shell: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process
 (before anything touches the GPU) and exits with its return code; under torch.distributed.run (RANK / WORLD_SIZE set) it is
@@ -10,28 +10,21 @@ one rank per GPU over RCCL.  --total-patches P: strong scaling (BASELINE configs
 A "step" is one reverse-diffusion step (noise embedding + full 97.8 M-parameter UNet forward + fused
 posterior update) over this GPU's batch of latents: `--patches` CAVE patches x 5 spectral groups, each a
 (3,128,128) latent conditioned on its low-resolution latent (BASELINE.json configs[1]; cosine T=1000).
-Inputs are resident in HBM before the timed region; the step is a captured HIP graph.  Rank 0 prints ONE
-JSON line.  value = steps * total batch / seconds  ("UNet denoise-steps/sec x batch").
+Inputs are resident in HBM before the timed region; the step is a captured HIP graph.
+value = steps * total batch / seconds  ("UNet denoise-steps/sec x batch").
 
-The headline precision mode is "fp16" (fp16 storage and MFMA operands, hi + lo weights on the two high-resolution levels, the four
-steps of a chain whose update has an error gain >= 0.5 on the fp32-mode kernels - they are inside the timed region): the fastest
-mode that meets north_star's tolerance on FIVE chains run by the imported reference (tests/golden/chain.npz, chains/*.npz) - the
-`parity` object of the line says so per mode and fixture, worst case first, measured in this run.  bf16 (the mode BASELINE configs[1] names) is faster and does NOT
-meet it; its throughput is reported beside the headline (`bf16_mode`), as is the fp32 mode's (`fp32_mode`).
+OUTPUT.  The LAST line of stdout (rank 0) is ONE compact JSON object (< 4 KB, `compact_line`): the contract fields, `roofline`
+(dominant kernel instance + the conv_v3 family as one row + the whole step), `cpu_baseline` (both cases) and `parity` (the
+headline mode's worst case over the reference-chain fixtures).  Everything else - per-fixture parity, every kernel instance's
+roofline row, and with --detail the other precision modes, small batches, the group autoencoder, the training step and the
+1000-step reference chains - goes to the side file `bench_detail.json` (--detail-out), never to stdout.
 
-Extra objects in the line:
-  roofline     - the implicit-GEMM conv kernel family (the dominant kernel): algorithmic FLOPs of its launches
-                 in one step / their HIP-event durations, against the dense 16-bit MFMA peak.
-  parity       - per precision mode: the reference's validation chain (one CAVE image, 97.8 M UNet, pretrained autoencoder) run on
-                 this GPU against FIVE runs of the imported reference (tests/golden/chain.npz, chains/*.npz: two weight sets x two
-                 draws at T = 20, and the metric's own 1000-step chain): per fixture and WORST-case latents relative error, cube
-                 relative error, dPSNR, dSAM, and meets_north_star (1e-3 / 0.01 dB / 0.001 degrees, about the worst case).
-  cpu_baseline - the oracle (CPU restatement of the reference, oracle/) timed on this host, rank 0, N=1 only.
-  bf16_mode / fp32_mode - the same step in the other two modes: ms per step, throughput, dominant-kernel roofline
-                 (rank 0, N=1 only).
-  gae          - group-autoencoder encode / decode of this rank's patches (31 x 128 x 128 CAVE cubes): ms, TFLOP/s,
-                 fraction of the MFMA peak (the step before / after the chain, sr_gae.py:456,467).
-  rccl_ranks / allgather_ms - N > 1: ranks in the RCCL group and the time of the final all-gather of the SR cubes.
+The headline precision mode is "fp16" (fp16 storage and MFMA operands, hi + 2:4-sparse lo weights on the two high-resolution
+levels; the four steps of a chain whose update has an error gain >= 0.5 run on the fp32-mode kernels).  Those four steps are
+the FIRST four of a chain: the warm-up (>= 6 steps: both modes' eager step and graph capture) consumes them, so a timed window
+shorter than the rest of the chain (`--steps` < ~990, e.g. the driver's --steps 20) contains NONE of them.  The line says how
+many it contained (`config.fp32_mode_steps_in_window`), times the fp32-mode graph separately and reports the per-chain mix
+(996 fp16-mode + 4 fp32-mode steps) as `config.value_chain_mix` beside the measured `value`.
 """
 import argparse
 import json
@@ -51,8 +44,11 @@ SCHED = dict(schedule="cosine", n_timestep=1000, linear_start=1e-6, linear_end=1
 GROUPS = 5                 # CAVE: 31 bands, n_subs=8, n_ovls=2 -> 5 spectral groups (AE.py:263)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, bf16 and fp16 alike, MI355X_MICROARCH.md
 HEADLINE = "fp16"                # the fastest mode that meets north_star's tolerance (see `parity`)
-DTYPE = {"bf16": "bf16", "fp16": "fp16 (hi + 2:4-sparse lo fp16 weights on the Cout<=128 layers; the 4 steps of a chain with update gain >= 0.5 in the fp32 mode)", "fp16x1": "fp16 (one weight pass)",
-         "fp16x2": "fp16 (hi+lo fp16 weights wherever a kernel takes them)", "fp32": "fp32 (bf16x3 split)"}
+DTYPE = {"bf16": "bf16 storage and MFMA operands (outside north_star's tolerance: experimental)",
+         "fp16": "fp16 storage and MFMA operands; hi + 2:4-sparse lo fp16 weights on the Cout<=128 layers; the 4 steps of a chain with "
+                 "update gain >= 0.5 on the fp32-mode kernels",
+         "fp16x1": "fp16 (one weight pass)", "fp16x2": "fp16 (hi+lo fp16 weights wherever a kernel takes them)",
+         "fp32": "fp32 storage, every product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi)"}
 HBM_PEAK_GBPS = 8000.0           # HBM3E spec (6290 measured by a streaming read), MI355X_MICROARCH.md
 
 
@@ -146,10 +142,22 @@ def conv_roofline(run, batch, reps=3, peak=MFMA_BF16_PEAK_TFLOPS, passes=1, mode
                 # ("+proj": the launches that carry a ResnetBlock's 1x1 projection as one-tap chunks; its FLOPs are counted)
                 kernels=[dict(kernel=k, launches=g["n"], ms_per_step=g["ms"], avg_launch_us=g["ms"] / g["n"] * 1e3,
                               tflops=g["flops"] / (g["ms"] * 1e-3) / 1e12, frac=g["flops"] / (g["ms"] * 1e-3) / 1e12 / peak)
-                         for k, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])][:8])
+                         for k, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])],
+                # the conv_v3 launches of the 128x128 level (64 couts, with and without the fused projection) as ONE row: the kernel
+                # FAMILY with the largest share of the step, whichever instance leads
+                conv_v3_family=family_row(groups, "conv_v3 bn64", peak))
 
 
-def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32")):
+def family_row(groups, prefix, peak):
+    rows = [g for k, g in groups.items() if k.startswith(prefix)]
+    if not rows:
+        return None
+    ms, fl, n = sum(g["ms"] for g in rows), sum(g["flops"] for g in rows), sum(g["n"] for g in rows)
+    return dict(kernel=prefix + " (all instances)", launches=n, ms_per_step=ms, avg_launch_us=ms / n * 1e3,
+                tflops=fl / (ms * 1e-3) / 1e12, frac=fl / (ms * 1e-3) / 1e12 / peak)
+
+
+def chain_parity(dev, modes=("fp16",), long_modes=(), orth_net=None):
     """north_star's tolerance, measured here on the chain fixture SET: the reference's own validation iteration (sr_gae.py:436-474)
     at its shipped configuration - T = 20 cosine chain, one CAVE image = 5 group latents, 97.8 M UNet, pretrained CAVE
     autoencoder - run BY THE IMPORTED REFERENCE for two weight sets (synthetic Gaussian keyed by name; the reference's own
@@ -181,8 +189,13 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
                 u.load_state_dict({k: torch.from_numpy(synth_param("unet_full." + k, tuple(v.shape))) for k, v in u.state_dict().items()
                                    if not k.startswith("_")}, strict=False)
             else:       # build_model()'s weights; the fixture's probes prove they are the ones the reference's init_weights produced
-                init_weights_orthogonal(u, seed=0)
-                chain_weights_check({k: v.detach() for k, v in u.state_dict().items()}, [str(k) for k in g["w_keys"]], g["w_probe"])
+                if orth_net is not None:
+                    u = orth_net                 # the very network the headline was timed on
+                else:
+                    init_weights_orthogonal(u, seed=0)
+                keys = [str(k) for k in g["w_keys"]]
+                usd = u.state_dict()
+                chain_weights_check({k: usd[k].detach().cpu() for k in keys}, keys, g["w_probe"])
             nets[weights] = u.to(dev).eval()
         return nets[weights]
 
@@ -210,7 +223,8 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
             # (the Chikusei fixture stores every fourth band of the reference's cube and its indices of the whole cube)
             ref_y = G(g["y_sub4"]) if chi else G(g["y"])
             q_ref = (float(g["mpsnr_formula"]), float(g["sam_oracle"])) if chi else tuple(float(v) for v in metrics.quality_indices(truth, ref_y)[0][:2])
-            for prec in ([p for p in modes if p in long_modes] if (steps > 100 or chi) else modes):
+            # (the 1000-step chains only in `long_modes`; bf16 - outside the tolerance by 8x - not on the Chikusei fixture)
+            for prec in ([p for p in modes if p in long_modes] if steps > 100 else ([p for p in modes if p != "bf16"] if chi else modes)):
                 y, lat = pipeline.super_resolve(m_chi if chi else m, gd, G(sr), x_T=x_T, noise=noise, precision=prec)
                 q = metrics.quality_indices(truth, y)[0]
                 e_lat = float((lat[0] - ref_lat).double().norm() / ref_lat.double().norm())
@@ -221,6 +235,8 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
             del noise, gd
     for prec in modes:
         rows = per[prec]
+        if not rows:
+            continue
         worst = {k: max(r[k] for r in rows.values()) for k in ("latents_rel_err", "cube_rel_err", "dPSNR_dB", "dSAM_deg")}
         out[prec] = dict(worst, fixtures=rows, n_fixtures=len(rows),
                          meets_north_star=bool(worst["latents_rel_err"] <= 1e-3 and worst["cube_rel_err"] <= 1e-3 and
@@ -230,20 +246,23 @@ def chain_parity(dev, modes=("fp16", "bf16", "fp32"), long_modes=("fp16", "fp32"
     return out
 
 
-def cpu_baseline(cases=((1, 120), (5, 30)), warm=2):
-    """The oracle on the host CPU: full-size UNet p_sample steps (fp32), a bounded sample (about 10-15 s per case) of the same
-    workload at B = 1 (one group latent) and B = 5 (one CAVE image = 5 group latents, the reference's own unit of work,
-    sr_gae.py:458-465): `steps` of the 1000 reverse steps each (every step costs the same).  `value` is the better
-    of the two rates; both are in `cases`."""
+def cpu_baseline(cases=((1, 42), (5, 12)), warm=2, segments=3, sd=None):
+    """The oracle on the host CPU: full-size UNet p_sample steps (fp32), a bounded sample (~10 s in total) of the same workload
+    at B = 1 (one group latent per call: how the reference itself runs, sr_gae.py:458-465 loops over the groups at batch 1) and
+    B = 5 (one CAVE image's five group latents in one batch): `steps` of the 1000 reverse steps each (every step costs the
+    same).  Threads are pinned to the usable cores; each case is timed in `segments` equal parts and reports the
+    MEDIAN part (hosts of this pool are shared: single samples ranged 7.7 ... 14.7).  `value` is the B = 1 case - the
+    reference's own mode of execution; both are in `cases`."""
     from oracle import diffusion as odiff, sr3_unet
     from hsi_dmgasr_amd.init import init_weights_orthogonal
     from hsi_dmgasr_amd.sr3_modules import unet
     threads = min(usable_cpus(), 64)
     torch.set_num_threads(threads)
-    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8],
-                  attn_res=[16], res_blocks=2, dropout=0.2, image_size=128)
-    init_weights_orthogonal(u, seed=0)
-    sd = {k: v.detach() for k, v in u.state_dict().items()}
+    if sd is None:          # (main() passes the timed network's own state: the same orthogonal-init weights, one initialisation fewer)
+        u = unet.UNet(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=[1, 2, 4, 8, 8],
+                      attn_res=[16], res_blocks=2, dropout=0.2, image_size=128)
+        init_weights_orthogonal(u, seed=0)
+        sd = {k: v.detach() for k, v in u.state_dict().items()}
     sched = odiff.noise_schedule(SCHED)
     den = lambda xx, gam: sr3_unet.unet_forward(sd, FULL_CFG, xx, gam)
     recs = {}
@@ -251,18 +270,26 @@ def cpu_baseline(cases=((1, 120), (5, 30)), warm=2):
         g = torch.Generator().manual_seed(1)
         cond = torch.randn((batch, 3, 128, 128), generator=g).clamp(-2.5, 2.5)
         x = torch.randn((batch, 3, 128, 128), generator=g)
+        per = max(1, steps // segments)
+        parts = []
         with torch.no_grad():
-            t0 = None
-            for k in range(warm + steps):
-                if k == warm:
-                    t0 = time.perf_counter()
+            for k in range(warm):
                 x = odiff.p_sample_step(den, sched, x, cond, 999 - k, torch.randn(x.shape, generator=g))
-            dt = time.perf_counter() - t0
-        recs["batch_%d" % batch] = dict(value=steps * batch / dt, s_per_step=dt / steps, steps=steps, seconds=dt)
-    best = max(recs.values(), key=lambda r: r["value"])
-    return dict(value=best["value"], unit="denoise-steps*batch/s", cores=threads, kind="port", cases=recs,
-                sample="p_sample steps of the full UNet on the fp32 oracle, %d threads: %s" % (threads, "; ".join(
-                    "%d steps at batch %s in %.1f s" % (r["steps"], k.split("_")[1], r["seconds"]) for k, r in recs.items())))
+            k = warm
+            for _ in range(segments):
+                t0 = time.perf_counter()
+                for _ in range(per):
+                    x = odiff.p_sample_step(den, sched, x, cond, 999 - k, torch.randn(x.shape, generator=g))
+                    k += 1
+                parts.append(time.perf_counter() - t0)
+        med = sorted(parts)[len(parts) // 2]
+        recs["batch_%d" % batch] = dict(value=per * batch / med, s_per_step=med / per, steps=per * segments, seconds=sum(parts),
+                                        segment_rates=[per * batch / p for p in parts])
+    head = recs["batch_%d" % cases[0][0]]
+    return dict(value=head["value"], unit="denoise-steps*batch/s", cores=threads, kind="port", cases=recs,
+                sample="p_sample steps of the full 97.8M UNet on the fp32 oracle, %d pinned threads, median of %d segments: %s" % (
+                    threads, segments, "; ".join("%d steps at batch %s in %.1f s" % (r["steps"], k.split("_")[1], r["seconds"])
+                                                 for k, r in recs.items())))
 
 
 def log(msg):
@@ -504,6 +531,70 @@ def main_train(args, dev, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def _r(v, nd=4):
+    """Numbers of the compact line: `nd` significant digits are what the measurement carries."""
+    if isinstance(v, float):
+        return float("%.*g" % (nd + 2, v))
+    return v
+
+
+def compact_line(head, roof=None, parity=None, cpu=None, mode=HEADLINE, detail_path=None, extra=None):
+    """The contract line (the LAST stdout line of rank 0) from the measured objects - kept under 4 KB so that a driver reading
+    the tail of stdout always gets the whole object (tests/test_host_logic.py holds it to that).  `head`: the contract's scalar
+    fields + config; roof / parity / cpu: the full objects (conv_roofline, chain_parity, cpu_baseline), of which only the
+    headline figures are kept here - the full objects go to the detail file."""
+    line = dict(head)
+    if roof is not None:
+        tr = roof.get("traffic")
+        hv = roof.get("hbm_view") or {}
+        fam = roof.get("conv_v3_family")
+        line["roofline"] = {
+            "bound": roof["bound"], "kernel": roof["kernel"], "launches": roof["launches"], "avg_launch_us": _r(roof["avg_launch_us"]),
+            "algorithmic_flops_per_launch": _r(roof["algorithmic_flops_per_launch"]),
+            "algorithmic_bytes_per_launch": _r(roof["algorithmic_bytes_per_launch"]),
+            "achieved": _r(roof["achieved"]), "peak": roof["peak"], "unit": roof["unit"], "frac": _r(roof["frac"]),
+            # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE counter passes of this command (profiles/, same batch), or null
+            "traffic": None if tr is None else _r(tr["hbm_bytes_per_launch"]),
+            "traffic_source": None if tr is None else roof.get("traffic_source"),
+            "share_of_conv_time": _r(roof["share_of_conv_time"]),
+            "whole_step": None if roof.get("whole_step") is None else {k: _r(v) for k, v in roof["whole_step"].items()},
+            "conv_v3_family": None if fam is None else {k: _r(v) for k, v in fam.items()},
+            "fused_resnetblock_hbm_frac": _r((hv.get("fused_unit") or {}).get("frac")),
+            "resnetblock_launch_hbm_frac": _r(hv.get("frac")),
+        }
+    if cpu is not None:
+        line["cpu_baseline"] = {"value": _r(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                "sample": cpu["sample"],
+                                "cases": {k: {"value": _r(r["value"]), "s_per_step": _r(r["s_per_step"])} for k, r in cpu["cases"].items()}}
+    if parity is not None and parity.get(mode):
+        pm = parity[mode]
+        line["parity"] = {"mode": mode, "latents_rel_err": _r(pm["latents_rel_err"]), "cube_rel_err": _r(pm["cube_rel_err"]),
+                          "dPSNR_dB": _r(pm["dPSNR_dB"]), "dSAM_deg": _r(pm["dSAM_deg"]), "n_fixtures": pm["n_fixtures"],
+                          "worst_of": sorted(pm["fixtures"]), "bounds": "1e-3 rel / 0.01 dB / 0.001 deg (north_star)",
+                          "oracle": "chains run by the imported reference (tests/golden/chain*.npz)",
+                          "meets_north_star": pm["meets_north_star"]}
+        line["meets_north_star"] = pm["meets_north_star"]
+    if extra:
+        line.update(extra)
+    if detail_path:
+        line["detail"] = detail_path
+    return line
+
+
+def timed_mode_replays(run, mode, n):
+    """Average ms of `n` replays of the run's captured graph of `mode` (after the timed region; the state just keeps walking)."""
+    g = run.graphs.get(mode)
+    if g is None:
+        return None
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -516,14 +607,20 @@ def main():
                     help="strong scaling: this many patches in total, sharded contiguously over the ranks (BASELINE configs[3]: 64)")
     ap.add_argument("--precision", default=HEADLINE, choices=["bf16", "fp32", "fp16", "fp16x1", "fp16x2"],
                     help="precision mode of the headline number (default: the fastest mode that meets north_star's tolerance)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity object (the T=20 reference chain in every mode)")
-    ap.add_argument("--no-modes", action="store_true", help="skip the bf16_mode / fp32_mode objects")
+    ap.add_argument("--detail", action="store_true",
+                    help="also measure the secondary legs into the detail file: other precision modes, small batches, the group "
+                         "autoencoder, the training step, parity in every mode incl. the 1000-step reference chains (adds ~1 min)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"))
+    ap.add_argument("--parity-long", action="store_true", help="parity also over the two 1000-step reference chains (-m gpu runs them too)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode object")
-    ap.add_argument("--no-gae", action="store_true", help="skip the group-autoencoder object")
-    ap.add_argument("--no-small", action="store_true", help="skip the small-batch object (40 and 5 latents per GPU)")
-    ap.add_argument("--no-train", action="store_true", help="skip the training-step object (BASELINE configs[4])")
+    # (legs of --detail, individually switchable)
+    ap.add_argument("--no-modes", action="store_true", help="--detail without the bf16_mode / fp32_mode objects")
+    ap.add_argument("--no-fp32", action="store_true", help="--detail without the fp32-mode object")
+    ap.add_argument("--no-gae", action="store_true", help="--detail without the group-autoencoder object")
+    ap.add_argument("--no-small", action="store_true", help="--detail without the small-batch object (40 and 5 latents per GPU)")
+    ap.add_argument("--no-train", action="store_true", help="--detail without the training-step object (BASELINE configs[4])")
     ap.add_argument("--workload", default="sample", choices=["sample", "train"],
                     help="sample: the headline metric (reverse-diffusion steps); train: BASELINE configs[4], one joint-train step "
                          "(UNet forward + backward + Adam, gradients all-reduced over the ranks) on --train-batch latents per GPU")
@@ -548,7 +645,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
-    from hsi_dmgasr_amd import parallel
+    from hsi_dmgasr_amd import parallel, precision as P
+    if args.detail or args.precision in P.EXPERIMENTAL_MODES or args.workload == "train":
+        P.allow_experimental(True)          # the bf16 kernel set is measured beside the public modes, labelled `meets_north_star: false`
     if args.workload == "train":
         return main_train(args, dev, rank, world, use_dist)
     log('building model')
@@ -575,7 +674,8 @@ def main():
     with torch.no_grad():
         # >= 6: the chain's first four steps run in the fp32 mode (eager step, graph capture, two replays), then the fp16 mode's eager
         # step and its capture - every later step, timed or not, is a graph replay of one of the two modes
-        for _ in range(max(args.warmup, 6)):
+        n_warm = max(args.warmup, 6)
+        for _ in range(n_warm):
             run.step()
         torch.cuda.synchronize()
         log('warmup done')
@@ -598,6 +698,22 @@ def main():
         dt, dt_min = float(el.item()), float(el_min.item())
         assert torch.isfinite(run.x).all(), "sampler state diverged"
         log('timed region done: %.3f s' % dt)
+        # steps of the timed window that ran in another mode than the chain's base mode (the precision schedule's fp32-mode steps
+        # sit at the START of each chain: a window shorter than the rest of the chain has none), and the per-chain mix
+        T = run.T
+        base_mode = run.modes[-1]
+        n_other = sum(1 for k in range(n_warm, n_warm + args.steps) if run.modes[k % T] != base_mode)
+        per_chain_other = sum(1 for m in run.modes if m != base_mode)
+        mix = None
+        if per_chain_other and rank == 0:
+            other = next(m for m in run.modes if m != base_mode)
+            t_other = timed_mode_replays(run, other, 8)
+            if t_other is not None and args.steps > n_other:
+                t_base = (dt * 1e3 - n_other * t_other) / (args.steps - n_other)
+                ms_mix = ((T - per_chain_other) * t_base + per_chain_other * t_other) / T
+                mix = dict(ms_per_step_base_mode=t_base, ms_per_step_other_mode=t_other, other_mode=other,
+                           steps_per_chain_other_mode=per_chain_other, chain_steps=T, ms_per_step_chain_mix=ms_mix,
+                           value_chain_mix=total_patches * GROUPS / (ms_mix * 1e-3))
         if use_dist:
             # the path's one data collective: every rank ends with all SR cubes (here: cube-sized stand-ins for the decoded
             # patches, 31 x 128 x 128 fp32 each = 2.0 MB per patch)
@@ -615,9 +731,15 @@ def main():
         roof = None
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(run, batch, mode=args.precision)
-            # (fp16 mode: launches with hi + lo weights issue two MFMAs per product; `achieved` counts the algorithmic FLOPs once)
-            roof["mfma_passes_per_product"] = "2 on the Cout<=128 layers, 1 elsewhere" if args.precision == "fp16" else (2 if args.precision == "fp16x2" else 1)
+            # (fp16 mode: launches with hi + lo weights issue 1.5 matrix passes per product; `achieved` counts the algorithmic FLOPs once)
+            roof["mfma_passes_per_product"] = "1.5 on the Cout<=128 layers (hi + 2:4-sparse lo), 1 elsewhere" if args.precision == "fp16" else (2 if args.precision == "fp16x2" else 1)
+            roof["traffic_source"] = "profiles/hbm_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2*FETCH+WRITE, gfx950)" % args.precision
+            # the whole step against the same roof: SURVEY 8(d)'s 92.35 GFLOP per latent and step over the measured step time
+            ms_base = mix["ms_per_step_base_mode"] if mix else dt / args.steps * 1e3
+            tf = 92.35e9 * batch / (ms_base * 1e-3) / 1e12
+            roof["whole_step"] = dict(algorithmic_flops=92.35e9 * batch, ms=ms_base, tflops=tf, frac=tf / roof["peak"])
     log('roofline done')
+
     def other_mode(prec, passes):
         """The same step, workload and batch in another precision mode (rank 0, N = 1)."""
         with torch.no_grad():
@@ -638,25 +760,30 @@ def main():
         torch.cuda.empty_cache()
         return rec
 
+    solo = rank == 0 and world == 1
+    del run
+    torch.cuda.empty_cache()
     fp32 = bf16 = None
-    if rank == 0 and world == 1 and not args.no_modes and args.precision == HEADLINE:
-        del run
-        torch.cuda.empty_cache()
+    if solo and args.detail and not args.no_modes and args.precision == HEADLINE:
         bf16 = other_mode("bf16", 1)
         log('bf16 mode done')
         if not args.no_fp32:
             fp32 = other_mode("fp32", 3)      # fp32 storage, every product as three bf16 MFMAs
             log('fp32 mode done')
     parity = None
-    if rank == 0 and world == 1 and not args.no_parity:
-        parity = chain_parity(dev)
-        if bf16 is not None:
+    if solo and not args.no_parity:
+        # default: the headline mode over the T = 20 reference chains (4 CAVE + Chikusei); --parity-long / --detail add the two
+        # 1000-step chains, --detail the other modes
+        pm = ("fp16", "bf16", "fp32") if args.detail else ((args.precision,) if args.precision in ("fp16", "bf16", "fp32") else ("fp16",))
+        lm = tuple(m for m in pm if m != "bf16") if (args.detail or args.parity_long) else ()
+        parity = chain_parity(dev, modes=pm, long_modes=lm, orth_net=gd.denoise_fn)
+        if bf16 is not None and parity.get("bf16"):
             bf16["meets_north_star"] = parity["bf16"]["meets_north_star"]
-        if fp32 is not None:
+        if fp32 is not None and parity.get("fp32"):
             fp32["meets_north_star"] = parity["fp32"]["meets_north_star"]
         log('parity done')
     small = None
-    if rank == 0 and world == 1 and not args.no_small and args.precision == HEADLINE and batch > 8 * GROUPS:
+    if solo and args.detail and not args.no_small and args.precision == HEADLINE and batch > 8 * GROUPS:
         # the same step at the per-GPU share of BASELINE configs[3] on 8 GPUs (8 patches = 40 latents) and at one CAVE image (the
         # reference's own use: 5 latents): what strong scaling and single-image latency are made of
         small = {}
@@ -673,48 +800,64 @@ def main():
                     r.step()
                 torch.cuda.synchronize()
                 d = time.perf_counter() - t0
-                small["%d_latents" % b] = dict(value=n * b / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n)
+                small["%d_latents" % b] = dict(value=n * b / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n,
+                                               note="steady-state fp16-mode steps (behind the chain's first six)")
                 del r
         log('small batches done')
     gae_rec = gae_chik = None
-    if rank == 0 and not args.no_gae:
+    if rank == 0 and args.detail and not args.no_gae:
         with torch.no_grad():
             gae_rec = gae_bench(dev, patches)
             # BASELINE configs[2]: Chikusei, 128 bands, n_subs 16 / n_ovls 4 -> G = 11 groups (AE.py:263-280)
             gae_chik = gae_bench(dev, min(patches, 16), bands=128, n_subs=16, n_ovls=4, groups=11, flops=dict(encode=92.5e9, decode=92.5e9 + 3.8e9))
         log('gae done')
     train_rec = None
-    if rank == 0 and world == 1 and not args.no_train:
+    if solo and args.detail and not args.no_train:
         train_rec = train_bench(dev)
         log('train step done')
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+    if solo and not args.no_cpu_baseline:
+        sd = {k: v.detach().cpu() for k, v in gd.denoise_fn.state_dict().items()}
+        del gd
+        torch.cuda.empty_cache()
+        cpu = cpu_baseline(sd=sd)
         log('cpu baseline done')
 
     if rank == 0:
         total_batch = total_patches * GROUPS
-        line = {
+        head = {
             "metric": "UNet denoise-steps/sec x batch, CAVE 31-band 16->128, 1000-step p_sample_loop",
-            "value": args.steps * total_batch / dt,
+            "value": _r(args.steps * total_batch / dt, 5),
             "unit": "denoise-steps*batch/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": _r(dt / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": DTYPE[args.precision],
-            "meets_north_star": None if parity is None or args.precision not in parity else parity[args.precision]["meets_north_star"],
+            "dtype": {"fp16": "fp16", "fp16x1": "fp16", "fp16x2": "fp16", "bf16": "bf16", "fp32": "f32 (bf16x3)"}[args.precision],
             "data": "synthetic (orthogonal-init weights seed 0, N(0,1) latents clipped to +-2.5, Philox noise)",
             "config": {"workload": "SR3 UNet 97.8M (6->3 ch, inner 64, mults 1-2-4-8-8, attn@16) p_sample step on "
                                    "GAE latents 3x128x128, cosine T=1000, BASELINE configs[%d]" % (3 if scaling == "strong" else 1),
                        "patches_per_gpu": patches, "total_patches": total_patches, "groups_per_patch": GROUPS,
-                       "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world},
-            "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": allgather_ms,
-            "rank_ms_per_step": {"min": dt_min / args.steps * 1e3, "max": dt / args.steps * 1e3},
-            "roofline": roof, "parity": parity, "bf16_mode": bf16, "fp32_mode": fp32, "small_batches": small, "gae": gae_rec,
-            "gae_chikusei": gae_chik, "train_step": train_rec, "cpu_baseline": cpu,
+                       "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world,
+                       "precision_mode": DTYPE[args.precision],
+                       "fp32_mode_steps_in_window": n_other,
+                       "ms_per_step_chain_mix": None if mix is None else _r(mix["ms_per_step_chain_mix"], 5),
+                       "value_chain_mix": None if mix is None else _r(mix["value_chain_mix"], 5)},
+            "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": _r(allgather_ms),
+            "rank_ms_per_step": {"min": _r(dt_min / args.steps * 1e3, 5), "max": _r(dt / args.steps * 1e3, 5)},
         }
+        detail = {"line": None, "chain_mix": mix, "roofline": roof, "parity": parity, "bf16_mode": bf16, "fp32_mode": fp32,
+                  "small_batches": small, "gae": gae_rec, "gae_chikusei": gae_chik, "train_step": train_rec, "cpu_baseline": cpu}
+        dpath = None
+        try:
+            line = compact_line(head, roof, parity, cpu, args.precision, os.path.relpath(args.detail_out, ROOT))
+            detail["line"] = line
+            with open(args.detail_out, "w") as f:
+                json.dump(detail, f, indent=1)
+            dpath = args.detail_out
+        except OSError:
+            line = compact_line(head, roof, parity, cpu, args.precision, None)       # read-only tree: the line alone
         flush_c_stdio()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if use_dist:
         dist.barrier()                     # rank 0's extra measurements are done: every rank leaves the group together
         dist.destroy_process_group()

@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ops
 from .._lib import act_dtype
-from ..precision import is_16bit, resolve_precision, wide_weights
+from ..precision import forward_precision, is_16bit, resolve_precision, wide_weights
 
 
 def exists(x):
@@ -95,7 +95,12 @@ class _HipModule(nn.Module):
     precision = None           # None -> package default (hsi_dmgasr_amd.set_default_precision)
 
     def _prec(self, precision=None):
-        return resolve_precision(precision if precision is not None else self.precision)
+        """Kernel set of this call.  An explicit `precision` (the sampler's per-step choice, the training step) is taken as named; a
+        bare module call runs the set its mode prescribes for an output that IS the result (precision.forward_precision: the
+        "fp16" policy -> the fp32 kernel set)."""
+        if precision is not None:
+            return resolve_precision(precision)
+        return forward_precision(resolve_precision(self.precision))
 
     @staticmethod
     def _check_input(x):
