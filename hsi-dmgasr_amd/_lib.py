@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSIDM_LIB: diagnostic override (A/B builds, in-kernel stamp builds); the product library is libhsidm.so next to this file
 LIB_PATH = os.environ.get("HSIDM_LIB") or os.path.join(_HERE, "libhsidm.so")
 
+ABI_VERSION = 2          # include/hsidm.h: HSIDM_ABI_VERSION (the ConvDesc below has w_v2_ls / w_v2_li)
 BF16, F32X3, F16 = 0, 1, 2
 XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
@@ -42,6 +43,7 @@ class WgradItem(C.Structure):
 SIGNATURES = {
     "hsidm_version": [],
     "hsidm_debug_switch": [C.c_char_p, _i32],
+    "hsidm_debug_query": [C.c_char_p],
     "hsidm_conv_bk": [_i32],
     "hsidm_conv2d": [C.POINTER(ConvDesc), _vp],
     "hsidm_conv_stats_nsplit": [C.POINTER(ConvDesc)],
@@ -116,6 +118,10 @@ def lib():
             fn.restype = _i64 if name in RESTYPE_I64 else _i32
         L.hsidm_error_string.argtypes = [_i32]
         L.hsidm_error_string.restype = C.c_char_p
+        got = L.hsidm_version()
+        if got != ABI_VERSION:      # a library built against another header would read the structs above past their end
+            raise RuntimeError("hsidm: %s implements ABI version %d, this binding is written against %d - rebuild it "
+                               "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, got, ABI_VERSION))
         _lib = L
     return _lib
 

@@ -39,7 +39,7 @@ int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, in
 
 using namespace hsidm;
 
-extern "C" int hsidm_version(void) { return 1; }
+extern "C" int hsidm_version(void) { return HSIDM_ABI_VERSION; }
 
 // Diagnostic builds (-DHSIDM_V2_STAMPS): device buffer [blocks][4][8][16] of s_memtime stamps; not part of hsidm.h.
 extern "C" void hsidm_debug_set_stamps(void* p) { conv_v2_set_stamps(reinterpret_cast<unsigned long long*>(p)); }
@@ -124,6 +124,13 @@ extern "C" int hsidm_debug_switch(const char* name, int value) {
     return HSIDM_E_BADARG;
 }
 
+extern "C" int hsidm_debug_query(const char* name) {
+    if (!name) return HSIDM_E_BADARG;
+    for (int i = 0; i < hsidm::DBG_COUNT; ++i)
+        if (!strcmp(name, kDebugNames[i])) { const int v = g_debug.v[i].load(); return v < 0 ? 0 : v; }
+    return HSIDM_E_BADARG;
+}
+
 static bool force_v1_1x1() { return debug_get(DBG_1X1_V1) == 1; }
 
 static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
@@ -142,6 +149,9 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     if (d->ups && d->stride != 1) return HSIDM_E_UNSUPPORTED;
     if (d->out_nchw && (d->ksize != 3 || d->stride != 1 || d->bn == 64 || d->stats)) return HSIDM_E_UNSUPPORTED;
     if (d->nphase == 2 && (d->ksize != 3 || d->stride != 1 || d->ups || d->ph[1].ntaps != 1)) return HSIDM_E_UNSUPPORTED;
+    // a fused projection reads its input RAW on every kernel that takes one (ResnetBlock.res_conv(x), reference unet.py:110): a
+    // transformed projection phase would give path-dependent results (the LDS-tiled kernel would apply it, conv_v3 / conv_sk not)
+    if (d->nphase == 2 && d->ph[1].transform != HSIDM_XF_NONE) return HSIDM_E_UNSUPPORTED;
     Hout = d->ups ? 2 * d->Hin : (d->stride == 2 ? (d->Hin + 1) / 2 : d->Hin);
     Wout = d->ups ? 2 * d->Win : (d->stride == 2 ? (d->Win + 1) / 2 : d->Win);
     if (Hout != d->Hout || Wout != d->Wout) return HSIDM_E_BADARG;

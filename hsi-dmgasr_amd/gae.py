@@ -187,6 +187,8 @@ class GAE(nn.Module):
 
     def __init__(self, Encoder=Encoder, Decoder=Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=128, precision="fp32"):
         super().__init__()
+        if precision not in (None, "fp32", "fp16"):         # (checked again per call: the attribute is assignable)
+            raise ValueError("hsidm: the group autoencoder runs in precision 'fp32' (default) or 'fp16', got %r" % (precision,))
         self.Encoder = Encoder(n_subs, 3, n_feats)
         self.Decoder = Decoder(3, n_subs, n_feats)
         self.precision = precision

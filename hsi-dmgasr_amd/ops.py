@@ -340,7 +340,9 @@ _fold_ups = True        # set False to run upsample convs with HSIDM_UPS_ADDRESS
 UPS_FOLDED = 2          # include/hsidm.h HSIDM_UPS_FOLDED
 
 
-_fused_proj = True      # set False to keep every residual projection a launch of its own (A/B measurements)
+import os as _os
+# set False (or HSIDM_NO_FUSED_PROJ=1, read ONCE here) to keep every residual projection a launch of its own (A/B measurements)
+_fused_proj = not _os.environ.get("HSIDM_NO_FUSED_PROJ")
 
 
 def set_fused_proj(flag):
@@ -349,8 +351,13 @@ def set_fused_proj(flag):
 
 
 def use_fused_proj():
-    import os
-    return _fused_proj and not os.environ.get("HSIDM_NO_FUSED_PROJ")
+    """Is the persistent kernel's projection form on offer?  The host switch AND the library's own switches (hsidm_debug_query:
+    NO_FUSED_PROJ / NO_V3 / NO_SPARSE_LO): asked BEFORE a ResnetBlock computes a GroupNorm table or packs the projection layouts
+    for the offer, so that a refused offer costs nothing (A/B runs through the debug switches stay clean)."""
+    if not _fused_proj:
+        return False
+    L = _lib.lib()
+    return not any(L.hsidm_debug_query(name) for name in (b"NO_FUSED_PROJ", b"NO_V3", b"NO_SPARSE_LO"))
 
 
 def set_fold_ups(flag):

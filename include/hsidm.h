@@ -44,12 +44,18 @@ extern "C" {
 #define HSIDM_ACT_NONE  0
 #define HSIDM_ACT_LEAKY 1        /* LeakyReLU(0.01)                                                  */
 
+/* ABI version of this header: bumped whenever a struct below grows or a prototype changes (2: hsidm_conv_desc gained w_v2_ls /
+ * w_v2_li).  hsidm_version() returns the version the LIBRARY was built against; a caller built against another header must refuse
+ * to run (a shorter hsidm_conv_desc would be read 16 bytes past its end) - the ctypes binding does (hsi-dmgasr_amd/_lib.py). */
+#define HSIDM_ABI_VERSION 2
 int hsidm_version(void);
 const char* hsidm_error_string(int code);
 /* Diagnostic dispatch switches for A/B measurements and tests: "NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1",
  * "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
  * reads the environment.  Returns the previous value (>= 0) or HSIDM_E_BADARG for an unknown name. */
 int hsidm_debug_switch(const char* name, int value);
+/* Current value of a switch (>= 0) without changing it, or HSIDM_E_BADARG. */
+int hsidm_debug_query(const char* name);
 
 /* ---- convolution ------------------------------------------------------------------------------
  * One K-phase of hsidm_conv2d: an input tensor (optionally the channel concat of two tensors,
@@ -135,8 +141,17 @@ typedef struct hsidm_conv_desc {
                                  input channels (per cout and tap) the two of larger magnitude - as the A operand of
                                  v_smfmac_f32_16x16x64_f16: fp16 [step][Cout_pad/32][half 2][lane 64][8]; lane = 16 * kgroup + cout % 16 of the
                                  16-cout half holds channels 16 * kgroup .. + 15 of the step's 64: stored slots 2m, 2m + 1 = the kept values of
-                                 channels 16 * kgroup + 4m .. + 3 (measured semantics: tools/ubench/smfmac_probe.hip).  A kernel that takes it
-                                 runs the second weight pass at ~0.6 of its dense cost on 80 % of the low halves' energy                  */
+                                 channels 16 * kgroup + 4m .. + 3 (measured semantics: tools/ubench/smfmac_probe.hip, its output:
+                                 profiles/r05_ubench/smfmac_probe.txt: stored slot sa of A lane group ga with index field v pairs with K = 16 ga + 4 (sa / 2) + v).
+                                 The instruction's B side (the activations; built inside the kernels, not part of this ABI) holds the
+                                 step's 64 channels as TWO DENSE 16x16x32 FRAGMENTS SIDE BY SIDE: lane = 16 * g + pixel % 16, slots 0-7 =
+                                 channels 8 g .. + 7, slots 8-15 = channels 32 + 8 g .. + 7 (probe: A (ga 1, sa 0, v 0) = K 16 meets B
+                                 (g 2, slot 0); A (ga 2, sa 5, v 2) = K 42 meets B (g 1, slot 10)) - which is why the kernels form it by
+                                 concatenating the tap's q = 0 and q = 1 activation fragments (conv_v3.hip / conv_v2.h: `bb`).
+                                 tests/test_gpu_anchor.py::test_sparse_second_weight_pass_removes_the_weight_bias gives every input channel
+                                 a distinct mean, so a wrong slot order, index word or k-group map shows as a per-cout mean shift.
+                                 A kernel that takes it runs the second weight pass at ~0.6 of its dense
+                                 cost on 80 % of the low halves' energy                                                                     */
     const void*  w_v2_li;     /* with w_v2_ls: int32 [step][Cout_pad/32][lane 64]: bits [2s+1 : 2s] of the low (high) 16 bits = position, within
                                  its group of four channels, of stored slot s of the first (second) 16-cout half                         */
 } hsidm_conv_desc;

@@ -135,13 +135,15 @@ def test_sparse_second_weight_pass_removes_the_weight_bias(dev, shape):
     (HSIDM_NO_SPARSE_LO switch) and with none: the three kernels stage identical operands, so their outputs differ by the weights alone.
     Per output channel, the MEAN over all pixels of (sparse - dense) - the contribution of the dropped smaller halves - must be well
     below that of (one pass - dense) - the contribution of ALL low halves.  A wrong index word, slot order or k-group mapping would make
-    the sparse pass add an error of the low halves' full size instead."""
+    the sparse pass add an error of the low halves' full size instead - PROVIDED the channels differ in their mean activation: with
+    one mean for all channels the shift sum_k mean_k * lo_k is invariant under any permutation of K, so every input channel gets its
+    own scale here (1 + c % 7: different within every group of four, every 16-channel lane group and both 32-channel fragments)."""
     from hsi_dmgasr_amd import ops
     Ci, Co, H, W = shape
     g = torch.Generator().manual_seed(21)
     B = 4
     w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
-    x = (torch.rand(B, H, W, Ci, generator=g) * 2).to(torch.float16)
+    x = (torch.rand(B, H, W, Ci, generator=g) * (1.0 + (torch.arange(Ci) % 7).float())).to(torch.float16)
     ab = ops.gn_table(torch.stack([torch.ones(B, Ci), torch.zeros(B, Ci)], dim=2).contiguous().to(dev))
     out = {}
     for tag, mode, dense in (("one", "fp16x1", 0), ("dense", "fp16x2", 1), ("sparse", "fp16x2", 0)):
@@ -164,6 +166,19 @@ def test_sparse_second_weight_pass_removes_the_weight_bias(dev, shape):
     assert all_lo > 2e-5, all_lo                                # the low halves are visible in the channel means at all
     assert dropped < 0.6 * all_lo, (dropped, all_lo)
     assert rel_err(out["sparse"].numpy(), out["dense"].numpy()) < 3e-4
+    # ... and the shift is the one a host model of the 2:4 rule predicts: per cout, the mean of conv(silu(x), the low halves the rule
+    # drops - of every four consecutive input channels per cout and tap the two of smaller magnitude).  An operand-mapping error makes
+    # the measured shift uncorrelated with the prediction (|got - pred| ~ 1.4 |pred|).
+    lo = (w - w.to(torch.float16).float()).double()                                        # [Co][Ci][3][3]
+    grp = lo.permute(0, 2, 3, 1).reshape(Co, 3, 3, Ci // 4, 4)
+    keep = torch.zeros_like(grp).scatter_(4, grp.abs().topk(2, dim=4).indices, 1.0)
+    lo_drop = (grp * (1.0 - keep)).reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    act = F.silu(x.double()).permute(0, 3, 1, 2)
+    pred = F.conv2d(act, lo_drop, padding=1).mean(dim=(0, 2, 3))                           # dense - sparse, per cout
+    got = (out["dense"] - out["sparse"]).mean(dim=(0, 1, 2))
+    miss = float((got - pred).abs().mean() / pred.abs().mean())
+    log_err("sparse_lo_mean_shift_vs_host_model_%dx%d" % (Ci, Co), "fp16x2", miss)
+    assert miss < 0.5, miss
 
 
 @pytest.mark.parametrize("shape", [(64, 128, 64, 2, 32, 48), (64, 64, 0, 3, 16, 16), (128, 64, 8, 2, 32, 32)],

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libhsidm.so does not export %s" % name
     assert declared - {"hsidm_error_string"} == set(_lib.SIGNATURES), "ctypes table out of sync with hsidm.h"
-    assert _lib.lib().hsidm_version() == 1
+    assert _lib.lib().hsidm_version() == _lib.ABI_VERSION == 2
     assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32 and _lib.lib().hsidm_conv_bk(_lib.F16) == 64
     assert b"invalid" in _lib.lib().hsidm_error_string(-1)
 
@@ -56,7 +56,7 @@ def test_clean_tree_build_produces_a_loadable_library(tmp_path):
     assert sorted(f[:-4] + ".o" for f in srcs) == sorted(os.listdir(tmp_path / "obj"))     # one fresh object per source, nothing else
     L = ctypes.CDLL(str(out))
     L.hsidm_version.restype = ctypes.c_int
-    assert L.hsidm_version() == 1
+    assert L.hsidm_version() == 2
     for name in _lib.SIGNATURES:
         assert hasattr(L, name), "the clean build does not export %s" % name
     assert L.hsidm_conv_bk(_lib.F16) == 64
@@ -395,7 +395,7 @@ def test_package_installs_under_its_import_name(tmp_path):
     assert (build / "hsi_dmgasr_amd" / "libhsidm.so").exists() and (build / "hsi_dmgasr_amd" / "sr3_modules" / "unet.py").exists()
     code = ("import os, sys; assert not any(os.path.abspath(p) == %r for p in sys.path); "
             "import hsi_dmgasr_amd, hsi_dmgasr_amd.sr3_modules.unet as u, hsi_dmgasr_amd._lib as L; "
-            "assert %r in hsi_dmgasr_amd.__file__ and L.lib().hsidm_version() == 1; "
+            "assert %r in hsi_dmgasr_amd.__file__ and L.lib().hsidm_version() == L.ABI_VERSION; "
             "print(u.UNet(inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1, image_size=16).precision)") % (ROOT, str(build))
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     env["PYTHONPATH"] = str(build)
