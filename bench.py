@@ -19,12 +19,13 @@ headline mode's worst case over the reference-chain fixtures).  Everything else 
 roofline row, and with --detail the other precision modes, small batches, the group autoencoder, the training step and the
 1000-step reference chains - goes to the side file `bench_detail.json` (--detail-out), never to stdout.
 
-The headline precision mode is "fp16" (fp16 storage and MFMA operands, hi + 2:4-sparse lo weights on the two high-resolution
-levels; the four steps of a chain whose update has an error gain >= 0.5 run on the fp32-mode kernels).  Those four steps are
-the FIRST four of a chain: the warm-up (>= 6 steps: both modes' eager step and graph capture) consumes them, so a timed window
-shorter than the rest of the chain (`--steps` < ~990, e.g. the driver's --steps 20) contains NONE of them.  The line says how
-many it contained (`config.fp32_mode_steps_in_window`), times the fp32-mode graph separately and reports the per-chain mix
-(996 fp16-mode + 4 fp32-mode steps) as `config.value_chain_mix` beside the measured `value`.
+The headline precision mode is "fp16" (precision.py: fp16 storage and MFMA operands, ONE weight pass with the weights dithered
+over the chain's steps so that their rounding averages out instead of biasing the chain; the eight steps of a chain whose update
+has an error gain >= 1/4 run on the fp32 kernel set).  Those eight steps are the FIRST eight of a chain: the warm-up (>= 16 steps:
+every kernel set's eager step and graph capture) consumes them, so a timed window shorter than the rest of the chain (`--steps`
+< ~980, e.g. the driver's --steps 20) contains NONE of them.  The line says how many it contained
+(`config.fp32_mode_steps_in_window`), times the fp32-set graph separately and reports the per-chain mix (992 fp16-set + 8
+fp32-set steps) as `config.value_chain_mix` beside the measured `value`.
 """
 import argparse
 import json
@@ -45,8 +46,8 @@ GROUPS = 5                 # CAVE: 31 bands, n_subs=8, n_ovls=2 -> 5 spectral gr
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, bf16 and fp16 alike, MI355X_MICROARCH.md
 HEADLINE = "fp16"                # the fastest mode that meets north_star's tolerance (see `parity`)
 DTYPE = {"bf16": "bf16 storage and MFMA operands (outside north_star's tolerance: experimental)",
-         "fp16": "fp16 storage and MFMA operands; hi + 2:4-sparse lo fp16 weights on the Cout<=128 layers; the 4 steps of a chain with "
-                 "update gain >= 0.5 on the fp32-mode kernels",
+         "fp16": "fp16 storage and MFMA operands, one weight pass; weights dithered over the chain's steps (fp16(w + d[k%4] ulp): the weight "
+                 "rounding averages out instead of biasing the chain); the 8 steps of a chain with update gain >= 1/4 on the fp32 kernel set",
          "fp16x1": "fp16 (one weight pass)", "fp16x2": "fp16 (hi+lo fp16 weights wherever a kernel takes them)",
          "fp32": "fp32 storage, every product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi)"}
 HBM_PEAK_GBPS = 8000.0           # HBM3E spec (6290 measured by a streaming read), MI355X_MICROARCH.md
@@ -672,9 +673,11 @@ def main():
 
     allgather_ms = None
     with torch.no_grad():
-        # >= 6: the chain's first four steps run in the fp32 mode (eager step, graph capture, two replays), then the fp16 mode's eager
-        # step and its capture - every later step, timed or not, is a graph replay of one of the two modes
-        n_warm = max(args.warmup, 6)
+        # the chain's first steps run on the fp32 kernel set (eager step, graph capture, replays), then every dither phase of the fp16
+        # set takes an eager step and a capture: behind WARM_MIN steps every step, timed or not, is a graph replay
+        from hsi_dmgasr_amd.precision import family
+        n_hi = sum(1 for m in run.modes if family(m) != family(run.modes[-1]))
+        n_warm = max(args.warmup, n_hi + 2 * len({m for m in run.modes if family(m) == family(run.modes[-1])}))
         for _ in range(n_warm):
             run.step()
         torch.cuda.synchronize()
@@ -701,12 +704,12 @@ def main():
         # steps of the timed window that ran in another mode than the chain's base mode (the precision schedule's fp32-mode steps
         # sit at the START of each chain: a window shorter than the rest of the chain has none), and the per-chain mix
         T = run.T
-        base_mode = run.modes[-1]
-        n_other = sum(1 for k in range(n_warm, n_warm + args.steps) if run.modes[k % T] != base_mode)
-        per_chain_other = sum(1 for m in run.modes if m != base_mode)
+        base_mode = family(run.modes[-1])
+        n_other = sum(1 for k in range(n_warm, n_warm + args.steps) if family(run.modes[k % T]) != base_mode)
+        per_chain_other = n_hi
         mix = None
         if per_chain_other and rank == 0:
-            other = next(m for m in run.modes if m != base_mode)
+            other = next(m for m in run.modes if family(m) != base_mode)
             t_other = timed_mode_replays(run, other, 8)
             if t_other is not None and args.steps > n_other:
                 t_base = (dt * 1e3 - n_other * t_other) / (args.steps - n_other)
@@ -732,7 +735,7 @@ def main():
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(run, batch, mode=args.precision)
             # (fp16 mode: launches with hi + lo weights issue 1.5 matrix passes per product; `achieved` counts the algorithmic FLOPs once)
-            roof["mfma_passes_per_product"] = "1.5 on the Cout<=128 layers (hi + 2:4-sparse lo), 1 elsewhere" if args.precision == "fp16" else (2 if args.precision == "fp16x2" else 1)
+            roof["mfma_passes_per_product"] = 2 if args.precision == "fp16x2" else 1
             roof["traffic_source"] = "profiles/hbm_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2*FETCH+WRITE, gfx950)" % args.precision
             # the whole step against the same roof: SURVEY 8(d)'s 92.35 GFLOP per latent and step over the measured step time
             ms_base = mix["ms_per_step_base_mode"] if mix else dt / args.steps * 1e3
@@ -745,7 +748,7 @@ def main():
         with torch.no_grad():
             r = gd.make_run(cond, wrap=True, precision=prec)
             n = max(10, min(50, args.steps // 20))
-            for _ in range(6):                                  # (both modes of a scheduled chain captured before the clock starts)
+            for _ in range(n_warm):                             # (every kernel set of a scheduled chain captured before the clock starts)
                 r.step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -791,7 +794,7 @@ def main():
             for pp in (8, 1):
                 b = pp * GROUPS
                 r = gd.make_run(cond[:b].contiguous(), wrap=True)
-                for _ in range(6):                              # the four fp32-mode steps of the chain's start, then the fp16 mode's eager step and capture
+                for _ in range(n_warm):                         # the fp32-set steps of the chain's start, then the fp16 set's eager steps and captures
                     r.step()
                 torch.cuda.synchronize()
                 n = max(50, min(300, args.steps))
@@ -801,7 +804,7 @@ def main():
                 torch.cuda.synchronize()
                 d = time.perf_counter() - t0
                 small["%d_latents" % b] = dict(value=n * b / d, unit="denoise-steps*batch/s", ms_per_step=d / n * 1e3, steps=n,
-                                               note="steady-state fp16-mode steps (behind the chain's first six)")
+                                               note="steady-state fp16-mode steps (behind the chain's warm-up)")
                 del r
         log('small batches done')
     gae_rec = gae_chik = None

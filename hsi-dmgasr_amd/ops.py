@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, XF_AFFINE, XF_AFFINE_SILU, XF_NONE  # noqa: F401 (re-exported)
-from .precision import wide_weights
+from .precision import dither_offset, dither_phase, wide_weights
 
 
 # ------------------------------------------------------------------------------------------- packing
@@ -134,9 +134,20 @@ class PackedConv:
         self.bias = None if b is None else b.to(dev).contiguous()
         # fp16 mode: does this layer multiply by hi + lo weights on the persistent kernels too (precision.wide_weights)?
         self.wide = (self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)) or self.prec == _lib.F32X3
+        # one-pass layouts of a dithered kernel set ("fp16d<k>", precision.py): step k of a chain multiplies by fp16(w + d_k * ulp(w)), the
+        # K offsets d_k spread over (-1/2, 1/2) ulp - the mean weight over K steps is w to 1 / (2K) ulp, so the weight rounding stops
+        # being a bias of the chain.  (Layers that carry hi + lo weights are not dithered: the low halves are the correction.)
+        ph = dither_phase(precision)
+        dith = ph is not None and not self.wide
+
+        def rnd(t):
+            if not dith:
+                return t.to(et).contiguous()
+            ulp = torch.exp2(torch.floor(torch.log2(t.abs().clamp_min(2.0 ** -14))) - 10.0)      # fp16: 10 stored significand bits; subnormals share 2^-24
+            return (t + dither_offset(*ph) * ulp).to(et).contiguous()
         for name in ("w_v2", "w_up4", "w_dn4"):
             t = lay[name]
-            hi = None if t is None else t.to(et).contiguous()
+            hi = None if t is None else rnd(t)
             setattr(self, name, hi)
             setattr(self, name + "_lo", (t - hi.float()).to(et).contiguous() if (hi is not None and self.wide) else None)
         # fp16 hi + lo layers on the plain 3x3 schedule: the low halves once more, 2:4 structured-sparse, for the kernels that run the

@@ -6,28 +6,30 @@ PUBLIC modes (both meet the reference's tolerance - 1e-3 relative, 0.01 dB, 0.00
            accumulated in fp32 on the same MFMA pipeline (~1e-5 relative; the fp32 parity gate);
   "fp16" : the package default, a POLICY rather than one kernel set: each UNet evaluation runs on the cheapest kernel set that
            keeps the caller's output inside the tolerance, decided by the GAIN with which the evaluation's error reaches that output:
-             - the fp16 kernel set (fp16 activations and MFMA operands - 11-bit significands, the same kernels and rate as bf16,
-               stores saturate at +-65504; the convolutions of the two high-resolution levels, Cout <= 128, multiply by fp16
-               hi + lo WEIGHTS: the weight rounding is the one error of a 16-bit pipeline that is the same in every step of a chain,
-               i.e. a bias, not noise - DESIGN.md section 5, tests/precision_emul.py) where the gain is below WIDE_STEP_GAIN;
+             - the fp16 kernel sets "fp16d0" ... "fp16d3" (fp16 activations and MFMA operands - 11-bit significands, the same
+               kernels and rate as bf16, stores saturate at +-65504 - ONE weight pass, the weights DITHERED over the steps of the
+               chain: step k multiplies by fp16(w + d[k % 4] ulp(w)).  The weight rounding is the one error of a 16-bit pipeline
+               that is the same in every step of a chain, i.e. a bias, not noise - DESIGN.md section 5, tests/precision_emul.py; the
+               dither turns it into noise that averages out over four steps, without the second weight pass rounds 3-4 paid for it)
+               where the gain is below WIDE_STEP_GAIN;
              - the "fp32" kernel set otherwise: the steps of a reverse chain whose update feeds the denoiser's error into the
-               state with a gain >= WIDE_STEP_GAIN (step_precision), and every BARE module call - UNet.forward, Block.forward,
-               ResnetBlock.forward ... outside a sampler: the output is the result, gain 1 (forward_precision).  One forward of
-               the UNet on the fp16 kernel set measures 1.07e-3 ... 1.16e-3 against the reference, i.e. outside the tolerance;
-               the reverse chain multiplies it by 0.45 or less wherever that set runs.
+               state with a gain >= WIDE_STEP_GAIN (step_precision: eight steps per chain on the reference's cosine schedule), and
+               every BARE module call - UNet.forward, Block.forward, ResnetBlock.forward ... outside a sampler: the output is the
+               result, gain 1 (forward_precision).  One forward of the UNet on an fp16 kernel set measures 1.1e-3 ... 1.4e-3 against
+               the reference, i.e. outside the tolerance; the reverse chain multiplies it by 0.24 or less wherever such a set runs.
 
 EXPERIMENTAL kernel sets (A/B forms; outside the tolerance or redundant; refused unless allow_experimental() / HSIDM_EXPERIMENTAL=1):
 
   "bf16"   : bf16 activations and MFMA operands (8-bit significands): 7.9e-3 on the reference chains, 8x outside the tolerance;
              kept as the fastest form of the training step and as a throughput reference (BASELINE configs[1] names bf16);
-  "fp16x1" / "fp16x2" : the fp16 policy with the second weight pass nowhere / wherever a kernel takes it.
+  "fp16x1" / "fp16x2" : fp16 with plainly rounded weights in one pass / with hi + lo weights (the second pass 2:4-sparse on
+             v_smfmac where a kernel takes it) wherever a kernel takes them; inside kernels_as_named() the name "fp16" is round 4's
+             set, hi + lo weights on the Cout <= 128 layers.
 
 The gain of a reverse step is |c_x0 * sqrt(1/acp_t - 1)| - the coefficient of eps in x_{t-1} (reference diffusion.py:142-149:
 posterior_mean_coef1 * sqrt_recipm1_alphas_cumprod).  With the reference's cosine schedule it is 31.6 at the first step of EVERY
 chain (beta is clamped at 0.999 there, diffusion.py:46) and 1.50 / 0.83 / 0.58 / 0.45 ... at the following steps whatever the chain
-length (near t = T the schedule's alpha-bar is ~ (T - t)^2): four steps per chain - four in the shipped 20-step validation chain,
-four in the benchmark's thousand.  (tests/precision_emul.py, key `is`: on the 20-step chain the first step alone carries 18 % of
-the fp16 kernel set's deviation from the reference, the first two 21 %, the first six 39 %.)
+length (near t = T the schedule's alpha-bar is ~ (T - t)^2).
 """
 import contextlib
 import os
@@ -51,7 +53,7 @@ def allow_experimental(flag=True):
 
 
 def _known(p):
-    if p in MODES:
+    if p in MODES or dither_phase(p) is not None:
         return True
     if p in EXPERIMENTAL_MODES:
         if not _experimental:
@@ -80,13 +82,50 @@ def resolve_precision(p):
     return p
 
 
-WIDE_STEP_GAIN = 0.5
+# Steps whose update passes a quarter or more of the denoiser's output error on to the state run on the fp32 kernel set: with the
+# reference's cosine schedule the gains of a chain's steps are 31.6, 1.50, 0.83, 0.58, 0.45, 0.37, 0.31, 0.27 | 0.24, 0.21 ... whatever
+# its length (~ 1.5 / k behind the first), i.e. EIGHT steps per chain (0.29 ms per step averaged over the metric's 1000-step chain).
+# The chain's deviation is made where the gain is large; emulated on the T = 20 reference chains (tests/precision_emul.py, one-pass
+# dithered weights, synth:0 / orth:1): 4 steps 6.8e-4 / 7.7e-4, 6 steps 5.4e-4 / 6.1e-4, 8 steps 4.9e-4 / 5.3e-4 (dSAM 4e-6 / 2.7e-4 deg);
+# hi + 2:4-sparse lo weights with 4 steps (round 4's policy) 5.5e-4 / 5.7e-4.  Each further step costs 0.16 % of a 1000-step chain.
+WIDE_STEP_GAIN = 0.25
+
+# Weight dither of the "fp16" policy's chain steps.  The fp16 rounding of a WEIGHT is the one error of a 16-bit pipeline that repeats
+# in every step of a chain - a bias, which is what moves the quality indices.  The fp16 kernel set of chain
+# step k therefore multiplies by  fp16(w + d[k % K] * ulp(w))  with DITHER_K offsets d spread over (-1/2, 1/2) (bit-reversed order):
+# over K consecutive steps every weight is rounded up in about frac * K of them (frac: its position in its rounding interval), so
+# the MEAN weight the chain sees is w to 1 / (2 K) ulp.  Kernel-set names: "fp16d0" ... "fp16d<K-1>" (produced by step_precision
+# only; one packed copy of the 16-bit weights and one captured graph per phase).  HSIDM_DITHER_K=0: off (A/B: plain rounding).
+DITHER_K = int(os.environ.get("HSIDM_DITHER_K", "4"))
 
 
-def step_precision(p, eps_gain):
-    """Mode of ONE reverse step of a chain run in mode p, given the step's gain on the denoiser's output (see the module docstring)."""
+def dither_phase(p):
+    """(phase, K) of a dithered kernel-set name "fp16d<phase>", else None."""
+    if isinstance(p, str) and p.startswith("fp16d") and p[5:].isdigit():
+        return int(p[5:]), DITHER_K
+    return None
+
+
+def dither_offset(phase, K):
+    """Offset (in ulp of the weight) of phase `phase` of K: ((bit-reversed phase) + 1/2) / K - 1/2."""
+    if K & (K - 1) == 0:
+        bits = max(1, (K - 1).bit_length())
+        phase = int(format(phase % K, "0%db" % bits)[::-1], 2)
+    return (phase % K + 0.5) / K - 0.5
+
+
+def family(p):
+    """Mode a kernel-set name belongs to ("fp16d2" -> "fp16")."""
+    return "fp16" if dither_phase(p) is not None else p
+
+
+def step_precision(p, eps_gain, step=0):
+    """Kernel set of ONE reverse step (the step-th of its chain) of a chain run in mode p, given the step's gain on the denoiser's
+    output (see the module docstring)."""
     if p in ("fp16", "fp16x1", "fp16x2") and eps_gain >= WIDE_STEP_GAIN and not os.environ.get("HSIDM_NO_STEP_SCHEDULE"):
         return "fp32"
+    if p == "fp16" and DITHER_K > 1:
+        return "fp16d%d" % (step % DITHER_K)
     return p
 
 
@@ -146,9 +185,15 @@ def _policy(exp, cout, cin, ksize):
     return bool(ev(ast.parse(exp, mode="eval")))
 
 
+DITHER_WIDE_COUT = int(os.environ.get("HSIDM_DITHER_WIDE_COUT", "0"))
+
+
 def wide_weights(p, cout, cin=0, ksize=3):
     """Does a convolution (cout x cin x ksize x ksize) carry hi + lo weights in mode p (second MFMA pass)?"""
     exp = os.environ.get("HSIDM_WIDE_POLICY")          # diagnostic (tools/policy_probe.py): comparisons over cout, cin, ksize
     if exp and p == "fp16":
         return _policy(exp, cout, cin, ksize)
+    # ("fp16d<k>": the dithered sets carry one-pass weights everywhere unless DITHER_WIDE_COUT keeps hi + lo on the narrowest layers)
+    if dither_phase(p) is not None:
+        return cout <= DITHER_WIDE_COUT
     return p == "fp16x2" or (p == "fp16" and cout <= 128)

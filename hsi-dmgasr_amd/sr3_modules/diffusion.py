@@ -90,8 +90,10 @@ class ReverseRun:
         # precision schedule along the chain (precision.step_precision): mode of the step at t = T-1-k, k = 0..T-1; the host
         # mirrors the device-side step counter (steps_done), so the choice costs no read-back
         base = resolve_precision(precision if precision is not None else getattr(gd.denoise_fn, "precision", None)) if self.fused else precision
-        self.modes = [step_precision(base, float(gd._run_eps_gain[T - 1 - k])) if self.fused else base for k in range(T)]
+        # (the "fp16" policy: high-gain steps on the fp32 kernel set, the others on the fp16 set with the weight dither of phase k % K)
+        self.modes = [step_precision(base, float(gd._run_eps_gain[T - 1 - k]), k) if self.fused else base for k in range(T)]
         self.graphs, self._eager_done = {}, set()
+        self._pool = None                  # one private memory pool for every captured graph of this run (replays are serial)
         self.steps_done = 0
 
     @property
@@ -123,7 +125,11 @@ class ReverseRun:
             if g is None:
                 torch.cuda.synchronize()
                 g = self.graphs[mode] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()
+                # (the kernel sets of a chain - fp32 + the K dither phases of the fp16 set - replay one at a time on one stream and
+                # leave nothing behind but x_t, which lives outside the pool: they share their activation memory)
+                with torch.cuda.graph(g, pool=self._pool):
                     self._enqueue(mode)                  # recorded, not executed
             g.replay()
         self.steps_done += 1

@@ -222,7 +222,7 @@ class ResnetBlock(_HipModule):
                 # (conv_v3.hip, PROJ) - no second pass over x for a separate GEMM, no round trip of its result through HBM
                 # (every condition the dispatch checks is checked HERE first - api.hip, v3_proj - so a refused offer never costs a
                 # second GroupNorm table or dead packed layouts)
-                if precision in ("fp16", "fp16x2") and h.shape[3] == 64 and H % 16 == 0 and W % 16 == 0 and \
+                if h.dtype == torch.float16 and h.shape[3] == 64 and H % 16 == 0 and W % 16 == 0 and \
                         (x0.shape[3] + (0 if x1 is None else x1.shape[3])) % 8 == 0 and \
                         wide_weights(precision, h.shape[3], h.shape[3], 3) and ops.use_fused_proj():
                     out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, fused_only=True)

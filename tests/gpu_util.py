@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # tolerances (relative Frobenius error vs the fp32 CPU oracle)
 TOL = {"fp32": 1e-3,    # north_star: 1e-3 relative for the fp32 path (measured ~1e-5)
        "fp16": 1e-3, "fp16x1": 1.5e-3, "fp16x2": 1e-3,     # fp16 modes: per op ~3e-4 (tests/test_gpu_anchor.py holds each kernel to 6e-4)
+       "fp16d0": 1.5e-3, "fp16d1": 1.5e-3, "fp16d2": 1.5e-3, "fp16d3": 1.5e-3,   # the dithered one-pass sets of the "fp16" policy's chain steps: a
+       # single forward sees weights up to 7/8 ulp off (plain rounding: 1/2) - per-op regression gates; the policy's claim is the chain's
        "bf16": 4e-2}    # bf16 operands: a regression bound per op (measured 2e-3 ... 9e-3), not a north-star claim
 
 

@@ -90,6 +90,9 @@ class Mode:
                 else:
                     self.lvl[k] = [int(u) for u in lv.split("+")]
             setattr(self, k, v)
+        # wd=4c128: layers the `w` rule leaves at one pass (e.g. w=x2s@c64 -> couts 65 ...) and with at most 128 output channels get
+        # one-pass weights DITHERED over the chain's steps (K = 4 offsets; see w=dK)
+        self.wd_k, self.wd_cmax = (int(kv["wd"].split("c")[0]), int(kv["wd"].split("c")[1])) if "wd" in kv else (0, 0)
         self.gn = kv.get("gn", "fp32")
         self.sk = kv.get("sk", "sSuhra")
         self.wl = kv["wl"].split("+") if "wl" in kv else None      # wl=final+ups.18: hi + lo weights on these units only
@@ -125,9 +128,11 @@ class Mode:
         return rnd(x, self.t)
 
     def weight(self, w, hw):
-        if self.wl is not None:
-            return split2(w, self.t) if any(self.cur.startswith(q) for q in self.wl) else rnd(w, self.t)
+        if self.wl is not None and any(self.cur.startswith(q) for q in self.wl):     # wl=final_conv+ups.18: hi + lo weights on these units, the other rules elsewhere
+            return split2(w, self.t)
         if self.cout_max is not None and (w.shape[0] > self.cout_max or (self.cin_max is not None and w.shape[1] > self.cin_max)):
+            if self.wd_k and w.shape[0] <= self.wd_cmax:
+                return self._dither(w, self.wd_k)
             return rnd(w, self.t)
         if self.w == "fp32" and self._ovr("w", hw):
             return w
@@ -146,12 +151,14 @@ class Mode:
         if self.w == "ed" and self._ovr("w", hw):
             return round_zero_sum(w, self.t)
         if self.w.startswith("d") and self._ovr("w", hw):
-            K = int(self.w[1:])
-            ph = int(format(self.phase % K, "0%db" % max(1, (K - 1).bit_length()))[::-1], 2) if K & (K - 1) == 0 else self.phase % K
-            mant = 10 if self.t == "fp16" else 7
-            ulp = torch.exp2(torch.floor(torch.log2(w.abs().clamp_min(2.0 ** -14))) - mant)
-            return rnd(w + ((ph + 0.5) / K - 0.5) * ulp, self.t)
+            return self._dither(w, int(self.w[1:]))
         return rnd(w, self.t)
+
+    def _dither(self, w, K):
+        ph = int(format(self.phase % K, "0%db" % max(1, (K - 1).bit_length()))[::-1], 2) if K & (K - 1) == 0 else self.phase % K
+        mant = 10 if self.t == "fp16" else 7
+        ulp = torch.exp2(torch.floor(torch.log2(w.abs().clamp_min(2.0 ** -14))) - mant)
+        return rnd(w + ((ph + 0.5) / K - 0.5) * ulp, self.t)
 
     def conv_in(self, x):
         """What a convolution reads of a stored tensor: with st=x2 (hi + lo planes) only the hi plane."""

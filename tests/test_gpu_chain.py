@@ -173,8 +173,8 @@ def test_T20_chain_ab_forms_of_the_fp16_mode(dev, prec):
 
 
 def test_benchmark_batch_chain_against_the_reference_run(dev):
-    """The BENCHMARK's kernel dispatch - 240 latents per GPU: 256-cout items on 8 waves, multi-round persistent loops, the sparse second
-    weight pass over 30 rounds per launch, XCD tile remap - against the reference: the orthogonal-weights T = 20 chain (five group
+    """The BENCHMARK's kernel dispatch - 240 latents per GPU: 256-cout items on 8 waves, multi-round persistent loops (30 rounds per
+    launch on the 128x128 level), XCD tile remap, the four dithered weight sets - against the reference: the orthogonal-weights T = 20 chain (five group
     latents by the imported reference) replicated 48 times into one batch of 240 in the headline mode; EVERY copy is held to north_star's
     1e-3 on the latents, and the copies agree with each other (the path has no cross-sample arithmetic)."""
     from hsi_dmgasr_amd import ops
@@ -197,21 +197,22 @@ def test_benchmark_batch_chain_against_the_reference_run(dev):
     try:
         run = gd.make_run(z, x_T=x_T, noise=noise, precision="fp16")
         with torch.no_grad():
-            run.step()                                                                    # (the first step: fp32 mode, eager - probed)
-            for _ in range(4):
+            n_hi = sum(1 for m in run.modes if m == "fp32")
+            assert n_hi == 8 and run.modes[n_hi + 1] == "fp16d1"
+            for _ in range(n_hi + 1):                                                     # the eight fp32-set steps and the first fp16-set one
                 run.step()
             torch.cuda.synchronize()
             del recs[:]
-            run2_labels_from = len(recs)
-            gd.use_graph, keep = False, gd.use_graph                                      # one eager fp16 step under the probe: which kernels the batch takes
+            gd.use_graph, keep = False, gd.use_graph                                      # one eager fp16-set step under the probe: which kernels the batch takes
             try:
                 run.step()
             finally:
                 gd.use_graph = keep
             labels = sorted({r["kernel"] for r in recs})
-            for _ in range(steps - 6):
+            for _ in range(steps - n_hi - 2):
                 run.step()
             torch.cuda.synchronize()
+            assert run.steps_done == steps
     finally:
         ops.set_conv_probe(None)
     for need in ("conv_v2 bn256 8x16", "conv_v3 bn64", "up4", "dn4", "conv1x1_g"):
@@ -329,38 +330,38 @@ def test_graph_replayed_philox_chain_at_batch_40_with_wrap(dev):
 
 
 def test_precision_schedule_runs_the_high_gain_steps_on_the_fp32_kernels(dev):
-    """precision.step_precision in the reverse loop: a chain in the fp16 mode runs its first four steps (update gain 31.6, 1.5, 0.83,
-    0.58 on the cosine schedule) in the fp32 mode - after those four steps its state is BIT-IDENTICAL to a chain run in the fp32 mode on
-    the same Philox noise - and the rest on the fp16 kernels (the states then differ); one captured graph per mode; the schedule is a
-    property of the chain's position, so it repeats after a wrap."""
+    """precision.step_precision in the reverse loop: a chain in the "fp16" policy runs its first eight steps (update gain 31.6, 1.5, 0.83,
+    0.58, 0.45, 0.37, 0.31, 0.27 on the cosine schedule) on the fp32 kernel set - after those eight steps its state is BIT-IDENTICAL to a chain run in
+    the fp32 mode on the same Philox noise - and the rest on the fp16 kernels with the weight dither of phase (step % 4) (the states
+    then differ); one captured graph per kernel set, all in one memory pool; the schedule is a property of the chain's position, so
+    it repeats after a wrap."""
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
     u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
                   image_size=16, precision="fp16").to(dev).eval()
     fill_synth(u, "unet_tiny.")
     gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
     gd.set_loss(dev)
-    T = 12
+    T = 20
     gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2), dev)
     gd.noise, gd.seed = "philox", 77
     cond = G(synth_tensor("sched.cond", (3, 3, 16, 16)), dev)
-    a = gd.make_run(cond, wrap=True)                            # fp16 mode (the module's)
+    a = gd.make_run(cond, wrap=True)                            # the module's mode: the "fp16" policy
     b = gd.make_run(cond, wrap=True, precision="fp32")
-    assert a.modes == ["fp32"] * 4 + ["fp16"] * (T - 4) and b.modes == ["fp32"] * T
+    assert a.modes == ["fp32"] * 8 + ["fp16d%d" % (k % 4) for k in range(8, T)] and b.modes == ["fp32"] * T
     with torch.no_grad():
-        for _ in range(4):
+        for _ in range(8):
             a.step(); b.step()
         torch.cuda.synchronize()
         assert torch.equal(a.x, b.x)
-        for _ in range(T - 4):
+        for _ in range(T - 8):
             a.step(); b.step()
         torch.cuda.synchronize()
         assert not torch.equal(a.x, b.x) and rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 2e-3
-        assert set(a.graphs) == {"fp16", "fp32"} and a.graph is a.graphs["fp16"] and int(a.t_ptr.item()) == T - 1      # wrapped
-        xa, xb = a.x.clone(), b.x.clone()
-        for _ in range(4):                                      # second lap: the four high-gain steps again on the fp32 kernels (graph replays)
+        assert set(a.graphs) == {"fp16d0", "fp16d1", "fp16d2", "fp16d3", "fp32"} and a.graph is a.graphs["fp16d3"] and int(a.t_ptr.item()) == T - 1      # wrapped
+        for _ in range(8):                                      # second lap: the eight high-gain steps again on the fp32 kernels (graph replays)
             a.step(); b.step()
         torch.cuda.synchronize()
-    assert torch.isfinite(a.x).all() and a.steps_done == T + 4
+    assert torch.isfinite(a.x).all() and a.steps_done == T + 8
 
 
 def test_sharded_driver_under_an_rccl_group_of_one(dev):

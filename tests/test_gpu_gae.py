@@ -28,7 +28,10 @@ GAE_TOL = {"fp32": None, "fp16": 1e-3}
 
 def test_gae_refuses_bf16(dev):
     from hsi_dmgasr_amd import gae
-    m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision="bf16").to(dev).eval()
+    with pytest.raises(ValueError, match="fp32"):           # at construction ...
+        gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64, precision="bf16")
+    m = gae.GAE(gae.Encoder, gae.Decoder, n_subs=8, n_ovls=2, n_colors=31, n_feats=64).to(dev).eval()
+    m.precision = "bf16"                                    # ... and per call (the attribute is assignable)
     x = torch.rand(1, 31, 16, 16, device=dev)
     with pytest.raises(ValueError, match="fp32"):
         m.encode(x)

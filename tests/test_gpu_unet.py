@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 # reverse chain at steps whose gain is <= 0.45 (seven reference chains at 1e-3 / 0.01 dB / 0.001 deg in tests/test_gpu_chain.py).
 # The bound below is a REGRESSION gate on the kernel set (measured worst x 1.08), used by the kernel-set test only.
 KERNEL_SET_FWD_FP16 = 1.25e-3
-PRECS = ["fp32", "fp16", "bf16"]
+PRECS = ["fp32", "fp16", "fp16d2", "bf16"]      # ("fp16": the hi + lo set; "fp16d2": one of the four dithered one-pass sets the policy's chain steps run)
 
 
 @pytest.fixture(autouse=True)
@@ -224,7 +224,7 @@ def test_unet_forward_per_kernel_set(dev, prec, name):
     """The same four cases on each KERNEL SET by name (regression gates of the sets themselves: the fp16 set's 1.07e-3 ... 1.16e-3
     is why the policy does not hand a bare forward to it; bf16 is experimental)."""
     u, x, gam, want = _unet_case(name, prec, dev)
-    check("unet_%s_kernel_set" % name, prec, u(G(x, dev), G(gam, dev)), want, tol={"fp32": 1e-3, "fp16": KERNEL_SET_FWD_FP16, "bf16": 8e-2}[prec])
+    check("unet_%s_kernel_set" % name, prec, u(G(x, dev), G(gam, dev)), want, tol={"fp32": 1e-3, "fp16": KERNEL_SET_FWD_FP16, "fp16d2": 2e-3, "bf16": 8e-2}[prec])
 
 
 @pytest.mark.public_modes

@@ -422,7 +422,7 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
         P.allow_experimental(was)
     assert P.resolve_precision("bf16") == "bf16"                       # (conftest.py: the suite measures them as regression gates)
     # the "fp16" policy: a chain step by its gain, a bare forward (gain 1) on the fp32 kernel set; named sets stay as named
-    assert P.step_precision("fp16", 0.45) == "fp16" and P.step_precision("fp16", 0.5) == "fp32" and P.step_precision("fp32", 9.0) == "fp32"
+    assert P.step_precision("fp16", 0.24, 7) == "fp16d3" and P.step_precision("fp16", 0.26) == "fp32" and P.step_precision("fp32", 9.0) == "fp32"
     assert P.forward_precision("fp16") == "fp32" and P.forward_precision("fp32") == "fp32" and P.forward_precision("bf16") == "bf16"
     assert P.forward_precision("fp16x1") == "fp16x1"
     with P.kernels_as_named():
@@ -460,24 +460,66 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
 
 
 def test_precision_schedule_along_the_chain():
-    """precision.step_precision: in the fp16 family the steps whose update multiplies the denoiser's output error by >= 0.5 run in
-    the fp32 mode - with the reference's cosine schedule the first FOUR steps of a chain of any length (gains 31.6 - beta clamped at
-    0.999, reference diffusion.py:46 - then 1.50, 0.83, 0.58: near t = T the schedule's alpha-bar is ~ (T - t)^2, whatever T);
-    bf16 and fp32 chains are uniform."""
+    """precision.step_precision: in the "fp16" policy the steps whose update multiplies the denoiser's output error by a quarter or more run on
+    the fp32 kernel set - with the reference's cosine schedule the first EIGHT steps of a chain of any length (gains 31.6 - beta clamped
+    at 0.999, reference diffusion.py:46 - then 1.50, 0.83, 0.58, 0.45, 0.37, 0.31, 0.27 | 0.24: near t = T the schedule's alpha-bar is ~ (T - t)^2,
+    whatever T) - and every other step on the fp16 set with the weight dither of phase (step % K); bf16 and fp32 chains are uniform,
+    the experimental one- / two-pass forms keep their own kernels behind the same eight steps."""
     from hsi_dmgasr_amd import precision
     from hsi_dmgasr_amd.sr3_modules import diffusion
     gd = diffusion.GaussianDiffusion(torch.nn.Identity(), image_size=16, channels=3, conditional=True)
-    for T, wide in ((20, [19, 18, 17, 16]), (1000, [999, 998, 997, 996]), (100, [99, 98, 97, 96])):
+    K = precision.DITHER_K
+    assert K == 4 and precision.WIDE_STEP_GAIN == 0.25
+    for T in (20, 1000, 100):
+        wide = [T - 1 - k for k in range(8)]
         gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2), "cpu")
         gain = gd._run_eps_gain
-        assert gain.shape == (T,) and abs(gain[T - 1] - 31.59) < 0.01
+        assert gain.shape == (T,) and abs(gain[T - 1] - 31.59) < 0.01 and gain[T - 8] > 0.25 > gain[T - 9]
         np.testing.assert_allclose(gain, np.abs(gd.posterior_mean_coef1.double().numpy() * gd.sqrt_recipm1_alphas_cumprod.double().numpy()), rtol=1e-5)
         for mode in ("fp16", "fp16x1", "fp16x2"):
-            assert [t for t in reversed(range(T)) if precision.step_precision(mode, gain[t]) == "fp32"] == wide, (T, mode)
+            assert [t for t in reversed(range(T)) if precision.step_precision(mode, gain[t], T - 1 - t) == "fp32"] == wide, (T, mode)
+        assert [precision.step_precision("fp16", gain[T - 1 - k], k) for k in range(8, 16)] == ["fp16d%d" % (k % K) for k in range(8, 16)]
+        assert all(precision.step_precision("fp16x1", gain[T - 1 - k], k) == "fp16x1" for k in range(8, T))
         for mode in ("bf16", "fp32"):
-            assert all(precision.step_precision(mode, gain[t]) == mode for t in range(T))
+            assert all(precision.step_precision(mode, gain[t], T - 1 - t) == mode for t in range(T))
     gd.set_sampler("ddim", steps=10, eta=0.0)                   # the strided sampler carries its own gains
     assert gd._run_eps_gain.shape == (10,) and gd._run_eps_gain[9] > 1.0
+
+
+def test_weight_dither_of_the_fp16_kernel_sets():
+    """The K = 4 dithered kernel sets "fp16d0" ... "fp16d3" (precision.py; ops.PackedConv): set k packs fp16(w + d_k ulp(w)) with the
+    offsets -3/8, +1/8, -1/8, +3/8 (bit-reversed order); every packed value is one of the weight's two fp16 neighbours, the number of
+    sets that round a weight UP grows with its position inside the rounding interval, and the MEAN over the four sets is within
+    1/8 ulp of the weight (plain rounding: 1/2) - the weight rounding averages out over four consecutive chain steps.  The sets are
+    one-pass (no low halves), zero weights stay zero, and the names resolve like any kernel-set name."""
+    from hsi_dmgasr_amd import _lib, ops, precision as P
+    assert [P.dither_offset(k, 4) for k in range(4)] == [-0.375, 0.125, -0.125, 0.375]
+    assert P.dither_phase("fp16d2") == (2, 4) and P.dither_phase("fp16") is None and P.family("fp16d3") == "fp16" and P.family("fp32") == "fp32"
+    assert P.resolve_precision("fp16d1") == "fp16d1" and _lib.prec_id("fp16d1") == _lib.F16 and not P.wide_weights("fp16d1", 64)
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    w[0, 0] = 0.0
+    ref = ops.pack_layouts(w, "fp16")[0]["w_v2"].double()
+    packs = [ops.PackedConv(w, None, "fp16d%d" % k, fold_ups=True, fold_dn=True) for k in range(4)]
+    for pk in packs:
+        assert pk.w_v2.dtype == torch.float16 and pk.w_v2_lo is None and pk.w_v2_ls is None and pk.w_up4_lo is None and pk.w_dn4 is not None
+    sets = torch.stack([pk.w_v2.double() for pk in packs])                         # [4, ...]
+    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -14))) - 10.0)
+    lo_n = torch.floor(ref / ulp) * ulp
+    frac = (ref - lo_n) / ulp                                                      # position inside the rounding interval [0, 1)
+    # (weights within an ulp above a power of two may land half an ulp BELOW it - the spacing halves there: excluded from the strict checks)
+    edge = (ref.abs() - torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -14))))) < ulp
+    assert float(edge.double().mean()) < 0.01 and bool(((sets - ref).abs() < ulp)[:, (ref != 0)].all())
+    ok = ~edge
+    assert bool(((sets == lo_n) | (sets == lo_n + ulp))[:, ok].all())
+    ups = (sets > lo_n).sum(dim=0).double()
+    assert float((ups - 4 * frac)[ok].abs().max()) <= 0.5 + 1e-9                   # round(4 frac) of the four sets round up
+    mean_err = ((sets.mean(dim=0) - ref).abs() / ulp)
+    rn_err = ((ref.to(torch.float16).double() - ref).abs() / ulp)
+    assert float(mean_err[ok].max()) <= 0.125 + 1e-9 and float(rn_err.max()) > 0.49
+    assert bool((sets[:, ref == 0] == 0).all())
+    # a layer that keeps hi + lo weights in a dithered set (HSIDM_DITHER_WIDE_COUT) would not be dithered: the low halves are the correction
+    assert float((packs[1].w_hi.double() - ops.PackedConv(w, None, "fp16").w_hi.double()).abs().max()) == 0.0    # (the LDS-tiled fallback's hi + lo order)
 
 
 def test_sparse_low_half_packing_matches_the_measured_operand_semantics():
