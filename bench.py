@@ -202,7 +202,7 @@ def chain_parity(dev, modes=("fp16",), long_modes=(), orth_net=None):
 
     out = {"fixtures": "the reference's validation iteration (one CAVE image, 5 group latents 3x128x128, 97.8M UNet, pretrained CAVE "
                        "autoencoder, cosine schedule) as run by the imported reference: weights {synthetic, reference orthogonal init} x "
-                       "two draws at T=20, two 1000-step chains (one per weight set), and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
+                       "three draws at T=20 (the last two generated after round 5's precision policy was fixed), two 1000-step chains (one per weight set; --parity-long / --detail), and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
                        "BASELINE configs[2]; every 4th band of its cube compared); bounds 1e-3 relative / 0.01 dB / 0.001 deg (BASELINE.json north_star)"}
     per = {p: {} for p in modes}
     with torch.no_grad():
@@ -231,20 +231,41 @@ def chain_parity(dev, modes=("fp16",), long_modes=(), orth_net=None):
                 e_lat = float((lat[0] - ref_lat).double().norm() / ref_lat.double().norm())
                 ys = y[:, ::4] if chi else y
                 e_y = float((ys - ref_y).double().norm() / ref_y.double().norm())
-                per[prec][":".join(str(v) for v in fx).replace(":%d:%d" % (draw, steps), ":n%d:T%d" % (draw, steps))] = dict(
-                    latents_rel_err=e_lat, cube_rel_err=e_y, dPSNR_dB=abs(float(q[0]) - q_ref[0]), dSAM_deg=abs(float(q[1]) - q_ref[1]))
+                row = dict(latents_rel_err=e_lat, cube_rel_err=e_y, dPSNR_dB=abs(float(q[0]) - q_ref[0]), dSAM_deg=abs(float(q[1]) - q_ref[1]))
+                if not chi:     # (the Chikusei fixture stores a quarter of the reference's cube: no per-pixel comparison of the SAM support)
+                    row["sam_support_flips"], row["dSAM_common_support_deg"] = sam_support(truth, y, ref_y)
+                per[prec][":".join(str(v) for v in fx).replace(":%d:%d" % (draw, steps), ":n%d:T%d" % (draw, steps))] = row
             del noise, gd
     for prec in modes:
         rows = per[prec]
         if not rows:
             continue
         worst = {k: max(r[k] for r in rows.values()) for k in ("latents_rel_err", "cube_rel_err", "dPSNR_dB", "dSAM_deg")}
-        out[prec] = dict(worst, fixtures=rows, n_fixtures=len(rows),
-                         meets_north_star=bool(worst["latents_rel_err"] <= 1e-3 and worst["cube_rel_err"] <= 1e-3 and
-                                               worst["dPSNR_dB"] <= 0.01 and worst["dSAM_deg"] <= 1e-3))
+        cont = bool(worst["latents_rel_err"] <= 1e-3 and worst["cube_rel_err"] <= 1e-3 and worst["dPSNR_dB"] <= 0.01)
+        # the SAM index where the two cubes agree about which pixels it skips (sam_support): the strict index where they do
+        sam_gate = max((r["dSAM_deg"] if not r.get("sam_support_flips") else r["dSAM_common_support_deg"]) for r in rows.values())
+        out[prec] = dict(worst, fixtures=rows, n_fixtures=len(rows), sam_support_flips=sum(r.get("sam_support_flips") or 0 for r in rows.values()),
+                         dSAM_deg_on_common_support=sam_gate,
+                         meets_north_star=bool(cont and worst["dSAM_deg"] <= 1e-3),
+                         meets_north_star_with_sam_on_common_support=bool(cont and sam_gate <= 1e-3))
     del nets, m, m_chi
     torch.cuda.empty_cache()
     return out
+
+
+def sam_support(truth, y, ref):
+    """(pixels whose zero-spectrum membership differs between our cube and the reference's, |SAM(truth, ours) - SAM(truth, reference's)|
+    in degrees over the pixels BOTH keep).  The reference's SAM (eval_hsi.py:47-65) skips pixels whose predicted spectrum is exactly
+    zero: the index is discontinuous where a spectrum sits at the clamp(0, 1) boundary of the decoded cube - one pixel entering or
+    leaving the mean moves it by (its angle - mean) / N, about 1.4e-3 degrees on these 128 x 128 cubes, however small the deviation
+    that flipped it.  `parity` reports the strict index, the number of such pixels and the index on the common support."""
+    import math
+    t, a, b = (v[0].reshape(v.shape[1], -1).float() for v in (truth, y, ref))
+    nt, na, nb = t.norm(dim=0), a.norm(dim=0), b.norm(dim=0)
+    flips = int(((na != 0) != (nb != 0)).sum())
+    ok = (nt != 0) & (na != 0) & (nb != 0)
+    sam = lambda p, n: float(torch.arccos(((t * p).sum(dim=0)[ok] / (nt[ok] * n[ok])).clamp(-1.0, 1.0)).double().mean()) * 180.0 / math.pi
+    return flips, abs(sam(a, na) - sam(b, nb))
 
 
 def cpu_baseline(cases=((1, 42), (5, 12)), warm=2, segments=3, sd=None):
@@ -573,7 +594,11 @@ def compact_line(head, roof=None, parity=None, cpu=None, mode=HEADLINE, detail_p
                           "dPSNR_dB": _r(pm["dPSNR_dB"]), "dSAM_deg": _r(pm["dSAM_deg"]), "n_fixtures": pm["n_fixtures"],
                           "worst_of": sorted(pm["fixtures"]), "bounds": "1e-3 rel / 0.01 dB / 0.001 deg (north_star)",
                           "oracle": "chains run by the imported reference (tests/golden/chain*.npz)",
-                          "meets_north_star": pm["meets_north_star"]}
+                          "meets_north_star": pm["meets_north_star"],
+                          # the SAM index skips exactly-zero spectra (eval_hsi.py:57): pixels at that discontinuity, and the bound with the
+                          # index taken where both cubes keep the same pixels (bench.py: sam_support)
+                          "sam_support_flips": pm.get("sam_support_flips"), "dSAM_deg_on_common_support": _r(pm.get("dSAM_deg_on_common_support")),
+                          "meets_north_star_with_sam_on_common_support": pm.get("meets_north_star_with_sam_on_common_support")}
         line["meets_north_star"] = pm["meets_north_star"]
     if extra:
         line.update(extra)

@@ -62,3 +62,21 @@ def chain_fixture(weights, draw, steps):
         sd = _ORTH["sd"]
     hr, sr = chain_cubes_draw(draw)
     return g, sd, hr, sr, (lambda gi, k: chain_noise_draw(draw, gi, k))
+
+
+def sam_common_support(truth, got, ref):
+    """The reference's SAM index (eval_hsi.py:47-65) SKIPS pixels whose predicted spectrum is exactly zero, so it is discontinuous
+    where a spectrum sits at the clamp(0, 1) boundary: a pixel that is all-zero in one cube and 1e-5 in one band in the other
+    enters / leaves the mean and moves it by (angle_pixel - mean) / N - about 1.4e-3 degrees per pixel on the 128 x 128 fixtures,
+    whatever the size of the deviation that flipped it.  Returns (number of pixels whose membership differs between `got` and
+    `ref`, |SAM(truth, got) - SAM(truth, ref)| in degrees over the pixels BOTH cubes keep).  All arrays (H, W, C)."""
+    t = truth.astype(np.float32).reshape(-1, truth.shape[2])
+    a = got.astype(np.float32).reshape(-1, got.shape[2])
+    b = ref.astype(np.float32).reshape(-1, ref.shape[2])
+    nt, na, nb = (np.linalg.norm(v, axis=1) for v in (t, a, b))
+    flips = int(np.count_nonzero((na != 0) != (nb != 0)))
+    ok = (nt != 0) & (na != 0) & (nb != 0)
+
+    def sam(p, npn):
+        return float(np.sum(np.arccos(np.sum(t[ok] * p[ok], axis=1) / (nt[ok] * npn[ok]))) / np.count_nonzero(ok) * 180.0 / np.pi)
+    return flips, abs(sam(a, na) - sam(b, nb))

@@ -330,7 +330,8 @@ def test_bench_contract_line_stays_compact():
     fx = {"%s:n%d:T%d" % (w, n, t): dict(latents_rel_err=5e-4, cube_rel_err=5e-4, dPSNR_dB=1e-5, dSAM_deg=1e-4)
           for w, n, t in (("synth", 0, 20), ("orth", 0, 20), ("orth", 1, 20), ("synth", 1, 20), ("orth", 2, 1000), ("synth", 3, 1000), ("chi:orth", 3, 20))}
     parity = {"fixtures": "t" * 700, "fp16": dict(latents_rel_err=5.75e-4, cube_rel_err=6.3e-4, dPSNR_dB=6e-5, dSAM_deg=7.1e-4, fixtures=fx,
-                                                    n_fixtures=len(fx), meets_north_star=True)}
+                                                    n_fixtures=len(fx), meets_north_star=False, sam_support_flips=3,
+                                                    dSAM_deg_on_common_support=1.23456789e-4, meets_north_star_with_sam_on_common_support=True)}
     cases = {"batch_%d" % b: dict(value=big, s_per_step=big, steps=42, seconds=big, segment_rates=[big] * 3) for b in (1, 5)}
     cpu = dict(value=big, unit="denoise-steps*batch/s", cores=64, kind="port", cases=cases,
                sample="p_sample steps of the full 97.8M UNet on the fp32 oracle, 64 pinned threads, median of 3 segments: 42 steps at batch 1 in 12.3 s; 12 steps at batch 5 in 12.3 s")
@@ -348,7 +349,7 @@ def test_bench_contract_line_stays_compact():
         assert k in rf, k
     assert isinstance(rf["traffic"], float) and "kernels" not in rf and "hbm_view" not in rf
     assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "cases"} and set(back["cpu_baseline"]["cases"]) == {"batch_1", "batch_5"}
-    assert "fixtures" not in back["parity"] and back["parity"]["n_fixtures"] == 7 and back["parity"]["meets_north_star"] is True
+    assert "fixtures" not in back["parity"] and back["parity"]["n_fixtures"] == 7 and back["parity"]["meets_north_star"] is False and back["parity"]["meets_north_star_with_sam_on_common_support"] is True
     # without the optional objects (N > 1 ranks, --no-* flags) the line is the head alone
     assert bench.compact_line(head) == head
 
