@@ -202,7 +202,7 @@ def chain_parity(dev, modes=("fp16",), long_modes=(), orth_net=None):
 
     out = {"fixtures": "the reference's validation iteration (one CAVE image, 5 group latents 3x128x128, 97.8M UNet, pretrained CAVE "
                        "autoencoder, cosine schedule) as run by the imported reference: weights {synthetic, reference orthogonal init} x "
-                       "three draws at T=20 (the last two generated after round 5's precision policy was fixed), two 1000-step chains (one per weight set; --parity-long / --detail), and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
+                       "three draws at T=20 (the last two generated after round 5's precision policy was fixed), two 1000-step chains (one per weight set), and a Chikusei image (128 bands, 11 group latents, pretrained Chikusei autoencoder: "
                        "BASELINE configs[2]; every 4th band of its cube compared); bounds 1e-3 relative / 0.01 dB / 0.001 deg (BASELINE.json north_star)"}
     per = {p: {} for p in modes}
     with torch.no_grad():
@@ -637,7 +637,7 @@ def main():
                     help="also measure the secondary legs into the detail file: other precision modes, small batches, the group "
                          "autoencoder, the training step, parity in every mode incl. the 1000-step reference chains (adds ~1 min)")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"))
-    ap.add_argument("--parity-long", action="store_true", help="parity also over the two 1000-step reference chains (-m gpu runs them too)")
+    ap.add_argument("--no-parity-long", action="store_true", help="parity without the two 1000-step reference chains (~8 s; -m gpu runs them too)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -800,10 +800,10 @@ def main():
             log('fp32 mode done')
     parity = None
     if solo and not args.no_parity:
-        # default: the headline mode over the T = 20 reference chains (4 CAVE + Chikusei); --parity-long / --detail add the two
-        # 1000-step chains, --detail the other modes
+        # default: the headline mode over every reference chain (six CAVE chains at T = 20, two at the metric's own T = 1000, Chikusei);
+        # --detail adds the other modes
         pm = ("fp16", "bf16", "fp32") if args.detail else ((args.precision,) if args.precision in ("fp16", "bf16", "fp32") else ("fp16",))
-        lm = tuple(m for m in pm if m != "bf16") if (args.detail or args.parity_long) else ()
+        lm = () if args.no_parity_long else tuple(m for m in pm if m != "bf16")
         parity = chain_parity(dev, modes=pm, long_modes=lm, orth_net=gd.denoise_fn)
         if bf16 is not None and parity.get("bf16"):
             bf16["meets_north_star"] = parity["bf16"]["meets_north_star"]

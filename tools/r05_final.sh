@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, final evidence (run through gpurun from the repo root): the default bench line + detail legs + per-kernel table + HBM traffic
+# (tools/collect_profiles.sh), SQ counters of the three largest conv instances of the step (one-pass fp16 sets), the N > 1 code path under a
+# one-rank RCCL group, smoke.  The -m gpu suite's log / parity.jsonl of the same tree are collected by a separate call.
+cd "$GRAFT_REPO_ROOT"
+bash tools/collect_profiles.sh r05_final detail > gpurun_out/r05_final_collect.log 2>&1
+tail -c 600 gpurun_out/r05_final/bench.json
+export HSIDM_EXPERIMENTAL=1
+for s in l32_256_256 l128_64_64 l64_128_128; do bash tools/pmc_conv.sh $s 240 fp16x1 > /dev/null 2>&1; done
+mkdir -p gpurun_out/r05_pmc; cp -r gpurun_out/pmc_l32_256_256_fp16x1 gpurun_out/pmc_l128_64_64_fp16x1 gpurun_out/pmc_l64_128_128_fp16x1 gpurun_out/r05_pmc/ 2>/dev/null
+find gpurun_out/r05_pmc -name "*.csv" -delete; find gpurun_out/r05_pmc -type d -name "pass*" -exec rm -rf {} + 2>/dev/null
+HSIDM_FORCE_DIST=1 python bench.py --gpus 1 --total-patches 64 --steps 100 --no-cpu-baseline --no-parity --detail-out gpurun_out/r05_final/force_dist_strong_detail.json > gpurun_out/r05_final/bench_force_dist_strong.json 2> gpurun_out/r05_final/bench_force_dist_strong.err
+tail -1 gpurun_out/r05_final/bench_force_dist_strong.json | cut -c1-300
+HSIDM_FORCE_DIST=1 python bench.py --gpus 1 --workload train --steps 30 > gpurun_out/r05_final/bench_force_dist_train.json 2> gpurun_out/r05_final/bench_force_dist_train.err
+tail -1 gpurun_out/r05_final/bench_force_dist_train.json | cut -c1-300
+python __graft_entry__.py smoke > gpurun_out/r05_final/smoke.log 2>&1; tail -5 gpurun_out/r05_final/smoke.log
