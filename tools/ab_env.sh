@@ -3,8 +3,8 @@
 steps=${STEPS:-200}; rounds=${ROUNDS:-3}
 for r in $(seq $rounds); do
   for v in "" "$@"; do
-    if [ -z "$v" ]; then tag=default; run() { python bench.py --steps $steps --warmup 10 --no-cpu-baseline 2>/dev/null; }
-    else tag=$v; run() { env "$v" python bench.py --steps $steps --warmup 10 --no-cpu-baseline 2>/dev/null; }; fi
+    if [ -z "$v" ]; then tag=default; run() { python bench.py --steps $steps --warmup 10 --no-cpu-baseline --no-parity --no-roofline 2>/dev/null; }
+    else tag=$v; run() { env "$v" python bench.py --steps $steps --warmup 10 --no-cpu-baseline --no-parity --no-roofline 2>/dev/null; }; fi
     run | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('$tag', round(d['ms_per_step'],3), 'ms/step', round(d['value'],1))"
   done
 done
