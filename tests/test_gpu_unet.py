@@ -431,6 +431,37 @@ def test_strided_ddim_sampler_matches_oracle(dev, steps, eta):
     assert gd.super_resolution(cond, continous=False).shape == (3, 16, 16)
 
 
+@pytest.mark.public_modes
+@pytest.mark.parametrize("steps,eta", [(10, 0.0), (20, 0.5)])
+def test_strided_ddim_sampler_in_the_default_mode(dev, steps, eta):
+    """The strided sampler under the "fp16" policy (the package default): its coefficient table carries its own update gains
+    (GaussianDiffusion.set_sampler: _run_eps_gain), so the policy's choice of the fp32-set steps follows the DDIM table, the other
+    steps run on the dithered fp16 sets; a K-step chain of a 40-step cosine schedule on the mid network against the oracle at 1e-3."""
+    from hsi_dmgasr_amd import precision
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    from oracle import diffusion as odiff, sr3_unet
+    cfg = jload(load_npz("unets.npz")["mid.cfg_json"])
+    u = unet.UNet(dropout=0.2, **cfg).to(dev).eval()              # precision=None: the package default
+    sd = fill_synth(u, "unet_mid.")
+    opt = dict(schedule="cosine", n_timestep=40, linear_start=1e-6, linear_end=1e-2)
+    gd = diffusion.GaussianDiffusion(u, image_size=cfg["image_size"], channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(opt, dev)
+    gd.set_sampler("ddim", steps=steps, eta=eta)
+    gd.noise, gd.seed = "philox", 91
+    shape = (2, 3, cfg["image_size"], cfg["image_size"])
+    cond = G(synth_tensor("ddim.default.cond", shape), dev)
+    run = gd.make_run(cond)
+    n_hi = sum(1 for m in run.modes if m == "fp32")
+    assert 1 <= n_hi < steps and all(precision.family(m) == "fp16" for m in run.modes[n_hi:]) and run.modes[:n_hi] == ["fp32"] * n_hi
+    got = run.run_all()
+    tab = odiff.ddim_schedule(opt, steps, eta)
+    den = lambda x, gam: sr3_unet.unet_forward(sd, cfg, x, gam)
+    nf = odiff.philox_noise_fn(91, shape)
+    want = odiff.ddim_sample_loop(den, tab, cond.cpu(), nf(steps), nf)
+    check("ddim_default_mode_K%d_eta%g" % (steps, eta), "default", got, want, tol=1e-3)
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96), (136, 16, 16, 128),
                                    (260, 8, 8, 64), (3, 16, 16, 64)])
 def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
