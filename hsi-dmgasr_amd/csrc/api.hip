@@ -171,9 +171,9 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         if (d->ksize != 3 || xf != HSIDM_XF_NONE || (d->bn != 64 && d->bn != 128) || (d->Hin & 1) || (d->Win & 1)) return HSIDM_E_UNSUPPORTED;
         path = PATH_V2;
     }
-    // fp32 NCHW output (the UNet's final Block, 64 -> 3): one padded 32-cout slice on the 256-pixel kernel (conv_v3.hip, WN = 1)
+    // fp32 NCHW output (the UNet's final Block, 64 -> 3; Cout <= 16): the first 16-cout half of one padded 32-cout slice on the 256-pixel kernel (conv_v3.hip, WN = 1)
     if (is16(d->prec) && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
-        xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 32 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
+        xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 16 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
         !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
     // A fused 1x1 projection (nphase == 2) on a persistent kernel: the sparse-lo form of conv_v3 (fp16 hi + lo layers, 64 couts, whole
     // 16x16 tiles) walks it as more one-tap chunks; everything else with a projection stays on the split-K or the LDS-tiled kernel

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     constexpr bool FRG = NP == 2 && !SPL;
     constexpr int FS = 6, FL = 4;                               // a k-slice pair keeps its two fragments for both row halves: FL <= FS - 2
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
+    // NCHW form (Cout <= 16, checked by the dispatcher: the UNet's final 64 -> 3 conv): only the first 16-cout half of the padded
+    // 32-cout slice holds weights - the second half's MFMAs would multiply zeros (half of this launch's matrix instructions)
+    constexpr int NHN = NCHW_ ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* halo = reinterpret_cast<E*>(smem_raw);
     if constexpr (!__is_same(E, bf16)) fp16_saturating_stores();     // (common.h)
@@ -467,20 +470,20 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     if (w < 2 && chunk == 0) {                  // first use of these accumulators: C = 0 as the MFMA's inline constant (uniform branch)
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int nh = 0; nh < 2; ++nh)
+                        for (int nh = 0; nh < NHN; ++nh)
 #pragma unroll
                             for (int mr = 0; mr < MR; ++mr)
                                 acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh], zero);
                     } else {
 #pragma unroll
-                        for (int nh = 0; nh < 2; ++nh)
+                        for (int nh = 0; nh < NHN; ++nh)
 #pragma unroll
                             for (int mr = 0; mr < MR; ++mr)
                                 acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], FRG ? fring[FRG ? (tap * 4 + q * 2 + nh) % FS : 0] : ring[FRG ? 0 : tap % 3][q * 2 + nh], acc[mr][r][nh]);
                     }
                     if (NP == 2) {
 #pragma unroll
-                        for (int nh = 0; nh < 2; ++nh)
+                        for (int nh = 0; nh < NHN; ++nh)
 #pragma unroll
                             for (int mr = 0; mr < MR; ++mr)
                                 acc[mr][r][nh] = EL::mfma16(a[w % AD][mr], fring_lo[FRG ? (tap * 4 + q * 2 + nh) % FS : 0], acc[mr][r][nh]);
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             asm volatile("" : "+v"(lane_o));
             const int c_o = lane_o & 15, g_o = lane_o >> 4;
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
+            for (int nh = 0; nh < NHN; ++nh) {
                 const int n_o = 16 * nh + c_o;
                 if (n_o < p.Cout) {
                     float* plane = reinterpret_cast<float*>(p.out) + ((size_t)b * p.Cout + n_o) * p.Hout * p.Wout;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 extern unsigned long long* g_stamps;      // conv_v2_inst.hip (diagnostic builds)
 
 // Hout % 16 == 0, Wout % 16 == 0, transform = GN+SiLU, no upsampling (checked by the caller); nchw = 0: Cout == 64, NHWC bf16 out;
-// nchw = 1: Cout <= 32 (one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
+// nchw = 1: Cout <= 16 (the first 16-cout half of one padded 32-cout slice), fp32 NCHW out, no FiLM / residual / statistics
 template <int WN_, bool NCHW_, typename E, int NP, bool SPL = false, bool PROJ = false>
 static int launch_v3(ConvV2Params& p, int G, hipStream_t s) {
     static PerDeviceOnce once;
