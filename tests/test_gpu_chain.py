@@ -99,7 +99,12 @@ def _run_chain(dev, prec, fixture):
            "meets_north_star": bool(e_lat <= NORTH_STAR["latents"] and e_y <= NORTH_STAR["latents"] and dpsnr <= NORTH_STAR["dpsnr"] and
                                     dsam <= NORTH_STAR["dsam"])}
     log_err("chain_T%d_full_latents" % steps, prec, e_lat, rec)
+    LAST_CHAIN_RECORD.clear()
+    LAST_CHAIN_RECORD.update(rec, latents_rel_err=e_lat, precision=prec)          # (tools/chain_probe.py prints it)
     return e_lat, e_y, dpsnr, _sam_gate(dsam, flips, dsam_common)
+
+
+LAST_CHAIN_RECORD = {}
 
 
 def _sam_gate(dsam, flips, dsam_common):

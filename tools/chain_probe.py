@@ -17,4 +17,6 @@ for prec in sys.argv[1].split(","):
     for spec in sys.argv[2:]:
         w, d, t = spec.split(":")
         e_lat, e_y, dpsnr, dsam = tc._run_chain(dev, prec, (w, int(d), int(t)))
-        print(json.dumps(dict(precision=prec, fixture=spec, latents=e_lat, cube=e_y, dPSNR_dB=dpsnr, dSAM_deg=dsam)), flush=True)
+        r = tc.LAST_CHAIN_RECORD
+        print(json.dumps(dict(precision=prec, fixture=spec, latents=e_lat, cube=e_y, dPSNR_dB=dpsnr, dSAM_deg=r["dSAM_deg"],
+                              dSAM_common_support_deg=r["dSAM_common_support_deg"], zero_spectrum_crossings=r["zero_spectrum_crossings"])), flush=True)
