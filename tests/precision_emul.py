@@ -93,6 +93,7 @@ class Mode:
         # wd=4c128: layers the `w` rule leaves at one pass (e.g. w=x2s@c64 -> couts 65 ...) and with at most 128 output channels get
         # one-pass weights DITHERED over the chain's steps (K = 4 offsets; see w=dK)
         self.wd_k, self.wd_cmax = (int(kv["wd"].split("c")[0]), int(kv["wd"].split("c")[1])) if "wd" in kv else (0, 0)
+        self.dseq = kv.get("dseq", "")
         self.gn = kv.get("gn", "fp32")
         self.sk = kv.get("sk", "sSuhra")
         self.wl = kv["wl"].split("+") if "wl" in kv else None      # wl=final+ups.18: hi + lo weights on these units only
@@ -156,6 +157,8 @@ class Mode:
 
     def _dither(self, w, K):
         ph = int(format(self.phase % K, "0%db" % max(1, (K - 1).bit_length()))[::-1], 2) if K & (K - 1) == 0 else self.phase % K
+        if self.dseq:                                       # dseq=0321 / 03213012: the ORDER of the K offsets over the steps (indices into the sorted offsets)
+            ph = int(self.dseq[(self.phase - self.first) % len(self.dseq)])
         mant = 10 if self.t == "fp16" else 7
         ulp = torch.exp2(torch.floor(torch.log2(w.abs().clamp_min(2.0 ** -14))) - mant)
         return rnd(w + ((ph + 0.5) / K - 0.5) * ulp, self.t)
