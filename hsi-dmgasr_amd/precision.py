@@ -88,7 +88,10 @@ def resolve_precision(p):
 # The chain's deviation is made where the gain is large; emulated on the T = 20 reference chains (tests/precision_emul.py, one-pass
 # dithered weights, synth:0 / orth:1): 4 steps 6.8e-4 / 7.7e-4, 6 steps 5.4e-4 / 6.1e-4, 8 steps 4.9e-4 / 5.3e-4 (dSAM 4e-6 / 2.7e-4 deg);
 # hi + 2:4-sparse lo weights with 4 steps (round 4's policy) 5.5e-4 / 5.7e-4.  Each further step costs 0.16 % of a 1000-step chain.
-WIDE_STEP_GAIN = 0.25
+# (HSIDM_WIDE_STEP_GAIN: the threshold is a knob between accuracy and speed on SHORT chains - 1/6 makes it twelve steps: measured
+# 2.8e-4 ... 3.0e-4 instead of 4.9e-4 ... 5.5e-4 on the 20-step reference chains, nothing on the 1000-step ones (3.0e-4 either way) nor on
+# the SAM index, for -0.5 % on the 1000-step benchmark (10 217 against 10 268 in one box) and +19 % time on a 20-step chain)
+WIDE_STEP_GAIN = float(os.environ.get("HSIDM_WIDE_STEP_GAIN", "0.25"))
 
 # Weight dither of the "fp16" policy's chain steps.  The fp16 rounding of a WEIGHT is the one error of a 16-bit pipeline that repeats
 # in every step of a chain - a bias, which is what moves the quality indices.  The fp16 kernel set of chain
