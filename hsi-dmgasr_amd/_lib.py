@@ -170,7 +170,7 @@ def prec_id(precision):
     if precision in ("fp32", "f32x3"):
         return F32X3
     if precision in ("fp16", "fp16x1", "fp16x2") or (isinstance(precision, str) and precision.startswith("fp16d") and precision[5:].isdigit()):
-        return F16
+        return F16              # ("fp16d<k>": the dithered one-pass sets of the "fp16" policy; precision.dither_phase validates k)
     raise ValueError("precision must be 'bf16', 'fp16' or 'fp32', got %r" % (precision,))
 
 

@@ -104,7 +104,7 @@ DITHER_K = int(os.environ.get("HSIDM_DITHER_K", "4"))
 
 def dither_phase(p):
     """(phase, K) of a dithered kernel-set name "fp16d<phase>", else None."""
-    if isinstance(p, str) and p.startswith("fp16d") and p[5:].isdigit():
+    if isinstance(p, str) and p.startswith("fp16d") and p[5:].isdigit() and int(p[5:]) < DITHER_K:
         return int(p[5:]), DITHER_K
     return None
 

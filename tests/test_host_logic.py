@@ -497,6 +497,9 @@ def test_weight_dither_of_the_fp16_kernel_sets():
     assert [P.dither_offset(k, 4) for k in range(4)] == [-0.375, 0.125, -0.125, 0.375]
     assert P.dither_phase("fp16d2") == (2, 4) and P.dither_phase("fp16") is None and P.family("fp16d3") == "fp16" and P.family("fp32") == "fp32"
     assert P.resolve_precision("fp16d1") == "fp16d1" and _lib.prec_id("fp16d1") == _lib.F16 and not P.wide_weights("fp16d1", 64)
+    assert P.dither_phase("fp16d4") is None                                        # only the K phases are names
+    with pytest.raises(ValueError):
+        P.resolve_precision("fp16d4")
     g = torch.Generator().manual_seed(5)
     w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
     w[0, 0] = 0.0
