@@ -867,6 +867,7 @@ def main():
                        "patches_per_gpu": patches, "total_patches": total_patches, "groups_per_patch": GROUPS,
                        "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world,
                        "precision_mode": DTYPE[args.precision],
+                       "warmup_steps_run": n_warm,       # >= --warmup: every kernel set's eager step and capture lie before the clock starts
                        "fp32_mode_steps_in_window": n_other,
                        "ms_per_step_chain_mix": None if mix is None else _r(mix["ms_per_step_chain_mix"], 5),
                        "value_chain_mix": None if mix is None else _r(mix["value_chain_mix"], 5)},

@@ -318,7 +318,7 @@ def test_bench_contract_line_stays_compact():
             "config": {"workload": "SR3 UNet 97.8M (6->3 ch, inner 64, mults 1-2-4-8-8, attn@16) p_sample step on GAE latents 3x128x128, "
                                    "cosine T=1000, BASELINE configs[3]", "patches_per_gpu": 48, "total_patches": 384, "groups_per_patch": 5,
                        "batch_per_gpu": 240, "global_batch": 1920, "parallelism": "dp8", "precision_mode": max(bench.DTYPE.values(), key=len),
-                       "fp32_mode_steps_in_window": 4, "ms_per_step_chain_mix": big, "value_chain_mix": big},
+                       "warmup_steps_run": 16, "fp32_mode_steps_in_window": 4, "ms_per_step_chain_mix": big, "value_chain_mix": big},
             "rccl_ranks": 8, "allgather_ms": big, "rank_ms_per_step": {"min": big, "max": big}}
     row = dict(kernel=kern, launches=20, ms_per_step=big, avg_launch_us=big, tflops=big, frac=0.123456789)
     roof = dict(bound="mfma", kernel=kern, launches=20, avg_launch_us=big, algorithmic_flops_per_launch=big * 1e7,
