@@ -226,25 +226,43 @@ def chain_parity(dev, modes=("fp16",), long_modes=(), orth_net=None):
             q_ref = (float(g["mpsnr_formula"]), float(g["sam_oracle"])) if chi else tuple(float(v) for v in metrics.quality_indices(truth, ref_y)[0][:2])
             # (the 1000-step chains only in `long_modes`; bf16 - outside the tolerance by 8x - not on the Chikusei fixture)
             for prec in ([p for p in modes if p in long_modes] if steps > 100 else ([p for p in modes if p != "bf16"] if chi else modes)):
-                y, lat = pipeline.super_resolve(m_chi if chi else m, gd, G(sr), x_T=x_T, noise=noise, precision=prec)
+                ae = m_chi if chi else m
+                y, lat = pipeline.super_resolve(ae, gd, G(sr), x_T=x_T, noise=noise, precision=prec)
                 q = metrics.quality_indices(truth, y)[0]
                 e_lat = float((lat[0] - ref_lat).double().norm() / ref_lat.double().norm())
+                # the same deviation over the elements the reference did NOT clamp to +-1 (diffusion.py:164): a saturated element carries no
+                # error and all of its weight in the norm (38 % of the T = 20 reference latents are exactly +-1)
+                free = ref_lat.abs() < 1.0
+                e_unsat = float(((lat[0] - ref_lat)[free]).double().norm() / ref_lat[free].double().norm())
                 ys = y[:, ::4] if chi else y
                 e_y = float((ys - ref_y).double().norm() / ref_y.double().norm())
-                row = dict(latents_rel_err=e_lat, cube_rel_err=e_y, dPSNR_dB=abs(float(q[0]) - q_ref[0]), dSAM_deg=abs(float(q[1]) - q_ref[1]))
+                # the CONTINUOUS companion of the SAM index: both latent sets through the same fp32-mode decoder WITHOUT the final clamp
+                # (sr_gae.py:473-474) - no spectrum is exactly zero there, so the index has no support to flip
+                C = 128 if chi else 31
+                raw_ours, raw_ref = ae.decode_batched(lat, C), ae.decode_batched(ref_lat.view(1, ngr, 3, 128, 128), C)
+                row = dict(latents_rel_err=e_lat, latents_rel_err_unsaturated=e_unsat, saturated_latent_fraction=float(1.0 - free.double().mean()),
+                           cube_rel_err=e_y, dPSNR_dB=abs(float(q[0]) - q_ref[0]), dSAM_deg=abs(float(q[1]) - q_ref[1]),
+                           dSAM_unclamped_deg=abs(sam_unclamped(truth, raw_ours) - sam_unclamped(truth, raw_ref)))
                 if not chi:     # (the Chikusei fixture stores a quarter of the reference's cube: no per-pixel comparison of the SAM support)
-                    row["sam_support_flips"], row["dSAM_common_support_deg"] = sam_support(truth, y, ref_y)
+                    row["sam_support_flips"], row["dSAM_common_support_deg"], row["flipped_pixel_norm_over_cube_rms"] = sam_support(truth, y, ref_y)
+                # the value the SAM bound is applied to: the reference's strict index, unless the two cubes disagree about which pixels it
+                # skips AND the disagreement is the index's discontinuity and nothing else (<= 2 pixels, each at the clamp boundary in both cubes)
+                fl = row.get("sam_support_flips") or 0
+                boundary = 0 < fl <= SAM_MAX_FLIPS and row["flipped_pixel_norm_over_cube_rms"] <= SAM_FLIP_NORM
+                row["dSAM_gated_deg"], row["sam_gate_is_strict_index"] = (row["dSAM_common_support_deg"], False) if boundary else (row["dSAM_deg"], True)
                 per[prec][":".join(str(v) for v in fx).replace(":%d:%d" % (draw, steps), ":n%d:T%d" % (draw, steps))] = row
             del noise, gd
     for prec in modes:
         rows = per[prec]
         if not rows:
             continue
-        worst = {k: max(r[k] for r in rows.values()) for k in ("latents_rel_err", "cube_rel_err", "dPSNR_dB", "dSAM_deg")}
-        cont = bool(worst["latents_rel_err"] <= 1e-3 and worst["cube_rel_err"] <= 1e-3 and worst["dPSNR_dB"] <= 0.01)
-        # the SAM index where the two cubes agree about which pixels it skips (sam_support): the strict index where they do
-        sam_gate = max((r["dSAM_deg"] if not r.get("sam_support_flips") else r["dSAM_common_support_deg"]) for r in rows.values())
+        worst = {k: max(r[k] for r in rows.values()) for k in ("latents_rel_err", "latents_rel_err_unsaturated", "cube_rel_err", "dPSNR_dB", "dSAM_deg",
+                                                                 "dSAM_unclamped_deg")}
+        cont = bool(worst["latents_rel_err"] <= 1e-3 and worst["latents_rel_err_unsaturated"] <= 1e-3 and worst["cube_rel_err"] <= 1e-3 and
+                    worst["dPSNR_dB"] <= 0.01 and worst["dSAM_unclamped_deg"] <= 1e-3)
+        sam_gate = max(r["dSAM_gated_deg"] for r in rows.values())
         out[prec] = dict(worst, fixtures=rows, n_fixtures=len(rows), sam_support_flips=sum(r.get("sam_support_flips") or 0 for r in rows.values()),
+                         strict_sam_misses=sorted(k for k, r in rows.items() if r["dSAM_deg"] > 1e-3),
                          dSAM_deg_on_common_support=sam_gate,
                          meets_north_star=bool(cont and worst["dSAM_deg"] <= 1e-3),
                          meets_north_star_with_sam_on_common_support=bool(cont and sam_gate <= 1e-3))
@@ -253,19 +271,35 @@ def chain_parity(dev, modes=("fp16",), long_modes=(), orth_net=None):
     return out
 
 
+SAM_MAX_FLIPS, SAM_FLIP_NORM = 2, 1e-3          # (tests/helpers.py: sam_gate - the same two conditions)
+
+
 def sam_support(truth, y, ref):
     """(pixels whose zero-spectrum membership differs between our cube and the reference's, |SAM(truth, ours) - SAM(truth, reference's)|
-    in degrees over the pixels BOTH keep).  The reference's SAM (eval_hsi.py:47-65) skips pixels whose predicted spectrum is exactly
-    zero: the index is discontinuous where a spectrum sits at the clamp(0, 1) boundary of the decoded cube - one pixel entering or
-    leaving the mean moves it by (its angle - mean) / N, about 1.4e-3 degrees on these 128 x 128 cubes, however small the deviation
-    that flipped it.  `parity` reports the strict index, the number of such pixels and the index on the common support."""
+    in degrees over the pixels BOTH keep, the largest spectrum norm of a flipped pixel in either cube over the reference cube's rms).
+    The reference's SAM (eval_hsi.py:47-65) skips pixels whose predicted spectrum is exactly zero: the index is discontinuous where a
+    spectrum sits at the clamp(0, 1) boundary of the decoded cube - one pixel entering or leaving the mean moves it by
+    (its angle - mean) / N, about 1.4e-3 degrees on these 128 x 128 cubes, however small the deviation that flipped it.  `parity`
+    reports the strict index, the number of such pixels, the index on the common support, and applies the bound to the latter ONLY
+    when at most SAM_MAX_FLIPS pixels flipped and each has a spectrum norm <= SAM_FLIP_NORM x the cube's rms in both cubes."""
     import math
     t, a, b = (v[0].reshape(v.shape[1], -1).float() for v in (truth, y, ref))
     nt, na, nb = t.norm(dim=0), a.norm(dim=0), b.norm(dim=0)
-    flips = int(((na != 0) != (nb != 0)).sum())
+    flip = (na != 0) != (nb != 0)
+    flips = int(flip.sum())
     ok = (nt != 0) & (na != 0) & (nb != 0)
     sam = lambda p, n: float(torch.arccos(((t * p).sum(dim=0)[ok] / (nt[ok] * n[ok])).clamp(-1.0, 1.0)).double().mean()) * 180.0 / math.pi
-    return flips, abs(sam(a, na) - sam(b, nb))
+    worst = float(torch.maximum(na[flip], nb[flip]).max() / b.double().pow(2).mean().sqrt()) if flips else 0.0
+    return flips, abs(sam(a, na) - sam(b, nb)), worst
+
+
+def sam_unclamped(truth, raw):
+    """Mean spectral angle in degrees over every pixel with a non-zero true spectrum, for an UN-CLAMPED decoded cube [1, C, H, W]."""
+    import math
+    t, p = (v[0].reshape(v.shape[1], -1).double() for v in (truth, raw))
+    nt, npn = t.norm(dim=0), p.norm(dim=0)
+    ok = (nt != 0) & (npn != 0)
+    return float(torch.arccos(((t * p).sum(dim=0)[ok] / (nt[ok] * npn[ok])).clamp(-1.0, 1.0)).mean()) * 180.0 / math.pi
 
 
 def cpu_baseline(cases=((1, 42), (5, 12)), warm=2, segments=3, sd=None):
@@ -590,8 +624,11 @@ def compact_line(head, roof=None, parity=None, cpu=None, mode=HEADLINE, detail_p
                                 "cases": {k: {"value": _r(r["value"]), "s_per_step": _r(r["s_per_step"])} for k, r in cpu["cases"].items()}}
     if parity is not None and parity.get(mode):
         pm = parity[mode]
-        line["parity"] = {"mode": mode, "latents_rel_err": _r(pm["latents_rel_err"]), "cube_rel_err": _r(pm["cube_rel_err"]),
-                          "dPSNR_dB": _r(pm["dPSNR_dB"]), "dSAM_deg": _r(pm["dSAM_deg"]), "n_fixtures": pm["n_fixtures"],
+        line["parity"] = {"mode": mode, "latents_rel_err": _r(pm["latents_rel_err"]),
+                          # over the elements the reference did not clamp to +-1 (diffusion.py:164), and the SAM angle on the un-clamped cubes
+                          "latents_rel_err_unsaturated": _r(pm.get("latents_rel_err_unsaturated")), "cube_rel_err": _r(pm["cube_rel_err"]),
+                          "dPSNR_dB": _r(pm["dPSNR_dB"]), "dSAM_deg": _r(pm["dSAM_deg"]), "dSAM_unclamped_deg": _r(pm.get("dSAM_unclamped_deg")),
+                          "strict_sam_misses": pm.get("strict_sam_misses"), "n_fixtures": pm["n_fixtures"],
                           "worst_of": sorted(pm["fixtures"]), "bounds": "1e-3 rel / 0.01 dB / 0.001 deg (north_star)",
                           "oracle": "chains run by the imported reference (tests/golden/chain*.npz)",
                           "meets_north_star": pm["meets_north_star"],
@@ -728,7 +765,7 @@ def main():
         log('timed region done: %.3f s' % dt)
         # steps of the timed window that ran in another mode than the chain's base mode (the precision schedule's fp32-mode steps
         # sit at the START of each chain: a window shorter than the rest of the chain has none), and the per-chain mix
-        T = run.T
+        T = run_T = run.T
         base_mode = family(run.modes[-1])
         n_other = sum(1 for k in range(n_warm, n_warm + args.steps) if family(run.modes[k % T]) != base_mode)
         per_chain_other = n_hi
@@ -741,7 +778,11 @@ def main():
                 ms_mix = ((T - per_chain_other) * t_base + per_chain_other * t_other) / T
                 mix = dict(ms_per_step_base_mode=t_base, ms_per_step_other_mode=t_other, other_mode=other,
                            steps_per_chain_other_mode=per_chain_other, chain_steps=T, ms_per_step_chain_mix=ms_mix,
-                           value_chain_mix=total_patches * GROUPS / (ms_mix * 1e-3))
+                           value_chain_mix=total_patches * GROUPS / (ms_mix * 1e-3),
+                           # the same policy on the chain length the reference SHIPS (config/sr_sr3_16_128.json:98,104: n_timestep 20 for
+                           # validation): the high-gain steps are the first ones of a chain whatever its length, so a 20-step chain pays
+                           # all of them in 20 steps (steady-state step times; a chain's graph captures are not in it)
+                           value_T20=total_patches * GROUPS * 20 / ((min(per_chain_other, 20) * t_other + max(20 - per_chain_other, 0) * t_base) * 1e-3))
         if use_dist:
             # the path's one data collective: every rank ends with all SR cubes (here: cube-sized stand-ins for the decoded
             # patches, 31 x 128 x 128 fp32 each = 2.0 MB per patch)
@@ -853,12 +894,20 @@ def main():
 
     if rank == 0:
         total_batch = total_patches * GROUPS
+        # The metric is the 1000-step p_sample_loop: `value` is the rate of a WHOLE chain under the precision policy.  A timed window that
+        # holds fewer of the policy's fp32-set steps than their share of a chain (the driver's 20 steps hold none: they are the first eight
+        # of a chain and the warm-up consumed them) would read optimistic, so `value` / `ms_per_step` are then the per-chain mix of the
+        # two measured step times - (T - n) x window step + n x fp32-set step, the latter timed right behind the window - and the raw
+        # window figures stay in `config`.  A window that is a whole chain (the default 1000 steps) IS the mix and is reported as measured.
+        win_value, win_ms = args.steps * total_batch / dt, dt / args.steps * 1e3
+        use_mix = mix is not None and n_other * run_T < per_chain_other * args.steps
+        value, ms_step = (mix["value_chain_mix"], mix["ms_per_step_chain_mix"]) if use_mix else (win_value, win_ms)
         head = {
             "metric": "UNet denoise-steps/sec x batch, CAVE 31-band 16->128, 1000-step p_sample_loop",
-            "value": _r(args.steps * total_batch / dt, 5),
+            "value": _r(value, 5),
             "unit": "denoise-steps*batch/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": _r(dt / args.steps * 1e3, 5),
+            "ms_per_step": _r(ms_step, 5),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": {"fp16": "fp16", "fp16x1": "fp16", "fp16x2": "fp16", "bf16": "bf16", "fp32": "f32 (bf16x3)"}[args.precision],
             "data": "synthetic (orthogonal-init weights seed 0, N(0,1) latents clipped to +-2.5, Philox noise)",
@@ -869,9 +918,15 @@ def main():
                        "precision_mode": DTYPE[args.precision],
                        "warmup_steps_run": n_warm,       # >= --warmup: every kernel set's eager step and capture lie before the clock starts
                        "fp32_mode_steps_in_window": n_other,
+                       "value_is": "per-chain mix of the measured step times" if use_mix else "the timed window as measured",
+                       "value_window": _r(win_value, 5), "ms_per_step_window": _r(win_ms, 5),
                        "ms_per_step_chain_mix": None if mix is None else _r(mix["ms_per_step_chain_mix"], 5),
-                       "value_chain_mix": None if mix is None else _r(mix["value_chain_mix"], 5)},
+                       "value_chain_mix": None if mix is None else _r(mix["value_chain_mix"], 5),
+                       "ms_per_step_fp32_set": None if mix is None else _r(mix["ms_per_step_other_mode"], 5),
+                       # the reference's shipped validation chain length (T = 20): all of the policy's fp32-set steps in 20 steps
+                       "value_T20": None if mix is None else _r(mix["value_T20"], 5)},
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": _r(allgather_ms),
+            # (the timed window, min / max over the ranks)
             "rank_ms_per_step": {"min": _r(dt_min / args.steps * 1e3, 5), "max": _r(dt / args.steps * 1e3, 5)},
         }
         detail = {"line": None, "chain_mix": mix, "roofline": roof, "parity": parity, "bf16_mode": bf16, "fp32_mode": fp32,

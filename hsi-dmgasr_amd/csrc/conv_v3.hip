@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
     static_assert(!SPL || (NP == 2 && WN_ == 2 && !NCHW_ && !__is_same(E, bf16)), "sparse low halves: fp16, two passes, the 64-cout form");
-    static_assert(!PROJ || SPL, "fused 1x1 projection: built for the sparse-lo form");
+    static_assert(!PROJ || SPL || (NP == 1 && WN_ == 2 && !NCHW_), "fused 1x1 projection: the sparse-lo form and the one-pass 64-cout forms");
     constexpr bool FRG = NP == 2 && !SPL;
     constexpr int FS = 6, FL = 4;                               // a k-slice pair keeps its two fragments for both row halves: FL <= FS - 2
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     };
     auto b_issue = [&](x8 (&dst)[4]) __attribute__((always_inline)) {
         const E* src = wlane + (size_t)wnext * wstep_stride;
+        if (!HSIDM_ABL(8)) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + frag_off(kk));
+            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const x8*>(src + frag_off(kk));
+        }
         wnext = (wnext + 1 == p.steps_per_item) ? 0 : wnext + 1;
     };
     auto f_issue = [&](int slot, int kk) __attribute__((always_inline)) {
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         return p.xcd_m > 0 ? (it & 7) * (p.m_tiles >> 3) + (it >> 3) : it;     // xcd_m is 0 or 8
     };
     auto describe = [&](int it_) __attribute__((always_inline)) {
+        if (HSIDM_ABL(32) && it_ != (int)blockIdx.x) return;     // (diagnostic builds: the first item's addresses for every item)
         const int it = tile_of(it_);
         const int b = div_tpi(it);
         const int tr = it - b * tiles_per_img;
@@ -173,6 +176,29 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             const bool ok = pos >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             hv_pix[i] = ok ? (b * p.Hin + iy) * p.Win + ix : -1;
         }
+    };
+    // A chunk's staging request: issue_begin (channel slice, source pointer, the GroupNorm pairs) and issue_one(i), the load of halo
+    // vector i - eleven back to back ahead of the matrix phase.  (Round 6 spread them over the phase's taps, conv_v2's schedule: neutral
+    // to 1 % slower in-box, profiles/r06_ab/ab_spread_issue.txt - not kept.)
+    const E* is_src = reinterpret_cast<const E*>(p.src0);
+    int is_cs = 0;
+    auto issue_begin = [&](int chunk) __attribute__((always_inline)) {
+        const int c = chunk * BK + cv * 8;
+        st_cok = c < ctot;
+        const int cc = st_cok ? c : 0;
+        if (cc < p.C0) { is_src = reinterpret_cast<const E*>(p.src0) + cc; is_cs = p.C0; }
+        else           { is_src = reinterpret_cast<const E*>(p.src1) + (cc - p.C0); is_cs = p.C1; }
+        {   // log2(e)-scaled fp16x2 part of the GroupNorm table (conv_v2.h: gn_params, silu_log2e)
+            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)3 * p.B * ctot + (size_t)st_b * ctot + cc);
+            const u32x4 lo = t[0], hi = t[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
+        }
+    };
+    auto issue_one = [&](int i) __attribute__((always_inline)) {
+        if (HSIDM_ABL(4)) return;
+        const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
+        hreg[i] = *reinterpret_cast<const u32x4*>(is_src + (size_t)pix * is_cs);
     };
     auto issue_all = [&](int chunk) __attribute__((always_inline)) {
         if (PROJ && chunk >= nch) {                             // workgroup-uniform
@@ -196,24 +222,9 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             for (int i = 0; i < 8; ++i) hreg[i] = *reinterpret_cast<const u32x4*>(base + i * pair);
             return;
         }
-        const int c = chunk * BK + cv * 8;
-        st_cok = c < ctot;
-        const int cc = st_cok ? c : 0;
-        const E* src;
-        int cs;
-        if (cc < p.C0) { src = reinterpret_cast<const E*>(p.src0) + cc; cs = p.C0; }
-        else           { src = reinterpret_cast<const E*>(p.src1) + (cc - p.C0); cs = p.C1; }
-        {   // log2(e)-scaled fp16x2 part of the GroupNorm table (conv_v2.h: gn_params, silu_log2e)
-            const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(p.gn_ab) + (size_t)3 * p.B * ctot + (size_t)st_b * ctot + cc);
-            const u32x4 lo = t[0], hi = t[1];
+        issue_begin(chunk);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { abh[k] = lo[k]; abh[4 + k] = hi[k]; }
-        }
-#pragma unroll
-        for (int i = 0; i < MAXHV; ++i) {
-            const int pix = hv_pix[i] >= 0 ? hv_pix[i] : 0;
-            hreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)pix * cs);
-        }
+        for (int i = 0; i < MAXHV; ++i) issue_one(i);
     };
     // dead slots of the last (partial) vector round store into the row padding instead of being branched around, so the
     // eleven transforms form one basic block the scheduler can interleave (conv_v2.h: dead_off)
@@ -232,9 +243,21 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             }
             return;
         }
+        if (HSIDM_ABL(16)) return;
         int posv[MAXHV];                                        // table reads before the first halo store (they may alias for the compiler)
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) posv[i] = pos_tab[i * 256 + tid];
+        if (HSIDM_ABL(2)) {                                     // (diagnostic builds: the raw vectors, no GroupNorm + SiLU)
+#pragma unroll
+            for (int i = 0; i < MAXHV; ++i) {
+                u32x4 ou = hreg[i];
+                const bool live = st_cok && hv_pix[i] >= 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ou[k] = live ? ou[k] : 0u;
+                *reinterpret_cast<u32x4*>(halo + (posv[i] >= 0 ? (posv[i] >> 10) : dead_off)) = ou;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MAXHV; ++i) {
             const int pos = posv[i];
@@ -308,7 +331,9 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         float ep_add[2] = {0.f, 0.f}, ep_bias[2] = {0.f, 0.f};  // FiLM / bias of the lane's couts [16-cout half]: loaded in the last chunk
         f32x4 ep4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // SPL: bias + FiLM of couts 16 nh + 4g .. + 3, loaded in the epilogue
 
-        for (int chunk = 0; chunk < nct; ++chunk) {
+        // (one-pass PROJ forms: the 9-tap loop covers the 3x3 chunks, the projection's chunks follow as three static slots below)
+        const int n_loop = (PROJ && !SPL) ? nch : nct;
+        for (int chunk = 0; chunk < n_loop; ++chunk) {
             commit_all(chunk >= nch);                           // hreg holds (item, chunk): transform -> LDS
             if (chunk == 0) HSIDM_STAMP(it, 1);
             if (PROJ && chunk == nch) HSIDM_STAMP(it, 6);
@@ -467,7 +492,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                     const int w = tap * 4 + kk, q = kk >> 1, r = kk & 1;
                     if (w + AD - 1 < 36) a_fetch(w + AD - 1);
                     if (FRG) f_issue((w + FL) % FS, (w + FL) % 4);
-                    if (w < 2 && chunk == 0) {                  // first use of these accumulators: C = 0 as the MFMA's inline constant (uniform branch)
+                    if (HSIDM_ABL(128)) {                        // (diagnostic builds: no matrix instructions)
+                    } else if (w < 2 && chunk == 0) {           // first use of these accumulators: C = 0 as the MFMA's inline constant (uniform branch)
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int nh = 0; nh < NHN; ++nh)
@@ -499,9 +525,60 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             if (chunk == 0) HSIDM_STAMP(it, 5);
             if (PROJ && chunk == nch) HSIDM_STAMP(it, 10);
         }
+        if constexpr (PROJ && !SPL) {
+            // ---- the ResnetBlock's 1x1 projection of a second input (hsidm_conv_desc.ph[1]; reference unet.py:102-103,110) as up to THREE
+            // more one-tap chunks accumulated into the same tile.  A projection chunk's raw 16 x 16 pixels are committed one halo row and
+            // column further in than their place in the halo tile (commit_all), so the offsets of tap 8 - (2, 2) - read them; its weight
+            // step comes through the same 3-step register ring.  The packed weights ALWAYS carry three projection steps per item (the host
+            // pads with zero steps: ops.pack_layouts), so that the ring's phase is the same at every item start and every index stays
+            // static; slots >= pchunks only pull their (zero) step through the ring.
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bool live = j < p.pchunks;                // workgroup-uniform
+                if (live) {
+                    commit_all(true);
+                    HSIDM_STAMP(it, 6 + j);
+                    stage_advance();
+                    if (st_valid) {
+                        if (st_chunk == 0) describe(st_item);
+                        issue_all(st_chunk);
+                    }
+                    lds_barrier();
+                }
+                b_issue(ring[(j + 2) % 3]);
+                if (live) {
+                    HSIDM_SETPRIO(1);
+                    x8 a[3][MR];
+                    auto a_fetch = [&](int w) __attribute__((always_inline)) {      // w = 32 + 2 q + r: tap 8, slice q, row r of the pair
+                        const int off = (2 + (w & 1)) * RP + 2 * PSTR + ((w >> 1) & 1) * 32;
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) a[w % 3][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
+                    };
+                    a_fetch(32);
+                    a_fetch(33);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int w = 32 + kk, q = kk >> 1, r = kk & 1;
+                        if (w + 2 < 36) a_fetch(w + 2);
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr)
+                                acc[mr][r][nh] = EL::mfma16(a[w % 3][mr], ring[FRG ? 0 : j][q * 2 + nh], acc[mr][r][nh]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    HSIDM_SETPRIO(0);
+                    lds_barrier();                              // every wave is done reading: the tile may be overwritten
+                }
+            }
+        }
         HSIDM_STAMP(it, 12);
 
         // ---- epilogue (conv_v2's vector epilogue; the halo buffer is free between the two barriers) ------------------------
+        if (HSIDM_ABL(64)) {                                    // (diagnostic builds: no epilogue; the accumulators stay live through one store)
+            if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][1] + acc[MR - 1][0][1][2];
+            continue;
+        }
         const int tr = tile - b * tiles_per_img;
         const int try_e = div_tx(tr);
         const int oy0 = try_e * TH, ox0 = (tr - try_e * p.tiles_x) * TW;
@@ -628,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                             o[k] = (E)f[k];
                         }
                     }
-                    *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(v4) + lane_el) = o;
+                    if (!HSIDM_ABL(1)) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + vec_base(v4) + lane_el) = o;
                     if (RES || SPL) {                                           // (SPL: a lane of the accumulator layout holds eight couts - the vector domain is cheaper)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
@@ -693,16 +770,22 @@ int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, int spl, hipStream_
     auto log2_or_neg = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
     p.tpi_shift = log2_or_neg(p.tiles_x * p.tiles_y);
     p.tx_shift = log2_or_neg(p.tiles_x);
-    p.abl = 0;
+    p.abl = debug_get(DBG_V2_ABL);            // (read by diagnostic builds only: -DHSIDM_V2_ABLATE)
     p.stamps = g_stamps;
     int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;
     if (G == 0) G = p.total_items;
-    if (elem == 0 && np == 1) return nchw ? launch_v3<1, true, bf16, 1>(p, G, s) : launch_v3<2, false, bf16, 1>(p, G, s);
-    if (elem == 1 && np == 1) return nchw ? launch_v3<1, true, f16, 1>(p, G, s) : launch_v3<2, false, f16, 1>(p, G, s);
-    if (p.pchunks > 0) {        // fused 1x1 projection: the sparse-lo form only (api.hip: conv_v3_takes_proj)
-        if (elem == 1 && np == 2 && spl && !nchw) return launch_v3<2, false, f16, 2, true, true>(p, G, s);
+    if (p.pchunks > 0) {        // fused 1x1 projection (api.hip: v3_proj): the one-pass 64-cout forms and the sparse-lo form
+        if (nchw) return HSIDM_E_UNSUPPORTED;
+        if (np == 1) {
+            if (p.pchunks > 3) return HSIDM_E_UNSUPPORTED;
+            p.steps_per_item = 9 * p.nchunks + 3;               // three projection steps per item in the packed weights, whatever pchunks (zero padded)
+            return elem ? launch_v3<2, false, f16, 1, false, true>(p, G, s) : launch_v3<2, false, bf16, 1, false, true>(p, G, s);
+        }
+        if (elem == 1 && np == 2 && spl) return launch_v3<2, false, f16, 2, true, true>(p, G, s);
         return HSIDM_E_UNSUPPORTED;
     }
+    if (elem == 0 && np == 1) return nchw ? launch_v3<1, true, bf16, 1>(p, G, s) : launch_v3<2, false, bf16, 1>(p, G, s);
+    if (elem == 1 && np == 1) return nchw ? launch_v3<1, true, f16, 1>(p, G, s) : launch_v3<2, false, f16, 1>(p, G, s);
     if (elem == 1 && np == 2 && spl && !nchw) return launch_v3<2, false, f16, 2, true>(p, G, s);
     if (elem == 1 && np == 2) return nchw ? launch_v3<1, true, f16, 2>(p, G, s) : launch_v3<2, false, f16, 2>(p, G, s);
     return HSIDM_E_UNSUPPORTED;

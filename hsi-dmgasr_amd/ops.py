@@ -55,13 +55,20 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     meta = dict(ksize=kh, cin=cin, cout=cout, bn=bn, cpad=cpad, proj_cin=proj_cin, prec=prec, tap_major=False)
     # register-streaming order for the persistent bf16 3x3 kernel: [step][Cout_pad/32][kk][lane][8] with
     # lane = (k-half h, cout r): element j = W[cout = 32*slice + r][k = 16*kk + 8*h + j]
-    # proj_scale != 1 (PackedConv: fp16 hi + lo layers): the projection steps of the register-streaming order carry log2(e) - the
-    # persistent kernels stage log2(e) * silu(.) and undo the factor on the accumulators, i.e. on the projection's products too
-    # (conv_v3.hip, PROJ); the "w" order, which the LDS-tiled kernel reads, stays unscaled
+    # bn == 64 (conv_v3's PROJ forms; proj_scale = log2(e)): the projection steps of the register-streaming order carry log2(e) - the
+    # persistent kernels stage log2(e) * silu(.) and undo the factor on the accumulators, i.e. on the projection's products too - and
+    # are padded with zero steps to THREE per item (conv_v3.hip: the one-pass form pulls three steps through its 3-step weight ring
+    # whatever the projection's width, so that the ring's phase is the same at every item; the sparse-lo form walks the real ones
+    # only); the "w" order, which the LDS-tiled kernel reads, stays unscaled and unpadded
     if b16 and proj_weight is not None and kh == 3 and not out_nchw and (bn == 128 or (bn == 64 and proj_scale != 1.0)):
-        steps = lay["w"] if proj_scale == 1.0 else torch.cat([parts[0], parts[1] * proj_scale], dim=0).contiguous()
+        steps = lay["w"]
+        if proj_scale != 1.0:
+            pj = parts[1] * proj_scale
+            if pj.shape[0] < 3:
+                pj = torch.cat([pj, pj.new_zeros((3 - pj.shape[0],) + tuple(pj.shape[1:]))], dim=0)
+            steps = torch.cat([parts[0], pj], dim=0).contiguous()
         lay["w_v2_steps"] = steps
-        lay["w_v2"] = PackedConv._lanes(steps, cpad)            # read by the split-K kernel (conv_sk.hip: projection chunks) or conv_v3's PROJ form
+        lay["w_v2"] = PackedConv._lanes(steps, cpad)            # read by the split-K kernel (conv_sk.hip: projection chunks) or conv_v3's PROJ forms
     # fp32 mode: the persistent 3x3 kernel has an fp32 form too (conv_v2.h, AP = 2: fp32 storage, hi + lo operands); it reads the same
     # register-streaming order with 64-channel steps
     f32_v2 = (not b16) and proj_weight is None and not out_nchw and bn in (64, 128) and (kh == 3 or cout % bn == 0)
@@ -120,8 +127,10 @@ class PackedConv:
         dev = weight.device
         cout, cin, ksz = weight.shape[0], weight.shape[1], weight.shape[2]
         wide16 = _lib.prec_id(precision) == _lib.F16 and wide_weights(precision, cout, cin + (-cin) % 8, ksz)
+        # (a fused projection on a 64-cout slice is conv_v3's: its steps carry log2(e), see pack_layouts)
+        v3_proj = proj_weight is not None and _lib.prec_id(precision) != _lib.F32X3 and pick_bn(cout, out_nchw) == 64
         lay, meta = pack_layouts(weight.detach().float(), precision, None if proj_weight is None else proj_weight.detach().float(),
-                                 out_nchw, fold_ups, fold_dn, proj_scale=LOG2E if (wide16 and proj_weight is not None) else 1.0)
+                                 out_nchw, fold_ups, fold_dn, proj_scale=LOG2E if v3_proj else 1.0)
         self._set_meta(meta, precision, out_nchw)
         b = None if bias is None else bias.detach().float().clone()
         if proj_weight is not None and proj_bias is not None:
@@ -361,14 +370,15 @@ def set_fused_proj(flag):
     _fused_proj = bool(flag)
 
 
-def use_fused_proj():
-    """Is the persistent kernel's projection form on offer?  The host switch AND the library's own switches (hsidm_debug_query:
-    NO_FUSED_PROJ / NO_V3 / NO_SPARSE_LO): asked BEFORE a ResnetBlock computes a GroupNorm table or packs the projection layouts
-    for the offer, so that a refused offer costs nothing (A/B runs through the debug switches stay clean)."""
+def use_fused_proj(wide=False):
+    """Is the persistent kernel's projection form on offer (wide: for a layer with fp16 hi + lo weights - the sparse-lo form)?  The
+    host switch AND the library's own switches (hsidm_debug_query: NO_FUSED_PROJ / NO_V3 / NO_SPARSE_LO): asked BEFORE a ResnetBlock
+    computes a GroupNorm table or packs the projection layouts for the offer, so that a refused offer costs nothing (A/B runs through
+    the debug switches stay clean)."""
     if not _fused_proj:
         return False
     L = _lib.lib()
-    return not any(L.hsidm_debug_query(name) for name in (b"NO_FUSED_PROJ", b"NO_V3", b"NO_SPARSE_LO"))
+    return not any(L.hsidm_debug_query(name) for name in ((b"NO_FUSED_PROJ", b"NO_V3") + ((b"NO_SPARSE_LO",) if wide else ())))
 
 
 def set_fold_ups(flag):

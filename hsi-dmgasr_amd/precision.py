@@ -52,9 +52,20 @@ def allow_experimental(flag=True):
     return old
 
 
+_internal = False            # inside the sampler's per-step dispatch (internal_names()): the dithered kernel-set names are accepted
+
+
 def _known(p):
-    if p in MODES or dither_phase(p) is not None:
+    if p in MODES:
         return True
+    if dither_phase(p) is not None:
+        # "fp16d<k>" names ONE kernel set of the "fp16" policy.  Only the sampler's per-step choice (step_precision) produces it:
+        # a module or a run built on it by name would skip the policy's fp32-set steps and the gain-1 widening of bare forwards -
+        # a single forward on such a set measures 1.1e-3 ... 1.4e-3 - so by name it is an experimental set like the others
+        if _internal or _experimental:
+            return True
+        raise ValueError("hsidm: precision %r is one kernel set of the \"fp16\" policy (chosen per chain step by the sampler), not a mode; "
+                         "use \"fp16\", or allow_experimental() to run the set by name" % (p,))
     if p in EXPERIMENTAL_MODES:
         if not _experimental:
             raise ValueError("hsidm: precision %r is an experimental kernel set outside the reference's tolerance (bf16: 7.9e-3 on the "
@@ -98,7 +109,8 @@ WIDE_STEP_GAIN = float(os.environ.get("HSIDM_WIDE_STEP_GAIN", "0.25"))
 # step k therefore multiplies by  fp16(w + d[k % K] * ulp(w))  with DITHER_K offsets d spread over (-1/2, 1/2) (bit-reversed order):
 # over K consecutive steps every weight is rounded up in about frac * K of them (frac: its position in its rounding interval), so
 # the MEAN weight the chain sees is w to 1 / (2 K) ulp.  Kernel-set names: "fp16d0" ... "fp16d<K-1>" (produced by step_precision
-# only; one packed copy of the 16-bit weights and one captured graph per phase).  HSIDM_DITHER_K=0: off (A/B: plain rounding).
+# only; one packed copy of the 16-bit weights and one captured graph per phase).  HSIDM_DITHER_K=0: off (A/B: the plainly rounded one-pass
+# set "fp16x1" on the fp16-set steps).
 DITHER_K = int(os.environ.get("HSIDM_DITHER_K", "4"))
 
 
@@ -127,8 +139,10 @@ def step_precision(p, eps_gain, step=0):
     output (see the module docstring)."""
     if p in ("fp16", "fp16x1", "fp16x2") and eps_gain >= WIDE_STEP_GAIN and not os.environ.get("HSIDM_NO_STEP_SCHEDULE"):
         return "fp32"
-    if p == "fp16" and DITHER_K > 1:
-        return "fp16d%d" % (step % DITHER_K)
+    if p == "fp16":
+        # (HSIDM_DITHER_K <= 1: the A/B form without the dither is the plainly rounded one-pass set, "fp16x1" - NOT the name "fp16",
+        # which as a kernel-set name is round 4's hi + lo set on Cout <= 128)
+        return "fp16d%d" % (step % DITHER_K) if DITHER_K > 1 else "fp16x1"
     return p
 
 
@@ -137,6 +151,17 @@ def forward_precision(p):
     the caller's result - gain 1 - so the "fp16" policy runs it on the fp32 kernel set (reference unet.py:239-263: what
     `netG.denoise_fn(x, t)` returns is held to 1e-3 like every other output of the path)."""
     return "fp32" if (p == "fp16" and not _as_named) else p
+
+
+@contextlib.contextmanager
+def internal_names():
+    """Inside: the kernel-set names step_precision produces ("fp16d<k>") resolve (the sampler's per-step dispatch)."""
+    global _internal
+    old, _internal = _internal, True
+    try:
+        yield
+    finally:
+        _internal = old
 
 
 @contextlib.contextmanager

@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..precision import resolve_precision, step_precision
+from ..precision import internal_names, resolve_precision, step_precision
 from .unet import UNet
 
 
@@ -52,49 +52,123 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2,
     raise NotImplementedError(schedule)
 
 
+class _GraphSlot:
+    """What a captured reverse step is tied to: the STATIC device buffers its kernels address (state x_t, conditioning latents, step
+    counter, injected noise, snapshots), the captured graphs per kernel set with their shared memory pool, and the parameter versions
+    the packed weights behind them were built from.  GaussianDiffusion keeps the slots of finished p_sample_loop calls
+    (`_graph_cache`) so that the next call on the same shapes copies its inputs in and REPLAYS from its first step - the reference's
+    validation loop (sr_gae.py:436-494) calls p_sample_loop once per image and group, and on its shipped 20-step chain the five eager
+    steps and five captures of a fresh run are half of the chain."""
+
+    def __init__(self, key, weights):
+        self.key, self.weights = key, weights
+        self.x = self.cond = self.t_ptr = self.stored = self.zbuf = self.snap = None
+        self.graphs, self.eager_done, self.pool = {}, set(), None
+        self.busy = True
+
+
+def _weights_version(fn):
+    return tuple((p.data_ptr(), p._version) for p in fn.parameters())
+
+
 class ReverseRun:
     """State of one reverse-diffusion chain batch on the device: x_t, the step counter t (device int32),
     noise source, optional snapshot buffer, and the captured HIP graph of one step.
 
     step()  : enqueue one reverse step (graph replay once captured);
     run_all(): the T steps of p_sample_loop.
-    With wrap=True the counter restarts at T-1 after t = 0 (benchmark loops longer than one chain)."""
+    With wrap=True the counter restarts at T-1 after t = 0 (benchmark loops longer than one chain).
+    reuse=True (GaussianDiffusion._reverse): the run takes a free cached slot of the same key if there is one - its inputs are copied
+    into the slot's static buffers and every step is a replay - and hands its slot back through release(); `x`, `snap` then belong to
+    the slot and must be copied out first."""
 
-    def __init__(self, gd, cond, shape, continous, x_T, noise, precision, wrap):
+    def __init__(self, gd, cond, shape, continous, x_T, noise, precision, wrap, reuse=False):
         dev = gd.betas.device
         T = gd._run_T                      # steps of the active sampler (num_timesteps for the reference's ancestral one)
         self.gd, self.T, self.precision, self.wrap = gd, T, precision, wrap
         self.inter = 1 | (T // 10)
-        if x_T is not None:
-            self.x = x_T.to(dev, torch.float32).contiguous().clone()
-        elif gd.noise == "philox":
-            self.x = ops.philox_normal(shape, gd.seed, T, dev)
-        else:
-            self.x = torch.randn(shape, device=dev)
-        self.first = self.x.clone() if continous else None
-        n = self.x.numel()
-        # per-step noise: caller-supplied [T-1, *shape] (index k <-> t = T-1-k), the Philox generator inside the
-        # update kernel, or a fresh torch.randn draw per step (reference behaviour, diffusion.py:174)
-        self.stored, self.zbuf, self.stride = None, None, 0
-        if noise is not None:
-            self.stored = noise.to(dev, torch.float32).contiguous()
-            assert self.stored.shape[0] >= T - 1 and self.stored[0].numel() == n
-            self.stride = n
-        elif gd.noise != "philox":
-            self.zbuf = torch.empty_like(self.x)
-        nsnap = (T - 1) // self.inter + 1
-        self.snap = torch.empty((nsnap,) + tuple(shape), dtype=torch.float32, device=dev) if continous else None
-        self.t_ptr = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
-        self.cond = None if cond is None else cond.to(dev, torch.float32).contiguous()
         self.fused = isinstance(gd.denoise_fn, UNet)
         # precision schedule along the chain (precision.step_precision): mode of the step at t = T-1-k, k = 0..T-1; the host
         # mirrors the device-side step counter (steps_done), so the choice costs no read-back
         base = resolve_precision(precision if precision is not None else getattr(gd.denoise_fn, "precision", None)) if self.fused else precision
         # (the "fp16" policy: high-gain steps on the fp32 kernel set, the others on the fp16 set with the weight dither of phase k % K)
         self.modes = [step_precision(base, float(gd._run_eps_gain[T - 1 - k]), k) if self.fused else base for k in range(T)]
-        self.graphs, self._eager_done = {}, set()
-        self._pool = None                  # one private memory pool for every captured graph of this run (replays are serial)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nsnap = (T - 1) // self.inter + 1
+        slot = None
+        if reuse and self.fused and gd.use_graph:
+            src = "stored" if noise is not None else gd.noise
+            key = (tuple(shape), bool(continous), src, None if noise is None else tuple(noise.shape), T, tuple(self.modes), cond is None,
+                   int(gd.seed), id(gd._run_coef), id(gd._run_level), str(dev))
+            ver = _weights_version(gd.denoise_fn)
+            cache = gd._graph_cache
+            cache[:] = [s for s in cache if s.busy or s.weights == ver]        # graphs over superseded packed weights: dropped
+            slot = next((s for s in cache if not s.busy and s.key == key), None)
+            if slot is None:
+                slot = _GraphSlot(key, ver)
+                free = [s for s in cache if not s.busy]
+                while len(free) >= gd.graph_cache_slots:                      # (each slot holds a batch's activations in its pool)
+                    cache.remove(free.pop(0))
+                cache.append(slot)
+            else:
+                cache.remove(slot)
+                cache.append(slot)                                            # most recently used last
+                slot.busy = True
+        self.slot = slot
+        fresh = slot is None or slot.x is None
+        if x_T is not None:
+            x0 = x_T.to(dev, torch.float32)
+        elif gd.noise == "philox":
+            x0 = ops.philox_normal(shape, gd.seed, T, dev)
+        else:
+            x0 = torch.randn(shape, device=dev)
+        if fresh:
+            self.x = x0.contiguous().clone() if x_T is not None else x0
+        else:
+            self.x = slot.x
+            self.x.copy_(x0.reshape(self.x.shape))
+        self.first = self.x.clone() if continous else None
+        # per-step noise: caller-supplied [T-1, *shape] (index k <-> t = T-1-k), the Philox generator inside the
+        # update kernel, or a fresh torch.randn draw per step (reference behaviour, diffusion.py:174)
+        self.stored, self.zbuf, self.stride = None, None, 0
+        if noise is not None:
+            assert noise.shape[0] >= T - 1 and noise[0].numel() == n
+            if fresh:
+                # (a cached slot owns its copy: the caller's tensor may be gone, or changed, by the next call)
+                self.stored = noise.to(dev, torch.float32).contiguous() if slot is None else noise.to(dev, torch.float32).contiguous().clone()
+            else:
+                self.stored = slot.stored
+                self.stored.copy_(noise)
+            self.stride = n
+        elif gd.noise != "philox":
+            self.zbuf = torch.empty_like(self.x) if fresh else slot.zbuf
+        if fresh:
+            self.snap = torch.empty((nsnap,) + tuple(shape), dtype=torch.float32, device=dev) if continous else None
+            self.t_ptr = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
+            self.cond = None if cond is None else cond.to(dev, torch.float32).contiguous()
+            if slot is not None and self.cond is not None and self.cond.data_ptr() == cond.data_ptr():
+                self.cond = self.cond.clone()                                 # (the slot's own copy, see above)
+        else:
+            self.snap, self.t_ptr, self.cond = slot.snap, slot.t_ptr, slot.cond
+            self.t_ptr.fill_(T - 1)
+            if cond is not None:
+                self.cond.copy_(cond)
+        if slot is not None:
+            slot.x, slot.cond, slot.t_ptr, slot.stored, slot.zbuf, slot.snap = self.x, self.cond, self.t_ptr, self.stored, self.zbuf, self.snap
+            self.graphs, self._eager_done = slot.graphs, slot.eager_done
+        else:
+            self.graphs, self._eager_done = {}, set()
+        self._pool = None if slot is None else slot.pool   # one private memory pool for every captured graph of this run (replays are serial)
         self.steps_done = 0
+
+    def release(self):
+        """Hand the slot back to the cache (GaussianDiffusion._reverse, after it has copied the results out of the static buffers)."""
+        if self.slot is not None:
+            self.slot.pool = self._pool
+            self.slot.busy = False
+            self.slot = None
 
     @property
     def graph(self):
@@ -103,7 +177,8 @@ class ReverseRun:
 
     def _enqueue(self, precision=None):
         gd = self.gd
-        eps = gd._denoise(self.cond, self.x, self.t_ptr, self.modes[-1] if precision is None else precision)
+        with internal_names():              # (the step's kernel set may be one of the policy's dithered sets: an internal name)
+            eps = gd._denoise(self.cond, self.x, self.t_ptr, self.modes[-1] if precision is None else precision)
         if self.zbuf is not None:
             self.zbuf.normal_()
         ops.p_sample_update(self.x, eps.contiguous(), gd._run_coef, self.t_ptr, self.T,
@@ -127,6 +202,8 @@ class ReverseRun:
                 g = self.graphs[mode] = torch.cuda.CUDAGraph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
+                    if self.slot is not None:
+                        self.slot.pool = self._pool
                 # (the kernel sets of a chain - fp32 + the K dither phases of the fp16 set - replay one at a time on one stream and
                 # leave nothing behind but x_t, which lives outside the pool: they share their activation memory)
                 with torch.cuda.graph(g, pool=self._pool):
@@ -177,7 +254,8 @@ class GaussianDiffusion(nn.Module):
         self.noise = "torch"       # "torch" | "philox": where x_T and the per-step noise come from
         self.seed = 0              # Philox key
         self.use_graph = os.environ.get("HSIDM_NO_GRAPH", "") == ""   # eager launches for per-dispatch counters
-        self._graph_cache = {}
+        self._graph_cache = []     # free / busy _GraphSlot objects of p_sample_loop calls (ReverseRun(reuse=True))
+        self.graph_cache_slots = 2 # free slots kept (distinct shapes / chain lengths / noise sources); 0: every call captures afresh
 
     # ---------------------------------------------------------------------------------- configuration
     def set_loss(self, device):
@@ -223,7 +301,7 @@ class GaussianDiffusion(nn.Module):
         self.register_buffer("_coef", coef, persistent=False)
         self.register_buffer("_level", torch.tensor(self.sqrt_alphas_cumprod_prev, dtype=torch.float32, device=device),
                              persistent=False)
-        self._graph_cache = {}
+        self._graph_cache = []
         self._schedule_opt = dict(schedule_opt)
         self.set_sampler("ddpm")
 
@@ -262,6 +340,7 @@ class GaussianDiffusion(nn.Module):
             self._run_level = torch.tensor(self._run_level_host, dtype=torch.float32, device=dev)
         else:
             raise NotImplementedError(kind)
+        self._graph_cache = [s for s in self._graph_cache if s.busy]      # captured steps address the previous sampler's tables
         self.sampler = kind
 
     # ---------------------------------------------------------------------------------- reverse process
@@ -279,9 +358,19 @@ class GaussianDiffusion(nn.Module):
 
     def _reverse(self, cond, shape, continous, x_T=None, noise=None, precision=None):
         """Runs t = T-1 .. 0.  Returns (final x [B,C,H,W], snapshots [K,B,C,H,W] or None, x_T or None)."""
-        run = ReverseRun(self, cond, tuple(shape), continous, x_T, noise, precision, False)
-        run.run_all()
-        return run.x, run.snap, run.first
+        run = ReverseRun(self, cond, tuple(shape), continous, x_T, noise, precision, False, reuse=self.graph_cache_slots > 0)
+        try:
+            run.run_all()
+        except BaseException:
+            if run.slot is not None and run.slot in self._graph_cache:      # a half-captured slot is not offered again
+                self._graph_cache.remove(run.slot)
+            raise
+        if run.slot is None:
+            return run.x, run.snap, run.first
+        # the state and the snapshots live in the slot's static buffers, which the next call overwrites: the caller gets copies
+        out = (run.x.clone(), None if run.snap is None else run.snap.clone(), run.first)
+        run.release()
+        return out
 
     @torch.no_grad()
     def p_sample_loop(self, x_in, continous=False):

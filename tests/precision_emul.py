@@ -16,6 +16,9 @@ A mode is  <type>[:key=value,...]  with type in {fp32, bf16, fp16}; keys
                         spread over (-1/2, 1/2) ulp (bit-reversed order), so that the weight error - the one rounding that is the
                         same in every step - averages to 1/K of its size over K consecutive steps
     a value of w / st / op may carry "@128+64": the map sizes (of the conv's INPUT) on which the override applies
+    is=K                the FIRST K steps of the chain on the exact UNet (the policy's fp32-set steps); fs=K: the last K
+    mid=N  with  SPEC|SPEC2   the N steps behind the first `is` ones run in mode SPEC2 (e.g. "fp16:w=d4,is=1,mid=7|fp16:w=x2,st=fp32":
+                        one exact step, seven with hi + lo weights and fp32 storage, the rest on dithered one-pass weights)
 """
 import json
 import math
@@ -74,6 +77,8 @@ def round_zero_sum(w, t):
 class Mode:
     def __init__(self, spec):
         self.spec = spec
+        spec, _, spec2 = spec.partition("|")
+        self.second = Mode(spec2) if spec2 else None
         parts = spec.split(":")
         self.t = parts[0]
         kv = dict(p.split("=") for p in parts[1].split(",")) if len(parts) > 1 else {}
@@ -104,6 +109,7 @@ class Mode:
         self.sm = kv.get("sm", "")
         self.fs = int(kv.get("fs", 0))                             # fs=K: the LAST K steps of the chain (t < K) on the exact UNet
         self.first = int(kv.get("is", 0))                          # is=K: the FIRST K steps of the chain on the exact UNet
+        self.mid = int(kv.get("mid", 0))                           # mid=N: the N steps behind them in the mode behind "|"
 
     def _ovr(self, k, hw):
         return k not in self.lvl or hw in self.lvl[k]
@@ -290,10 +296,14 @@ def run(spec, steps=CHAIN_T, seed=0, fixture=None):
         x = torch.from_numpy(np.concatenate([cn(gi, 0) for gi in range(ngr)]))
         exact = lambda xc, gam: sr3_unet.unet_forward(sd, FULL, xc, gam)
         den = exact if spec == "fp32" else (lambda xc, gam: unet_forward(m, sd, FULL, xc, gam))
+        den2 = None if m.second is None else (exact if m.second.spec == "fp32" else (lambda xc, gam: unet_forward(m.second, sd, FULL, xc, gam)))
         for i in reversed(range(CHAIN_T)):
             zn = torch.from_numpy(np.concatenate([cn(gi, CHAIN_T - i) for gi in range(ngr)])) if i > 0 else None
             m.phase = CHAIN_T - 1 - i
-            x = diffusion.p_sample_step(exact if (i < m.fs or i >= CHAIN_T - m.first) else den, sched, x, z, i, zn)
+            if m.second is not None:
+                m.second.phase = m.phase
+            fn = exact if (i < m.fs or i >= CHAIN_T - m.first) else (den2 if (den2 is not None and m.phase < m.first + m.mid) else den)
+            x = diffusion.p_sample_step(fn, sched, x, z, i, zn)
             if CHAIN_T - i >= steps:
                 break
         lat = x.numpy()
@@ -301,7 +311,8 @@ def run(spec, steps=CHAIN_T, seed=0, fixture=None):
         if ngr < nfull:
             out.update(groups=ngr, latents_rel=float(np.linalg.norm(lat.astype(np.float64) - g["x0"][:ngr]) / np.linalg.norm(g["x0"][:ngr].astype(np.float64))))
         elif steps >= CHAIN_T:
-            y = gae.gae_decode(gsd, 31, [x[i:i + 1] for i in range(ngr)], 8, 2).clamp(0, 1).numpy()
+            y_raw = gae.gae_decode(gsd, 31, [x[i:i + 1] for i in range(ngr)], 8, 2)
+            y = y_raw.clamp(0, 1).numpy()
             a = hr[0].transpose(1, 2, 0)
             if seed == 0:
                 ref_lat, ref_y = g["x0"], g["y"]
@@ -312,9 +323,15 @@ def run(spec, steps=CHAIN_T, seed=0, fixture=None):
             ref = ref_y[0].transpose(1, 2, 0)
             got = y[0].transpose(1, 2, 0)
             nrm = lambda u, v: float(np.linalg.norm(u.astype(np.float64) - v) / np.linalg.norm(v.astype(np.float64)))
-            out.update(seed=seed, latents_rel=nrm(lat, ref_lat), cube_rel=nrm(y, ref_y),
+            free = np.abs(ref_lat) < 1.0
+            out.update(seed=seed, latents_rel=nrm(lat, ref_lat), latents_rel_unsaturated=nrm(lat[free], ref_lat[free]), cube_rel=nrm(y, ref_y),
                        dPSNR_dB=abs(metrics.mpsnr(a, got) - metrics.mpsnr(a, ref)),
                        dSAM_deg=abs(metrics.sam_degrees(a, got) - metrics.sam_degrees(a, ref)))
+            if seed == 0:       # the continuous companion of the SAM index: the angle on the UN-clamped cubes (tests/helpers.py: sam_continuous)
+                from helpers import sam_continuous
+                zr = torch.from_numpy(np.ascontiguousarray(g["x0"]))
+                ref_raw = gae.gae_decode(gsd, 31, [zr[i:i + 1] for i in range(ngr)], 8, 2).numpy()
+                out["dSAM_unclamped_deg"] = abs(sam_continuous(a, y_raw.numpy()[0].transpose(1, 2, 0)) - sam_continuous(a, ref_raw[0].transpose(1, 2, 0)))
             out["_y"], out["_lat"] = y, lat
             out["meets_north_star"] = bool(out["latents_rel"] <= 1e-3 and out["dPSNR_dB"] <= 0.01 and out["dSAM_deg"] <= 1e-3)
     return out

@@ -181,14 +181,16 @@ def test_sparse_second_weight_pass_removes_the_weight_bias(dev, shape):
     assert miss < 0.5, miss
 
 
-@pytest.mark.parametrize("shape", [(64, 128, 64, 2, 32, 48), (64, 64, 0, 3, 16, 16), (128, 64, 8, 2, 32, 32)],
-                         ids=["cat_192", "single_64", "ragged_72"])
+@pytest.mark.parametrize("shape", [(64, 128, 64, 2, 32, 48), (64, 64, 0, 3, 16, 16), (64, 64, 64, 2, 32, 32), (128, 64, 8, 2, 32, 32)],
+                         ids=["cat_192", "single_64", "cat_128", "ragged_72"])
 def test_projection_fused_into_the_persistent_kernel(dev, shape):
-    """ResnetBlock's tail, h2 = conv3x3(silu(GN(h))) + conv1x1(cat(x0, x1)) + biases (reference unet.py:105-111), on the fp16 hi + lo
+    """ResnetBlock's tail, h2 = conv3x3(silu(GN(h))) + conv1x1(cat(x0, x1)) + biases (reference unet.py:105-111), on the
     64-cout layers: the projection as one-tap chunks of the 3x3 launch (conv_v3.hip, PROJ: raw staging, centre tap, projection
-    weights scaled by log2(e) on the host, sparse low halves) against fp32 torch on the host and against the two-launch form (1x1 GEMM,
-    then the 3x3 kernel with its result as the residual).  Projection widths: 192 = two tensors, 64, and 72 (a last chunk of 8 live
-    channels: the staging zeroes the rest)."""
+    weights scaled by log2(e) on the host) against fp32 torch on the host and against the two-launch form (1x1 GEMM, then the 3x3
+    kernel with its result as the residual) - in the ONE-PASS kernel sets the benchmark's chain steps run ("fp16d1": a dithered set of
+    the fp16 policy; "fp16x1"; "bf16": three static projection slots behind the 3-step weight ring, zero-padded steps) and in the
+    hi + lo sets (sparse second pass).  Projection widths: 192 = two tensors (three chunks), 64 (one), 128 = two tensors (two), and 72
+    (a last chunk of 8 live channels: the staging zeroes the rest)."""
     from hsi_dmgasr_amd import ops
     Ci, P0, P1, B, H, W = shape
     g = torch.Generator().manual_seed(Ci + P0 + P1)
@@ -197,14 +199,18 @@ def test_projection_fused_into_the_persistent_kernel(dev, shape):
     b = 0.1 * torch.randn(Co, generator=g)
     wp = torch.randn(Co, P0 + P1, 1, 1, generator=g) / (P0 + P1) ** 0.5
     bp = 0.1 * torch.randn(Co, generator=g)
-    h = torch.randn(B, H, W, Ci, generator=g).to(torch.float16).to(dev)
-    x0 = torch.randn(B, H, W, P0, generator=g).to(torch.float16).to(dev)
-    x1 = torch.randn(B, H, W, P1, generator=g).to(torch.float16).to(dev) if P1 else None
+    h16 = torch.randn(B, H, W, Ci, generator=g).to(torch.float16)
+    x016 = torch.randn(B, H, W, P0, generator=g).to(torch.float16)
+    x116 = torch.randn(B, H, W, P1, generator=g).to(torch.float16) if P1 else None
     ab = torch.stack([1 + 0.1 * torch.randn(B, Ci, generator=g), 0.2 * torch.randn(B, Ci, generator=g)], 2).contiguous().to(dev)
     tab = ops.gn_table(ab)
-    want = _reference(h, None, ab, True, w, b, None, None) + _reference(x0, x1, None, False, wp, bp, None, None, ksize=1)
-    for mode in ("fp16", "fp16x2"):
+    for mode in ("fp16d1", "fp16x1", "bf16", "fp16", "fp16x2"):
+        dt = torch.bfloat16 if mode == "bf16" else torch.float16
+        h, x0 = h16.to(dt).to(dev), x016.to(dt).to(dev)
+        x1 = None if x116 is None else x116.to(dt).to(dev)
+        want = _reference(h, None, ab, True, w, b, None, None) + _reference(x0, x1, None, False, wp, bp, None, None, ksize=1)
         pk = ops.PackedConv(w.to(dev), b.to(dev), mode, proj_weight=wp.to(dev), proj_bias=bp.to(dev))
+        assert (pk.w_v2_lo is None) == (mode in ("fp16d1", "fp16x1", "bf16"))
         recs = []
         ops.set_conv_probe(recs)
         try:
@@ -214,7 +220,7 @@ def test_projection_fused_into_the_persistent_kernel(dev, shape):
             ops.set_conv_probe(None)
         assert y is not None and "conv_v3" in recs[-1]["kernel"], recs
         assert_stats(y._hsidm_stats[0], y, "proj_fused")
-        check("anchor_proj_fused_%d_%d" % (Ci, P0 + P1), mode, y, want, tol=TOL["fp16x2"])
+        check("anchor_proj_fused_%d_%d" % (Ci, P0 + P1), mode, y, want, tol=TOL["bf16"] if mode == "bf16" else (TOL["fp16x2"] if pk.w_v2_lo is not None else (8e-4 if mode == "fp16d1" else TOL["fp16"])))
         # the two-launch form on the same operands
         r = ops.conv2d(x0, ops.PackedConv(wp.to(dev), bp.to(dev), mode), x1=x1)
         y2 = ops.conv2d(h, ops.PackedConv(w.to(dev), b.to(dev), mode), gn_ab=tab, transform=ops.XF_AFFINE_SILU, res=r)

@@ -4,9 +4,14 @@ kernel dispatch needs.
   * chain.npz: the reference's validation iteration (sr_gae.py:436-474) on the 97.8 M-parameter UNet, its T = 20 cosine
     chain, one CAVE image (5 spectral groups, pretrained CAVE autoencoder), run by the imported reference with the noise
     of tests/golden/synth.py:chain_noise (tests/golden/make_golden_chain.py);
-  * north-star gates ("1e-3 relative; PSNR/SAM within 0.01 dB / 0.001"): the fp32 mode and the fp16 mode (fp16 storage and
-    operands, hi + lo weights on the high-resolution levels) are held to ALL of them; the bf16 mode meets the PSNR bound only
-    and is gated at its measured deviation with head-room (DSAM_MAX / LATENT_MAX below say so explicitly);
+  * north-star gates ("1e-3 relative; PSNR/SAM within 0.01 dB / 0.001"): the fp32 mode and the fp16 mode (a POLICY: dithered one-pass
+    fp16 kernel sets on the low-gain steps of a chain, the fp32 kernel set on its high-gain steps - precision.py) are held to ALL of
+    them, the latents also on the support the reference did not clamp; the bf16 set meets the PSNR bound only and is gated at its
+    measured deviation with head-room (DSAM_MAX / LATENT_MAX below say so explicitly);
+  * the SAM bound is applied to the reference's STRICT index (eval_hsi.py:47-65); the common-support index replaces it only under the
+    two conditions of helpers.sam_gate (at most two flipped pixels, each at the clamp boundary in both cubes), a strict miss is an
+    xfail of its own (test_strict_sam_index_of_the_headline_mode), and a CONTINUOUS companion - SAM on the un-clamped decoded cubes -
+    is gated on every chain;
   * the benchmark's dispatch (256-cout items on 8 waves, multi-round persistent loops, XCD tile remap) only engages at
     B >= 36: one forward of the shipped UNet at B = 40 against the oracle on the host, with the launch set asserted.
 """
@@ -15,7 +20,8 @@ import pytest
 import torch
 
 from gpu_util import check, fill_synth, log_err
-from helpers import sam_common_support, chain_fixture, jload, load_npz, rel_err, synth_tensor
+from helpers import (chain_fixture, jload, load_npz, reference_unclamped_cube, rel_err, rel_err_unsaturated, sam_common_support,
+                     sam_continuous, sam_gate, synth_tensor)
 from synth import CHAIN_CHIKUSEI, CHAIN_LONG_SET, CHAIN_SET, CHAIN_TUNED_ON
 
 pytestmark = pytest.mark.gpu
@@ -24,9 +30,11 @@ FULL = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, chann
             res_blocks=2, image_size=128)
 # north_star: "Outputs match the reference PyTorch CPU path within 1e-3 relative fp32 (PSNR/SAM within 0.01 dB / 0.001)".
 #   fp32  : meets every bound with four orders of magnitude to spare (bf16 hi + lo operands, three MFMA passes).
-#   fp16  : meets every bound - 11-bit significands, and the weight rounding (the one error that is the same in every step of
-#           the chain: a bias, not noise) removed where the second MFMA pass is nearly free; tests/precision_emul.py reproduces
-#           the device numbers on the host and shows which rounding contributes what.
+#   fp16  : meets every continuous bound - 11-bit significands, the weight rounding (the one error that is the same in every step
+#           of the chain: a bias, not noise) dithered over the steps, the high-gain steps on the fp32 kernel set;
+#           tests/precision_emul.py reproduces the device numbers on the host and shows which rounding contributes what.  The
+#           reference's SAM index is met strictly on eight of the nine chains; on orth:4:20 ONE pixel sits at the index's
+#           discontinuity (see below and test_strict_sam_index_of_the_headline_mode).
 #   bf16  : meets the PSNR bound (0.0012 dB) but neither the latent bound (7.7e-3) nor the SAM bound (0.012 degrees): 8-bit
 #           significands on every MFMA operand and stored activation.  Its gate is the measured value with 2.5x head-room - a
 #           regression gate, NOT a north-star claim (bench.py's `parity` object says meets_north_star: false for it).
@@ -34,8 +42,11 @@ FULL = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, chann
 # A note on dSAM on this fixture: the UNet's weights are synthetic, so the decoded cube is not an image - 55 % of it is clamped
 # to 0, SAM is 56 degrees, and the index (mean angle over pixels whose spectra are non-zero, eval_hsi.py:47-65; 67 all-zero pixels, 113 with one band left) moves by
 # 1.4e-3 degrees whenever ONE pixel's spectrum crosses between all-zero and not.  dSAM therefore counts such crossings rather
-# than measuring an angle: a mode passes when its perturbation (latents ~7e-4) flips none.
+# than measuring an angle: a mode passes when its perturbation (latents ~5e-4) flips none.  The CONTINUOUS companion - the same angle
+# on the un-clamped decoded cubes (ours: the product's decoder on our latents; the reference's: the oracle's decoder, pinned to the
+# reference at 1e-6, on the fixture's latents) - has no support to flip and is gated at the same 0.001 degrees on every chain.
 NORTH_STAR = dict(latents=1e-3, dpsnr=0.01, dsam=0.001)
+DSAM_CONT_MAX = {"fp32": 0.001, "fp16": 0.001, "fp16x2": 0.001, "fp16x1": 0.01, "bf16": 0.03}
 DPSNR_MAX = {"fp32": 0.01, "fp16": 0.01, "fp16x2": 0.01, "fp16x1": 0.01, "bf16": 0.01}
 DSAM_MAX = {"fp32": 0.001, "fp16": 0.001, "fp16x2": 0.001, "fp16x1": 0.01, "bf16": 0.03}
 LATENT_MAX = {"fp32": 1e-3, "fp16": 1e-3, "fp16x2": 1e-3, "fp16x1": 2e-3, "bf16": 2e-2}
@@ -77,43 +88,46 @@ def _run_chain(dev, prec, fixture):
     x_T = G(np.concatenate([cn(gi, 0) for gi in range(ngr)]), dev)                               # [G,3,H,W]
     noise = G(np.stack([np.concatenate([cn(gi, k) for gi in range(ngr)]) for k in range(1, steps)]), dev)
     y, lat = pipeline.super_resolve(m, gd, G(sr, dev), x_T=x_T, noise=noise, precision=prec)
+    y_raw = m.decode_batched(lat, 31)                   # the same decode before sr_gae.py:473-474 clamps it (super_resolve clamps in place)
     torch.cuda.synchronize()
     lat = lat[0].cpu().numpy()
     y = y.cpu().numpy()
     e_lat, e_y = rel_err(lat, g["x0"]), rel_err(y, g["y"])
+    e_unsat, sat_frac = rel_err_unsaturated(lat, g["x0"])
     a = hr[0].transpose(1, 2, 0)
     ref = g["y"][0].transpose(1, 2, 0)
     got = y[0].transpose(1, 2, 0)
     dpsnr = abs(metrics.mpsnr(a, got) - metrics.mpsnr(a, ref))
     dsam = abs(metrics.sam_degrees(a, got) - metrics.sam_degrees(a, ref))
-    flips, dsam_common = sam_common_support(a, got, ref)
+    flips, dsam_common, flip_norm = sam_common_support(a, got, ref, detail=True)
+    ref_raw = reference_unclamped_cube("%s:%d:%d" % fixture, "gae_cav_state.npz", 31, g["x0"], 8, 2)
+    assert rel_err(np.clip(ref_raw, 0.0, 1.0), g["y"][0]) < 2e-5                  # the oracle's decode IS the reference's cube before the clamp
+    dsam_cont = abs(sam_continuous(a, y_raw[0].cpu().numpy().transpose(1, 2, 0)) - sam_continuous(a, ref_raw.transpose(1, 2, 0)))
     # the fixture's own indices were computed by the reference's eval_hsi.py: the oracle's restatements must agree on them
     assert abs(metrics.sam_degrees(a, ref) - float(g["sam"])) < 2e-3
     assert abs(metrics.mpsnr(a, ref) - float(g["mpsnr_formula"])) < 1e-4
     assert np.isfinite(lat).all() and np.isfinite(y).all()
+    gated, strict = sam_gate(dsam, flips, dsam_common, flip_norm)
     rec = {"cube_rel_err": e_y, "dPSNR_dB": dpsnr, "dSAM_deg": dsam, "fixture": "%s:%d:%d" % fixture,
+           "latents_rel_err_unsaturated": e_unsat, "dSAM_unclamped_deg": dsam_cont,
            "psnr_of_ours_vs_reference_cube_dB": metrics.mpsnr(ref, got),         # the reference's decoded cube as the "truth"
            "max_abs_latent_diff": float(np.abs(lat - g["x0"]).max()),
-           "clamped_latent_fraction": float((np.abs(g["x0"]) >= 1.0).mean()),
-           "zero_spectrum_crossings": flips, "dSAM_common_support_deg": dsam_common,
+           "clamped_latent_fraction": sat_frac,
+           "zero_spectrum_crossings": flips, "dSAM_common_support_deg": dsam_common, "flipped_pixel_norm_over_cube_rms": flip_norm,
+           "sam_gate_is_strict_index": strict,
            "meets_north_star": bool(e_lat <= NORTH_STAR["latents"] and e_y <= NORTH_STAR["latents"] and dpsnr <= NORTH_STAR["dpsnr"] and
                                     dsam <= NORTH_STAR["dsam"])}
     log_err("chain_T%d_full_latents" % steps, prec, e_lat, rec)
     LAST_CHAIN_RECORD.clear()
     LAST_CHAIN_RECORD.update(rec, latents_rel_err=e_lat, precision=prec)          # (tools/chain_probe.py prints it)
-    return e_lat, e_y, dpsnr, _sam_gate(dsam, flips, dsam_common)
+    CHAIN_RECORDS[(prec, fixture)] = dict(LAST_CHAIN_RECORD)
+    # the latents are gated on BOTH supports (all elements; the elements the reference did not clamp), the continuous SAM next to the index
+    assert prec not in DSAM_CONT_MAX or dsam_cont <= DSAM_CONT_MAX[prec], (prec, fixture, dsam_cont)
+    return max(e_lat, e_unsat), e_y, dpsnr, gated
 
 
 LAST_CHAIN_RECORD = {}
-
-
-def _sam_gate(dsam, flips, dsam_common):
-    """The value the SAM bound is applied to.  The reference's index skips exactly-zero predicted spectra (eval_hsi.py:57), i.e. it jumps
-    by ~1.4e-3 degrees per pixel whose spectrum is all-zero in one cube and not in the other (helpers.sam_common_support) - a
-    discontinuity of the INDEX at the clamp(0, 1) boundary of the decoded cube, not a deviation of that size: when (and only when)
-    the two cubes disagree about such pixels, the bound is applied to the index over the pixels both cubes keep.  Both numbers and
-    the number of crossings are logged (parity.jsonl: dSAM_deg, dSAM_common_support_deg, zero_spectrum_crossings)."""
-    return dsam if flips == 0 else dsam_common
+CHAIN_RECORDS = {}          # (precision, fixture) -> record, for the strict-index test below
 
 
 @pytest.mark.parametrize("fixture", CHAIN_SET, ids=lambda f: "%s-n%d-T%d" % f)
@@ -139,6 +153,34 @@ def test_full_size_T1000_chain_against_the_reference_run(dev, prec, fixture):
     e_lat, e_y, dpsnr, dsam = _run_chain(dev, prec, fixture)
     assert e_lat < LATENT_MAX[prec] and e_y < LATENT_MAX[prec], (prec, e_lat, e_y)
     assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, dpsnr, dsam, e_lat, e_y)
+
+
+def test_strict_sam_index_of_the_headline_mode(dev):
+    """The reference's OWN SAM index (eval_hsi.py:47-65, strict) on every CAVE chain in the headline mode - the quantity north_star
+    names.  Where the bound is missed, the miss must be the index's discontinuity and nothing else - at most helpers.SAM_MAX_FLIPS
+    pixels whose zero-spectrum membership differs, each with a spectrum norm below helpers.SAM_FLIP_NORM x the cube's rms in both
+    cubes, the index over the common support and the un-clamped (continuous) index inside 0.001 deg - and is then reported as an
+    XFAIL naming the fixture, never absorbed: `pytest -rx` shows it.  (Round 5 / 6 builds: orth:4:20, one pixel whose largest band is
+    1.5e-4 in the reference's cube; strict 1.42e-3 deg, 1.1e-4 on the common support.)"""
+    from helpers import SAM_FLIP_NORM, SAM_MAX_FLIPS
+    misses = []
+    for fixture in tuple(CHAIN_SET) + tuple(CHAIN_LONG_SET):
+        rec = CHAIN_RECORDS.get(("fp16", fixture))
+        if rec is None:
+            _run_chain(dev, "fp16", fixture)
+            rec = CHAIN_RECORDS[("fp16", fixture)]
+        if rec["dSAM_deg"] <= NORTH_STAR["dsam"]:
+            continue
+        # a strict miss: only the discontinuity may explain it
+        assert 0 < rec["zero_spectrum_crossings"] <= SAM_MAX_FLIPS, rec
+        assert rec["flipped_pixel_norm_over_cube_rms"] <= SAM_FLIP_NORM, rec
+        assert rec["dSAM_common_support_deg"] <= NORTH_STAR["dsam"] and rec["dSAM_unclamped_deg"] <= NORTH_STAR["dsam"], rec
+        misses.append("%s: strict dSAM %.2e deg (%d pixel(s) at the clamp boundary, norm %.1e x cube rms; common support %.1e deg, un-clamped "
+                      "%.1e deg)" % (rec["fixture"], rec["dSAM_deg"], rec["zero_spectrum_crossings"], rec["flipped_pixel_norm_over_cube_rms"],
+                                     rec["dSAM_common_support_deg"], rec["dSAM_unclamped_deg"]))
+    log_err("chain_strict_sam_misses", "fp16", float(len(misses)), {"misses": misses})
+    if misses:
+        pytest.xfail("north_star's strict SAM bound (0.001 deg) missed at the index's discontinuity: " + "; ".join(misses))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
@@ -167,18 +209,26 @@ def test_chikusei_chain_against_the_reference_run(dev, prec):
     x_T = G(np.concatenate([chain_noise_draw(draw, gi, 0) for gi in range(ngr)]), dev)
     noise = G(np.stack([np.concatenate([chain_noise_draw(draw, gi, k) for gi in range(ngr)]) for k in range(1, steps)]), dev)
     y, lat = pipeline.super_resolve(m, gd, G(sr, dev), x_T=x_T, noise=noise, precision=prec)
+    y_raw = m.decode_batched(lat, 128)                  # before the clamp of sr_gae.py:473-474
     torch.cuda.synchronize()
     lat, y = lat[0].cpu().numpy(), y.cpu().numpy()
     e_lat, e_y = rel_err(lat, g["x0"]), rel_err(y[:, ::4], g["y_sub4"])
+    e_unsat, sat_frac = rel_err_unsaturated(lat, g["x0"])
     a, got = hr[0].transpose(1, 2, 0), y[0].transpose(1, 2, 0)
     dpsnr = abs(metrics.mpsnr(a, got) - float(g["mpsnr_formula"]))
     dsam = abs(metrics.sam_degrees(a, got) - float(g["sam_oracle"]))
     assert abs(float(g["sam_oracle"]) - float(g["sam"])) < 2e-3                        # the restatement against the reference's eval_hsi on its cube
+    # the continuous companion of the index (un-clamped cubes; the fixture stores a quarter of the reference's CLAMPED cube: the oracle's
+    # decode of the reference's latents is checked against it first)
+    ref_raw = reference_unclamped_cube("chi:%s:%d:%d" % CHAIN_CHIKUSEI, "gae_chi_state.npz", 128, g["x0"], 16, 4)
+    assert rel_err(np.clip(ref_raw[::4], 0.0, 1.0), g["y_sub4"][0]) < 2e-5
+    dsam_cont = abs(sam_continuous(a, y_raw[0].cpu().numpy().transpose(1, 2, 0)) - sam_continuous(a, ref_raw.transpose(1, 2, 0)))
     log_err("chain_chikusei_T20_latents", prec, e_lat, {"cube_rel_err_every_4th_band": e_y, "dPSNR_dB": dpsnr, "dSAM_deg": dsam,
-                                                        "fixture": "chi:%s:%d:%d" % CHAIN_CHIKUSEI})
+                                                        "latents_rel_err_unsaturated": e_unsat, "clamped_latent_fraction": sat_frac,
+                                                        "dSAM_unclamped_deg": dsam_cont, "fixture": "chi:%s:%d:%d" % CHAIN_CHIKUSEI})
     assert np.isfinite(lat).all() and np.isfinite(y).all()
-    assert e_lat < LATENT_MAX[prec] and e_y < LATENT_MAX[prec], (prec, e_lat, e_y)
-    assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec], (prec, dpsnr, dsam)
+    assert max(e_lat, e_unsat) < LATENT_MAX[prec] and e_y < LATENT_MAX[prec], (prec, e_lat, e_unsat, e_y)
+    assert dpsnr <= DPSNR_MAX[prec] and dsam <= DSAM_MAX[prec] and dsam_cont <= DSAM_CONT_MAX[prec], (prec, dpsnr, dsam, dsam_cont)
 
 
 @pytest.mark.parametrize("prec", ["fp16x2", "fp16x1"])
@@ -392,6 +442,85 @@ def test_precision_schedule_runs_the_high_gain_steps_on_the_fp32_kernels(dev):
     assert torch.isfinite(a.x).all() and a.steps_done == T + 8
 
 
+def _tiny_gd(dev, T, prec="fp16", seed_prefix="unet_tiny."):
+    from hsi_dmgasr_amd.sr3_modules import diffusion, unet
+    u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
+                  image_size=16, precision=prec).to(dev).eval()
+    fill_synth(u, seed_prefix)
+    gd = diffusion.GaussianDiffusion(u, image_size=16, channels=3, conditional=True)
+    gd.set_loss(dev)
+    gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2), dev)
+    return gd
+
+
+def test_captured_steps_are_reused_by_the_next_p_sample_loop_call(dev):
+    """The reference's validation loop calls p_sample_loop once per image and group (sr_gae.py:458-465); a fresh ReverseRun pays five
+    eager steps and five graph captures (fp32 set + four dither phases), half of the shipped 20-step chain.  GaussianDiffusion keeps
+    the finished call's slot (static buffers + graphs + pool): the next call on the same shapes copies its inputs in and replays from
+    its FIRST step - same graphs, results bit-identical to an eager (graph-free) run of the same inputs; a call with other inputs in
+    between does not leak into it; changed weights drop the slot; the results handed out are copies, not the slot's buffers."""
+    T, B = 20, 3
+    gd = _tiny_gd(dev, T)
+    eager = _tiny_gd(dev, T)
+    eager.use_graph = False
+    cond = [G(synth_tensor("slot.cond%d" % i, (B, 3, 16, 16)), dev) for i in range(2)]
+    x_T = [G(synth_tensor("slot.xT%d" % i, (B, 3, 16, 16)), dev) for i in range(2)]
+    noise = [G(synth_tensor("slot.noise%d" % i, (T - 1, B, 3, 16, 16)), dev) for i in range(2)]
+    want = [eager.p_sample_loop_batched(cond[i], x_T=x_T[i], noise=noise[i]) for i in range(2)]
+    a0 = gd.p_sample_loop_batched(cond[0], x_T=x_T[0], noise=noise[0])
+    assert len(gd._graph_cache) == 1 and not gd._graph_cache[0].busy
+    slot = gd._graph_cache[0]
+    graphs = dict(slot.graphs)
+    assert set(graphs) == {"fp32", "fp16d0", "fp16d1", "fp16d2", "fp16d3"}
+    keep = a0.clone()
+    b1 = gd.p_sample_loop_batched(cond[1], x_T=x_T[1], noise=noise[1])        # other inputs through the SAME slot: replays only
+    a2 = gd.p_sample_loop_batched(cond[0], x_T=x_T[0], noise=noise[0])
+    torch.cuda.synchronize()
+    assert len(gd._graph_cache) == 1 and gd._graph_cache[0] is slot and all(slot.graphs[k] is g for k, g in graphs.items())
+    assert torch.equal(a0, keep) and a0.data_ptr() != slot.x.data_ptr()         # the first call's result was a copy: the later calls did not touch it
+    assert torch.equal(a0, want[0]) and torch.equal(b1, want[1]) and torch.equal(a2, want[0])
+    # the stock entry points go through the same slots (continous: the snapshots are copied out too)
+    gd.noise, gd.seed = eager.noise, eager.seed = "philox", 11
+    r1 = gd.p_sample_loop(cond[0], continous=True)
+    r2 = gd.p_sample_loop(cond[0], continous=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2) and torch.equal(r1, eager.p_sample_loop(cond[0], continous=True)) and len(gd._graph_cache) == 2
+    # new weights: the slots' graphs address the old packed weights and are dropped, the next call captures afresh
+    other = _tiny_gd(dev, T, seed_prefix="unet_tiny_b.")
+    gd.denoise_fn.load_state_dict(other.denoise_fn.state_dict())
+    other.use_graph = False
+    c = gd.p_sample_loop_batched(cond[0], x_T=x_T[0], noise=noise[0])
+    torch.cuda.synchronize()
+    assert slot not in gd._graph_cache and torch.equal(c, other.p_sample_loop_batched(cond[0], x_T=x_T[0], noise=noise[0]))
+    assert not torch.equal(c, a0)
+    # a sampler switch re-points the coefficient tables: no slot survives it
+    gd.set_sampler("ddim", steps=10)
+    assert gd._graph_cache == []
+
+
+def test_graphs_of_one_pool_replay_in_another_order_than_they_were_captured(dev):
+    """The kernel sets of a chain (fp32 + four dither phases) are captured into ONE memory pool: each replay may overwrite what the
+    others left behind, which is safe only while nothing allocated inside a capture outlives it except through the static buffers.
+    A 22-step chain with wrap captures in the order fp32, d0, d1, d2, d3 and, from the second lap on, replays ... d0, d1 | fp32 x 8, d0
+    ... - d1 followed by fp32, an order no capture saw; three laps against the same chain run eagerly (graph-free) on the same Philox
+    noise must be bit-identical."""
+    T, B = 22, 4
+    gd, eager = _tiny_gd(dev, T), _tiny_gd(dev, T)
+    eager.use_graph = False
+    for g in (gd, eager):
+        g.noise, g.seed = "philox", 23
+    cond = G(synth_tensor("pool.cond", (B, 3, 16, 16)), dev)
+    a, b = gd.make_run(cond, wrap=True), eager.make_run(cond, wrap=True)
+    assert a.modes[8:] == ["fp16d%d" % (k % 4) for k in range(8, T)] and a.modes[-1] == "fp16d1"
+    with torch.no_grad():
+        for lap in range(3):
+            for _ in range(T):
+                a.step(); b.step()
+            torch.cuda.synchronize()
+            assert torch.equal(a.x, b.x), lap
+    assert len(a.graphs) == 5 and not b.graphs
+
+
 def test_sharded_driver_under_an_rccl_group_of_one(dev):
     """pipeline.super_resolve_sharded with the default process group initialised on RCCL ("nccl", world size 1): same
     cubes as super_resolve."""
@@ -478,9 +607,13 @@ def test_bench_line_is_the_compact_contract_object(tmp_path):
     cfg = d["config"]
     assert cfg["batch_per_gpu"] == 60 and "workload" in cfg and "model" not in cfg
     assert abs(d["value"] - 20 * 60 / (d["ms_per_step"] * 20e-3)) < 1e-3 * d["value"]
-    # the four fp32-mode steps of the chain sit in the warm-up of a 20-step window: the line says so and gives the per-chain mix
-    assert cfg["fp32_mode_steps_in_window"] == 0 and cfg["ms_per_step_chain_mix"] > d["ms_per_step"] * 0.999
-    assert cfg["value_chain_mix"] < d["value"] * 1.001
+    # the policy's eight fp32-set steps of a chain sit in the warm-up of a 20-step window: the line says so, and `value` IS the per-chain
+    # mix (992 window steps + 8 fp32-set steps per 1000), not the optimistic window rate, which stays in config; the same policy on the
+    # reference's shipped 20-step chain is reported beside it
+    assert cfg["fp32_mode_steps_in_window"] == 0 and cfg["value_is"].startswith("per-chain mix")
+    assert d["value"] == cfg["value_chain_mix"] and d["ms_per_step"] == cfg["ms_per_step_chain_mix"]
+    assert cfg["value_window"] > d["value"] and cfg["ms_per_step_window"] < d["ms_per_step"] < cfg["ms_per_step_fp32_set"]
+    assert 0.3 * d["value"] < cfg["value_T20"] < d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["launches"] >= 1 and rf["avg_launch_us"] > 0 and rf["algorithmic_flops_per_launch"] > 0
@@ -488,9 +621,10 @@ def test_bench_line_is_the_compact_contract_object(tmp_path):
     assert 0.05 < rf["whole_step"]["frac"] < rf["frac"] + 0.2 and rf["conv_v3_family"]["launches"] == 10
     assert rf["fused_resnetblock_hbm_frac"] < rf["resnetblock_launch_hbm_frac"]
     par = d["parity"]
-    # (orth:4:20 - a hold-out - sits at the SAM index's discontinuity: one pixel's zero-spectrum membership differs, see _sam_gate)
+    # (orth:4:20 - a hold-out - sits at the SAM index's discontinuity: one pixel's zero-spectrum membership differs, see helpers.sam_gate)
     assert par["mode"] == "fp16" and par["meets_north_star_with_sam_on_common_support"] is True and par["n_fixtures"] == 9
-    assert par["meets_north_star"] is (par["sam_support_flips"] == 0 or par["dSAM_deg"] <= 1e-3)
+    assert par["meets_north_star"] is (par["dSAM_deg"] <= 1e-3) and par["meets_north_star"] is (par["strict_sam_misses"] == [])
+    assert par["latents_rel_err"] <= par["latents_rel_err_unsaturated"] < 1e-3 and par["dSAM_unclamped_deg"] <= 1e-3
     assert any("T1000" in k for k in par["worst_of"])
     assert par["latents_rel_err"] < 1e-3 and par["cube_rel_err"] < 1e-3 and par["dSAM_deg_on_common_support"] <= 1e-3 and par["dPSNR_dB"] <= 0.01
     assert d["meets_north_star"] is par["meets_north_star"]

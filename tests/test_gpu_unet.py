@@ -257,8 +257,8 @@ def test_bare_module_calls_in_the_default_mode(dev, ops_npz):
 @pytest.mark.parametrize("name", ["tiny", "mid", "wide_nonsquare"])
 def test_headline_mode_chain_on_the_other_networks(dev, name):
     """north_star's quantity - the OUTPUT of the reverse chain - in the headline (fp16) mode on the network configurations whose single
-    forward on the fp16 kernel set sits at 1.07e-3 ... 1.17e-3 (KERNEL_SET_FWD_FP16 above): a 20-step cosine chain (Philox noise; the mode's four
-    high-gain steps on the fp32-mode kernels, sixteen on the fp16 kernels) against the oracle's chain, held to 1e-3.  The oracle's
+    forward on the fp16 kernel set sits at 1.07e-3 ... 1.17e-3 (KERNEL_SET_FWD_FP16 above): a 20-step cosine chain (Philox noise; the policy's eight
+    high-gain steps on the fp32 kernel set, twelve on the dithered one-pass fp16 sets) against the oracle's chain, held to 1e-3.  The oracle's
     forward is pinned to the reference's for these configurations (unets.npz; the non-square one is the shipped channel plan)."""
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
     from oracle import diffusion as odiff, sr3_unet

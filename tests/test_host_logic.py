@@ -318,7 +318,9 @@ def test_bench_contract_line_stays_compact():
             "config": {"workload": "SR3 UNet 97.8M (6->3 ch, inner 64, mults 1-2-4-8-8, attn@16) p_sample step on GAE latents 3x128x128, "
                                    "cosine T=1000, BASELINE configs[3]", "patches_per_gpu": 48, "total_patches": 384, "groups_per_patch": 5,
                        "batch_per_gpu": 240, "global_batch": 1920, "parallelism": "dp8", "precision_mode": max(bench.DTYPE.values(), key=len),
-                       "warmup_steps_run": 16, "fp32_mode_steps_in_window": 4, "ms_per_step_chain_mix": big, "value_chain_mix": big},
+                       "warmup_steps_run": 16, "fp32_mode_steps_in_window": 4, "value_is": "per-chain mix of the measured step times",
+                       "value_window": big, "ms_per_step_window": big, "ms_per_step_chain_mix": big, "value_chain_mix": big,
+                       "ms_per_step_fp32_set": big, "value_T20": big},
             "rccl_ranks": 8, "allgather_ms": big, "rank_ms_per_step": {"min": big, "max": big}}
     row = dict(kernel=kern, launches=20, ms_per_step=big, avg_launch_us=big, tflops=big, frac=0.123456789)
     roof = dict(bound="mfma", kernel=kern, launches=20, avg_launch_us=big, algorithmic_flops_per_launch=big * 1e7,
@@ -328,8 +330,10 @@ def test_bench_contract_line_stays_compact():
                 hbm_view=dict(frac=0.27, fused_unit=dict(frac=0.128), note="z" * 500), kernels=[dict(row) for _ in range(14)],
                 all_conv_kernels=dict(launches=94), best_launch=dict(cin=1024), mfma_passes_per_product="1.5 on ...")
     fx = {"%s:n%d:T%d" % (w, n, t): dict(latents_rel_err=5e-4, cube_rel_err=5e-4, dPSNR_dB=1e-5, dSAM_deg=1e-4)
-          for w, n, t in (("synth", 0, 20), ("orth", 0, 20), ("orth", 1, 20), ("synth", 1, 20), ("orth", 2, 1000), ("synth", 3, 1000), ("chi:orth", 3, 20))}
-    parity = {"fixtures": "t" * 700, "fp16": dict(latents_rel_err=5.75e-4, cube_rel_err=6.3e-4, dPSNR_dB=6e-5, dSAM_deg=7.1e-4, fixtures=fx,
+          for w, n, t in (("synth", 0, 20), ("orth", 0, 20), ("orth", 1, 20), ("synth", 1, 20), ("orth", 4, 20), ("synth", 5, 20), ("orth", 2, 1000),
+                          ("synth", 3, 1000), ("chi:orth", 3, 20))}
+    parity = {"fixtures": "t" * 700, "fp16": dict(latents_rel_err=5.75e-4, latents_rel_err_unsaturated=8.23456789e-4, cube_rel_err=6.3e-4, dPSNR_dB=6e-5,
+                                                    dSAM_deg=7.1e-4, dSAM_unclamped_deg=1.23456789e-5, strict_sam_misses=["orth:n4:T20", "synth:n5:T20"], fixtures=fx,
                                                     n_fixtures=len(fx), meets_north_star=False, sam_support_flips=3,
                                                     dSAM_deg_on_common_support=1.23456789e-4, meets_north_star_with_sam_on_common_support=True)}
     cases = {"batch_%d" % b: dict(value=big, s_per_step=big, steps=42, seconds=big, segment_rates=[big] * 3) for b in (1, 5)}
@@ -349,7 +353,7 @@ def test_bench_contract_line_stays_compact():
         assert k in rf, k
     assert isinstance(rf["traffic"], float) and "kernels" not in rf and "hbm_view" not in rf
     assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "cases"} and set(back["cpu_baseline"]["cases"]) == {"batch_1", "batch_5"}
-    assert "fixtures" not in back["parity"] and back["parity"]["n_fixtures"] == 7 and back["parity"]["meets_north_star"] is False and back["parity"]["meets_north_star_with_sam_on_common_support"] is True
+    assert "fixtures" not in back["parity"] and back["parity"]["n_fixtures"] == 9 and back["parity"]["strict_sam_misses"] == ["orth:n4:T20", "synth:n5:T20"] and back["parity"]["meets_north_star"] is False and back["parity"]["meets_north_star_with_sam_on_common_support"] is True
     # without the optional objects (N > 1 ranks, --no-* flags) the line is the head alone
     assert bench.compact_line(head) == head
 
@@ -419,8 +423,18 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
         with pytest.raises(ValueError, match="experimental"):
             P.set_default_precision("bf16")
         assert P.resolve_precision(None) == "fp16" and P.resolve_precision("fp32") == "fp32"
+        # one kernel set of the policy is not a mode either: "fp16d<k>" only resolves inside the sampler's per-step dispatch (a module
+        # built on it by name would skip the policy's fp32-set steps and the gain-1 widening of bare forwards)
+        for call in (P.resolve_precision, P.set_default_precision):
+            with pytest.raises(ValueError, match="kernel set of the"):
+                call("fp16d1")
+        with P.internal_names():
+            assert P.resolve_precision("fp16d1") == "fp16d1"
+        with pytest.raises(ValueError):
+            P.resolve_precision("fp16d7")                                  # (no such phase)
     finally:
         P.allow_experimental(was)
+    assert P.resolve_precision("fp16d1") == "fp16d1"                   # (experimental sets allowed: by name, like the others)
     assert P.resolve_precision("bf16") == "bf16"                       # (conftest.py: the suite measures them as regression gates)
     # the "fp16" policy: a chain step by its gain, a bare forward (gain 1) on the fp32 kernel set; named sets stay as named
     assert P.step_precision("fp16", 0.24, 7) == "fp16d3" and P.step_precision("fp16", 0.26) == "fp32" and P.step_precision("fp32", 9.0) == "fp32"
@@ -559,11 +573,13 @@ def test_sparse_low_half_packing_matches_the_measured_operand_semantics():
 
 
 def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent_kernel():
-    """A ResnetBlock's block2 conv packed together with its 1x1 res_conv (reference unet.py:102-103,110) for an fp16 hi + lo layer: the
-    register-streaming order gets 9 steps per 64-channel chunk of the 3x3 conv followed by ONE step per chunk of the projection, and the
-    projection's steps carry log2(e) (conv_v3.hip, PROJ: the SiLU staging leaves that factor on every product of the launch and the
-    epilogue removes it from the accumulators); hi + lo + the 2:4-sparse low halves describe the same scaled weights; the order the
-    LDS-tiled kernel reads stays unscaled; the biases are summed.  A layer without hi + lo weights (bf16) is packed unscaled."""
+    """A ResnetBlock's block2 conv packed together with its 1x1 res_conv (reference unet.py:102-103,110) for a 64-cout slice (conv_v3's
+    PROJ forms): the register-streaming order gets 9 steps per 64-channel chunk of the 3x3 conv followed by THREE projection steps -
+    one per 64-channel chunk of the projection, zero steps behind them (the one-pass kernel pulls three steps through its 3-step
+    weight ring at every item, whatever the projection's width) - and the projection's steps carry log2(e) (the SiLU staging leaves
+    that factor on every product of the launch and the epilogue removes it from the accumulators); with hi + lo weights, hi + lo + the
+    2:4-sparse low halves describe the same scaled weights; the order the LDS-tiled kernel reads stays unscaled and unpadded; the
+    biases are summed.  One-pass sets (bf16, a dithered fp16 set) get the same steps without low halves."""
     from hsi_dmgasr_amd import ops
     g = torch.Generator().manual_seed(11)
     co, ci, pc = 64, 64, 72                       # 72 projection channels: two chunks, the second with 8 live channels
@@ -572,7 +588,7 @@ def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent
     b, bp = torch.randn(co, generator=g), torch.randn(co, generator=g)
     pk = ops.PackedConv(w, b, "fp16", proj_weight=wp, proj_bias=bp)
     assert pk.wide and pk.proj_cin == pc and torch.allclose(pk.bias, b + bp)
-    nst = 9 * 1 + 2
+    nst = 9 * 1 + 3
     assert pk.w_v2.shape[0] == nst and pk.w_v2_lo.shape == pk.w_v2.shape and pk.w_v2_ls.shape[0] == nst and pk.w_v2_li.shape[0] == nst
     # undo _lanes: [step][cout/32][kk][h][r][8] -> [step][cout][64]
     def unlane(t):
@@ -581,13 +597,18 @@ def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent
     both = unlane(pk.w_v2.double() + pk.w_v2_lo.double())
     want3 = w.double().reshape(co, ci, 9).permute(2, 0, 1)                          # [tap][cout][cin]
     assert float((both[:9] - want3).abs().max()) < 1e-7
-    wpad = torch.zeros(co, 128, dtype=torch.float64)
+    wpad = torch.zeros(co, 192, dtype=torch.float64)
     wpad[:, :pc] = wp.double().reshape(co, pc) * ops.LOG2E
-    wantp = wpad.reshape(co, 2, 64).permute(1, 0, 2)                                # [chunk][cout][64]
+    wantp = wpad.reshape(co, 3, 64).permute(1, 0, 2)                                # [chunk][cout][64]
     assert float((both[9:] - wantp).abs().max()) < 2e-7
-    assert float(both[10, :, 8:].abs().max()) == 0.0                                # zero weights behind the 72nd channel
+    assert float(both[10, :, 8:].abs().max()) == 0.0 and float(both[11].abs().max()) == 0.0   # zero weights behind the 72nd channel, a zero third step
     # the LDS-tiled kernel's order: unscaled
     raw = pk.w_hi.double() + pk.w_lo.double()                                       # [step][cout_pad][64]
     assert float((raw[9, :, :64] - wp.double().reshape(co, pc)[:, :64]).abs().max()) < 1e-7
-    pk16 = ops.PackedConv(w, b, "bf16", proj_weight=wp, proj_bias=bp)
-    assert not pk16.wide and pk16.w_v2 is None                                      # (64 couts: no split-K form, nothing reads a w_v2 with projection steps)
+    assert pk.w_hi.shape[0] == 9 + 2
+    for mode, dt in (("bf16", torch.bfloat16), ("fp16d2", torch.float16)):          # one-pass sets: the same steps, no low halves
+        pk1 = ops.PackedConv(w, b, mode, proj_weight=wp, proj_bias=bp)
+        assert not pk1.wide and pk1.w_v2.dtype == dt and pk1.w_v2.shape[0] == nst and pk1.w_v2_lo is None and pk1.w_v2_ls is None
+        one = unlane(pk1.w_v2.double())
+        tol = (2.0 ** -8 if mode == "bf16" else 2.0 ** -10) * 1.01               # one rounding (the dithered set: up to 7/8 ulp)
+        assert float((one[9:] - wantp).abs().max()) <= tol * float(wantp.abs().max()) and float(one[11].abs().max()) == 0.0

@@ -5,6 +5,6 @@ steps=${STEPS:-200}; rounds=${ROUNDS:-2}
 for r in $(seq $rounds); do
   for lib in "" "$@"; do
     if [ -z "$lib" ]; then tag=base; unset HSIDM_LIB; else tag=$(basename $lib); export HSIDM_LIB=$PWD/$lib; fi
-    python bench.py --precision ${PREC:-fp16} --steps $steps --warmup 10 --no-cpu-baseline --no-roofline --no-parity 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('$tag', round(d['ms_per_step'],3), 'ms/step', round(d['value'],1))"
+    python bench.py --precision ${PREC:-fp16} --steps $steps --warmup 10 --no-cpu-baseline --no-roofline --no-parity 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); c=d.get('config',{}); print('$tag', round(c.get('ms_per_step_window') or d['ms_per_step'],3), 'ms/step (timed window)', round(c.get('value_window') or d['value'],1))"
   done
 done
