@@ -98,7 +98,7 @@ struct DebugTable {
         auto env_int = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
         v[hsidm::DBG_NO_V3] = getenv("HSIDM_NO_V3") ? 1 : 0;
         v[hsidm::DBG_V2_BN256] = env_int("HSIDM_V2_BN256", 1);
-        v[hsidm::DBG_ATTENTION_V1] = getenv("HSIDM_ATTENTION_V1") ? 1 : 0;
+        v[hsidm::DBG_ATTENTION_V1] = env_int("HSIDM_ATTENTION_V1", 0);      // 1: the score-panel kernel, 2: attention_v2 (A/B against attention_v3)
         v[hsidm::DBG_NO_XCD_MAP] = getenv("HSIDM_NO_XCD_MAP") ? 1 : 0;
         const char* e = getenv("HSIDM_1X1");
         v[hsidm::DBG_1X1_V1] = (e && e[0] == 'v') ? 1 : 0;

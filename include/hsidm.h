@@ -126,12 +126,17 @@ typedef struct hsidm_conv_desc {
                                  (csrc/conv_sk.hip) for launches with few pixel tiles and a long contraction -
                                  the 8x8 / 16x16 levels at small batches; NULL: the persistent kernels only.
                                  With nphase == 2 and w_v2 (its steps: 9 per chunk of phase 0, then 1 per chunk of
-                                 phase 1) two w_v2 kernels apply: the split form - ask hsidm_conv_workspace_bytes first -
-                                 and, for HSIDM_F16 descriptors with w_v2_lo + w_v2_ls / w_v2_li, Cout == 64, GN + SiLU on
-                                 phase 0, whole 16x16 tiles and no residual, the persistent kernel's projection form
-                                 (csrc/conv_v3.hip, PROJ: hsidm_conv_kernel_id(d) & 15 == 4); its phase-1 steps of w_v2 /
-                                 w_v2_lo / w_v2_ls carry the projection's weights times log2(e) (the kernel removes the
-                                 factor its SiLU staging leaves on every product).  Neither: launch the projection separately */
+                                 phase 1) two w_v2 kernels apply: the split form (bn == 128) - ask hsidm_conv_workspace_bytes
+                                 first - and, for 16-bit descriptors with Cout == 64 (bn == 64), GN + SiLU on phase 0, whole
+                                 16x16 tiles and no residual, the persistent kernel's projection forms (csrc/conv_v3.hip, PROJ:
+                                 hsidm_conv_kernel_id(d) & 15 == 4; the ResnetBlock's res_conv of reference unet.py:102-103,110
+                                 inside block2's launch): one-pass weights (no w_v2_lo; HSIDM_BF16 | HSIDM_F16) with
+                                 at most 192 projection channels, or HSIDM_F16 with w_v2_lo + w_v2_ls / w_v2_li.  For bn == 64
+                                 the phase-1 steps of w_v2 (/ w_v2_lo / w_v2_ls) carry the projection's weights times log2(e)
+                                 (the kernel removes the factor its SiLU staging leaves on every product) and are padded with
+                                 zero steps to THREE per item: w_v2 holds 9 * chunks(phase 0) + 3 steps (the one-pass form pulls
+                                 three steps per item through its weight ring, whatever the projection's width; w_hi / w_lo, the
+                                 LDS-tiled kernel's order, stay unscaled and unpadded).  Neither: launch the projection separately */
     int64_t workspace_bytes;
     const void*  w_v2_lo;     /* optional (HSIDM_F16 with w_v2): fp16(W - fp16(W)) in the layout of w_v2 - the weights then carry
                                  ~18-19 significant bits (the low halves are fp16 subnormals for |w| < 0.125: absolute granularity 6e-8) for twice the matrix instructions (the weight rounding

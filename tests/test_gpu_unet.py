@@ -6,7 +6,7 @@ import torch
 
 from gpu_util import assert_stats, check, fill_synth
 from hsi_dmgasr_amd import _lib
-from helpers import jload, load_npz, sub_shapes, synth_sd, synth_tensor
+from helpers import jload, load_npz, rel_err, sub_shapes, synth_sd, synth_tensor
 
 pytestmark = pytest.mark.gpu
 
@@ -465,22 +465,32 @@ def test_strided_ddim_sampler_in_the_default_mode(dev, steps, eta):
 @pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96), (136, 16, 16, 128),
                                    (260, 8, 8, 64), (3, 16, 16, 64)])
 def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
-    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (N = 64 / 256, C % 64 == 0; 136 / 260 images: more
-    workgroups than CUs), the panel kernel it replaces (other shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same bf16
-    inputs."""
+    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (attention_v3: N = 64 / 256, C % 64 == 0, 64 queries per
+    wave pair - keys split over the pair in the score phase, the row maxima / sums and the probabilities exchanged through LDS, channels
+    split in the output phase; 136 / 260 images: more workgroups than CUs), the form it replaced (attention_v2, HSIDM_ATTENTION_V1=2:
+    one 32-query group per wave, no exchange - the two agree to the rounding of the stored element type), the panel kernel (other
+    shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same 16-bit inputs, in both element types."""
     from hsi_dmgasr_amd import ops
     B, H, W, C = shape
     g = torch.Generator().manual_seed(sum(shape))
-    qkv = (torch.randn(B, H, W, 3 * C, generator=g) * 1.5).to(torch.bfloat16)
-    q, k, v = qkv.float().reshape(B, H * W, 3, C).unbind(2)
-    ref = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
-    got = ops.attention(qkv.to(dev), "bf16")
-    torch.cuda.synchronize()
-    with _lib.debug_switch("ATTENTION_V1", 1):
-        old = ops.attention(qkv.to(dev), "bf16")
+    raw = torch.randn(B, H, W, 3 * C, generator=g) * 1.5
+    for mode, dt, tol in (("bf16", torch.bfloat16, 1e-2), ("fp16x1", torch.float16, 1.5e-3)):
+        qkv = raw.to(dt)
+        q, k, v = qkv.float().reshape(B, H * W, 3, C).unbind(2)
+        ref = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
+        got = ops.attention(qkv.to(dev), mode)
         torch.cuda.synchronize()
-    check("attention%s" % (shape,), "bf16", got.reshape(B, H * W, C), ref, tol=1e-2)
-    check("attention_panel%s" % (shape,), "bf16", old.reshape(B, H * W, C), ref, tol=1e-2)
+        with _lib.debug_switch("ATTENTION_V1", 1):
+            old = ops.attention(qkv.to(dev), mode)
+            torch.cuda.synchronize()
+        with _lib.debug_switch("ATTENTION_V1", 2):
+            v2 = ops.attention(qkv.to(dev), mode)
+            torch.cuda.synchronize()
+        check("attention%s" % (shape,), mode, got.reshape(B, H * W, C), ref, tol=tol)
+        check("attention_panel%s" % (shape,), mode, old.reshape(B, H * W, C), ref, tol=tol)
+        check("attention_v2%s" % (shape,), mode, v2.reshape(B, H * W, C), ref, tol=tol)
+        # same products, same fp32 softmax; only the order of the row sum differs (lane halves, then the pair): one ulp of the store
+        assert rel_err(got.float().cpu().numpy(), v2.float().cpu().numpy()) < (4e-3 if mode == "bf16" else 5e-4)
 
 
 
