@@ -219,6 +219,10 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
 //   * K and V stream through a double-buffered LDS image in 64-channel chunks with row-contiguous 16-byte loads, shared
 //     by the 4 waves (128 queries) of the workgroup: K and V are read twice per image instead of eight times;
 //   * O^T tiles have the query on the lane and 4 consecutive channels per register quad: 8-byte stores, no epilogue pass.
+// Round 6: what bounds it at the benchmark's batch is HBM, not LDS or the matrix pipe - 32 GFLOP over 378 MB (NW = 4: K and V are read by
+// both workgroups of an image) or 252 MB (NW = 8: one workgroup per image) is 85 / 128 FLOP per byte against a ridge of 312.  A form in
+// which every LDS operand fed two MFMAs (64 queries per wave pair, the probabilities exchanged through LDS; git history: "attention_v3")
+// halved the LDS reads and ran 7 % SLOWER; reading K and V once is worth 8 % (profiles/r06_attention/ab_forms.txt).
 #ifndef HSIDM_ATT_VRS
 #define HSIDM_ATT_VRS 80
 #endif
@@ -370,233 +374,6 @@ static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStre
     if (int rc = raise_lds_cap(once, &attention_v2_kernel<NKT, NW, E>, lds)) return rc;
     dim3 grid(NKT / NW, B);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW, E>), grid, dim3(64 * NW), lds, s, (const E*)qkv, (E*)out, C,
-                       1.0f / sqrtf((float)C));
-    return (int)hipGetLastError();
-}
-
-// ---- attention_v3 (round 6; 16-bit element types, N = 32*NKT keys, C % 64 == 0): 64 queries per wave PAIR -------------------------------
-// What held attention_v2 at 19 % of the matrix peak (profiles/r03_attention: pipe busy 22.8 % at N = 256) is LDS bandwidth: in both phases
-// every MFMA takes a fresh 1 KB operand from LDS (a K fragment in phase 1, a transposed V fragment in phase 2) while the other operand -
-// one 32-query group - sits in registers: four SIMDs x 1 KB per 32-cycle MFMA is the CU's 128 B/clk with the pipe at 100 %.  Here every
-// LDS fragment feeds TWO MFMAs:
-//   * two waves share 64 queries (two 32-query groups, both in registers).  Phase 1 splits the KEYS over the pair - wave h owns key
-//     tiles h*NKT/2 .. - so a K fragment multiplies both query groups: the same 128 score registers per lane, half the LDS reads;
-//   * the row softmax stays exact and in fp32: per query the maximum and the sum are combined across the lane halves as before, then
-//     across the pair through LDS (two barriers);
-//   * the probabilities are exchanged ONCE (each wave hands its P^T fragments - already in operand order - to the same lanes of its
-//     partner through LDS, two rounds through the K buffer the phase has just freed), so that phase 2 splits the CHANNELS instead of
-//     the keys: wave h owns channels 32 h .. of every 64-channel chunk, and a transposed V fragment multiplies both query groups.
-// Matrix instructions per wave as before (32 per chunk and phase); LDS operand reads halved; K and V staging, layouts, the accumulator-
-// tile-as-operand order and the 8-byte stores are attention_v2's.
-template <int NKT, int NW, typename E>
-__global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attention_v3_kernel(const E* __restrict__ qkv, E* __restrict__ out, int C, float scale) {
-    using ex8 = typename Elem<E>::x8;
-    using ex4 = typename Elem<E>::x4;
-    static_assert(NKT % 2 == 0 && NW % 2 == 0, "key tiles and waves come in pairs");
-    constexpr int N = 32 * NKT, T = 64 * NW, NV = N * 8 / T, KH = NKT / 2;
-    constexpr int KRS = 72, VRS = 80;                       // (attention_v2_kernel: row pitches of the K / V images)
-    constexpr int BUFE = N * VRS;
-    constexpr int NFR = KH * 2 * 2;                         // P^T fragments a wave hands over: [key tile][k-step][query group]
-    constexpr int NR = (NW * NFR > 64) ? 4 : 2, FPR = NFR / NR;   // exchange rounds / fragments per round (1 KB per wave and fragment)
-    static_assert(NFR % NR == 0 && (size_t)NW * FPR * 1024 + (size_t)NW * 64 * 4 * 2 <= (size_t)BUFE * 2, "the exchange fits one K buffer");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* buf = reinterpret_cast<E*>(smem_raw);                // [2][BUFE]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave >> 1, wh = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.y, q0 = blockIdx.x * 32 * NW + 64 * pair;
-    const size_t row3 = (size_t)3 * C;
-    const E* base = qkv + (size_t)b * N * row3;
-    const int nch = C >> 6;
-
-    u32x4 hreg[NV];
-    auto issue = [&](int chunk, int third) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * T;
-            hreg[i] = *reinterpret_cast<const u32x4*>(base + (size_t)(v >> 3) * row3 + third * C + chunk * 64 + (v & 7) * 8);
-        }
-    };
-    auto commit = [&](int bi, int rs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * T;
-            *reinterpret_cast<u32x4*>(buf + bi * BUFE + (v >> 3) * rs + (v & 7) * 8) = hreg[i];
-        }
-    };
-
-    // ---- phase 1: S^T[key][query] = K Q^T for this wave's KH key tiles and both query groups, 32 channels per trip ------------------------
-    const E* qrow = base + (size_t)(q0 + lr) * row3 + 8 * lh;            // query group g: + 32 g rows
-    ex8 qf[2][2], qn[2][2];                                               // [k-step of the 32-channel half][query group]
-    auto q_load = [&](ex8 (&dst)[2][2], int hc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) dst[kk][g] = *reinterpret_cast<const ex8*>(qrow + (size_t)(32 * g) * row3 + hc * 32 + kk * 16);
-    };
-    q_load(qf, 0);
-    issue(0, 1);
-    commit(0, KRS);
-    __syncthreads();
-    f32x16 sc[KH][2];
-#pragma unroll
-    for (int kt = 0; kt < KH; ++kt)
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sc[kt][g][j] = 0.f;
-    for (int chunk = 0; chunk < nch; ++chunk) {
-        const bool more = chunk + 1 < nch;
-        if (more) issue(chunk + 1, 1);
-        const E* kb = buf + (chunk & 1) * BUFE + (wh * KH * 32 + lr) * KRS + 8 * lh;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int hc = 2 * chunk + half;
-            if (hc + 1 < 2 * nch) q_load(qn, hc + 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int kt = 0; kt < KH; ++kt) {
-                    const ex8 a = *reinterpret_cast<const ex8*>(kb + kt * 32 * KRS + half * 32 + kk * 16);
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) sc[kt][g] = Elem<E>::mfma(a, qf[kk][g], sc[kt][g]);
-                }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) qf[kk][g] = qn[kk][g];
-        }
-        if (more) commit((chunk + 1) & 1, KRS);
-        __syncthreads();
-    }
-
-    // ---- exact softmax over ALL keys of each of this lane's two queries (fp32): lane halves, then the wave pair through LDS ----------------
-    issue(0, 2);                                            // V chunk 0 is on its way meanwhile
-    // the buffer the last K chunk did NOT use is the one V chunk 0 goes to; the last chunk's own buffer (every wave is behind the loop's
-    // final barrier: nobody reads it any more) carries the pair exchanges
-    const int vb0 = nch & 1;                                // V chunk c lives in buffer (c + vb0) & 1
-    unsigned char* xreg = smem_raw + (size_t)(vb0 ^ 1) * BUFE * 2;
-    float* red = reinterpret_cast<float*>(xreg + (size_t)NW * FPR * 1024);             // [2][NW][64]
-    float m[2], inv[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        float mm = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < KH; ++kt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { sc[kt][g][j] *= scale; mm = fmaxf(mm, sc[kt][g][j]); }
-        mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
-        m[g] = mm;
-        if (lh == 0) red[wave * 64 + 32 * g + lr] = mm;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        m[g] = fmaxf(m[g], red[(wave ^ 1) * 64 + 32 * g + lr]);
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KH; ++kt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { sc[kt][g][j] = __expf(sc[kt][g][j] - m[g]); sum += sc[kt][g][j]; }
-        sum += __shfl_xor(sum, 32, 64);
-        inv[g] = sum;
-        if (lh == 0) red[NW * 64 + wave * 64 + 32 * g + lr] = sum;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 2; ++g) inv[g] = 1.0f / (inv[g] + red[NW * 64 + (wave ^ 1) * 64 + 32 * g + lr]);
-    // P^T fragments of ALL key tiles for both query groups: this wave's half from its scores, the partner's through LDS (same lane, same
-    // fragment index: a straight copy - the fragments are already in the matrix instruction's operand order, attention_v2_kernel)
-    ex8 pf[NKT][2][2];
-#pragma unroll
-    for (int kt = 0; kt < KH; ++kt)
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[kt][st][g][j] = (E)(sc[kt][g][8 * st + j] * inv[g]);
-    // (own fragments sit at index kt = 0 .. KH-1 for now; moved to their key tiles' places after the exchange)
-    ex8* xs = reinterpret_cast<ex8*>(xreg);                 // [NW][FPR][64 lanes]
-#pragma unroll
-    for (int rnd = 0; rnd < NR; ++rnd) {
-#pragma unroll
-        for (int f = 0; f < FPR; ++f) {
-            const int fi = rnd * FPR + f;                   // fragment (kt, st, g) = (fi / 4, (fi / 2) % 2, fi % 2)
-            xs[(wave * FPR + f) * 64 + lane] = pf[fi >> 2][(fi >> 1) & 1][fi & 1];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int f = 0; f < FPR; ++f) {
-            const int fi = rnd * FPR + f;
-            pf[KH + (fi >> 2)][(fi >> 1) & 1][fi & 1] = xs[((wave ^ 1) * FPR + f) * 64 + lane];
-        }
-        __syncthreads();
-    }
-    // key-tile order: wave 0 of a pair owns tiles 0 .. KH-1 (already in place), wave 1 tiles KH .. (swap the two halves)
-    if (wh) {
-#pragma unroll
-        for (int kt = 0; kt < KH; ++kt)
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const ex8 t = pf[kt][st][g];
-                    pf[kt][st][g] = pf[KH + kt][st][g];
-                    pf[KH + kt][st][g] = t;
-                }
-    }
-    commit(vb0, VRS);
-    __syncthreads();
-
-    // ---- phase 2: O^T[channel][query] = V^T P^T: this wave's 32 channels of every 64-channel chunk, both query groups -------------------------
-    const int gi = lane & 15;
-    const int tr_lane = (4 * lh + (gi >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (gi & 3);   // this lane's address duty in its 16-lane group
-    E* orow = out + ((size_t)b * N + q0 + lr) * C + 32 * wh + 4 * lh;
-    for (int chunk = 0; chunk < nch; ++chunk) {
-        const bool more = chunk + 1 < nch;
-        if (more) issue(chunk + 1, 2);
-        const E* vb = buf + ((chunk + vb0) & 1) * BUFE + tr_lane + 32 * wh;
-        f32x16 o[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) o[g][j] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
-                const E* a0 = vb + (kt * 32 + st * 16) * VRS;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 8 * VRS));
-                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int g = 0; g < 2; ++g) o[g] = Elem<E>::mfma(__builtin_bit_cast(ex8, both), pf[kt][st][g], o[g]);
-            }
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int jg = 0; jg < 4; ++jg) {
-                ex4 w4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w4[e] = (E)Elem<E>::sat(o[g][4 * jg + e]);
-                *reinterpret_cast<ex4*>(orow + (size_t)(32 * g) * C + chunk * 64 + 8 * jg) = w4;
-            }
-        if (more) commit((chunk + 1 + vb0) & 1, VRS);
-        __syncthreads();
-    }
-}
-
-template <int NKT, int NW, typename E>
-static int launch_attention_v3(const void* qkv, void* out, int B, int C, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * 32 * NKT * 80 * 2;
-    static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &attention_v3_kernel<NKT, NW, E>, lds)) return rc;
-    dim3 grid(NKT / NW, B);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v3_kernel<NKT, NW, E>), grid, dim3(64 * NW), lds, s, (const E*)qkv, (E*)out, C,
                        1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
@@ -789,23 +566,21 @@ static int launch_attention_v2_f32(const void* qkv, void* out, int B, int C, hip
 extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int N, int C, void* stream) {
     if (!qkv || !out || B <= 0 || N <= 0 || C <= 0 || (C & 31)) return HSIDM_E_BADARG;
     if (N > 1024) return HSIDM_E_UNSUPPORTED;
-    // (diagnostic A/B switches: HSIDM_ATTENTION_V1=1 the score-panel kernel, =2 attention_v2 - one 32-query group per wave)
+    // N = 256: ONE workgroup of 8 waves per image when the batch fills at least half of the CUs with such workgroups - K and V are then
+    // read once per image instead of once per 128-query workgroup (-33 % of the launch's bytes, -8 % of its time at 240 images: the launch
+    // is HBM-bound, 128 FLOP per byte; profiles/r06_attention/ab_forms.txt) - else two workgroups of 4 waves (more workgroups in flight).
+    // (diagnostic A/B switches: HSIDM_ATTENTION_V1=1 the score-panel kernel, =2 the 4-wave form whatever the batch)
     const int att = hsidm::debug_get(hsidm::DBG_ATTENTION_V1);
+    const bool one_wg = att != 2 && 2 * B >= hsidm::device_cus();
     if (prec == HSIDM_BF16 && (C & 63) == 0 && att != 1) {
-        if (N == 256 && att == 3) return hsidm::launch_attention_v2<8, 8, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 256 && att == 4) return hsidm::launch_attention_v3<8, 8, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 256) return att == 2 ? hsidm::launch_attention_v2<8, 4, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream)
-                                      : hsidm::launch_attention_v3<8, 4, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 64) return att == 2 ? hsidm::launch_attention_v2<2, 2, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream)
-                                     : hsidm::launch_attention_v3<2, 2, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256) return one_wg ? hsidm::launch_attention_v2<8, 8, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream)
+                                    : hsidm::launch_attention_v2<8, 4, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 64) return hsidm::launch_attention_v2<2, 2, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
     }
     if (prec == HSIDM_F16 && (C & 63) == 0 && att != 1) {
-        if (N == 256 && att == 3) return hsidm::launch_attention_v2<8, 8, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 256 && att == 4) return hsidm::launch_attention_v3<8, 8, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 256) return att == 2 ? hsidm::launch_attention_v2<8, 4, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream)
-                                      : hsidm::launch_attention_v3<8, 4, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
-        if (N == 64) return att == 2 ? hsidm::launch_attention_v2<2, 2, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream)
-                                     : hsidm::launch_attention_v3<2, 2, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256) return one_wg ? hsidm::launch_attention_v2<8, 8, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream)
+                                    : hsidm::launch_attention_v2<8, 4, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 64) return hsidm::launch_attention_v2<2, 2, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
     }
     if (prec == HSIDM_F16) return hsidm::launch_attention<hsidm::f16, false, hsidm::f16>(qkv, out, B, N, C, (hipStream_t)stream);
     if (prec == HSIDM_BF16) return hsidm::launch_attention<hsidm::bf16, false>(qkv, out, B, N, C, (hipStream_t)stream);

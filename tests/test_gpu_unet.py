@@ -465,11 +465,10 @@ def test_strided_ddim_sampler_in_the_default_mode(dev, steps, eta):
 @pytest.mark.parametrize("shape", [(3, 16, 16, 512), (2, 8, 8, 128), (5, 8, 8, 64), (2, 16, 16, 64), (1, 4, 8, 96), (136, 16, 16, 128),
                                    (260, 8, 8, 64), (3, 16, 16, 64)])
 def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
-    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (attention_v3: N = 64 / 256, C % 64 == 0, 64 queries per
-    wave pair - keys split over the pair in the score phase, the row maxima / sums and the probabilities exchanged through LDS, channels
-    split in the output phase; 136 / 260 images: more workgroups than CUs), the form it replaced (attention_v2, HSIDM_ATTENTION_V1=2:
-    one 32-query group per wave, no exchange - the two agree to the rounding of the stored element type), the panel kernel (other
-    shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same 16-bit inputs, in both element types."""
+    """softmax(q k^T / sqrt(C)) v on random qkv: the register-resident kernel (attention_v2: N = 64 / 256, C % 64 == 0; at N = 256 one
+    8-wave workgroup per image from 128 images on - 136 images - else two of 4 waves, HSIDM_ATTENTION_V1=2; 260 images at N = 64: more
+    workgroups than CUs), the panel kernel (other shapes, and HSIDM_ATTENTION_V1=1) and torch fp32 on the same 16-bit inputs, in
+    both element types; the two workgroup shapes compute the same products in the same order: bit-identical."""
     from hsi_dmgasr_amd import ops
     B, H, W, C = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -488,9 +487,8 @@ def test_attention_core_matches_torch_and_v1(dev, shape, monkeypatch):
             torch.cuda.synchronize()
         check("attention%s" % (shape,), mode, got.reshape(B, H * W, C), ref, tol=tol)
         check("attention_panel%s" % (shape,), mode, old.reshape(B, H * W, C), ref, tol=tol)
-        check("attention_v2%s" % (shape,), mode, v2.reshape(B, H * W, C), ref, tol=tol)
-        # same products, same fp32 softmax; only the order of the row sum differs (lane halves, then the pair): one ulp of the store
-        assert rel_err(got.float().cpu().numpy(), v2.float().cpu().numpy()) < (4e-3 if mode == "bf16" else 5e-4)
+        check("attention_4wave%s" % (shape,), mode, v2.reshape(B, H * W, C), ref, tol=tol)
+        assert torch.equal(got, v2)
 
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the attention kernel forms at the benchmark's shape (240 images, N = 256, C = 512): HSIDM_ATTENTION_V1 switch values
-0 attention_v3<8,4>, 2 attention_v2<8,4>, 3 attention_v2<8,8> (one workgroup per image: K and V read once), 4 attention_v3<8,8>.
-Prints us per launch (best of 8) and the deviation from torch fp32 on the same fp16 inputs."""
+"""A/B of the attention kernel's workgroup shapes at the benchmark's shape (240 images, N = 256, C = 512): HSIDM_ATTENTION_V1 switch
+values 0 the dispatch's choice (one 8-wave workgroup per image from 128 images on: K and V read once), 2 two 4-wave workgroups per
+image, 1 the score-panel kernel.  Prints us per launch (best of 8) and the deviation from torch fp32 on the same fp16 inputs.
+(Round 6's A/B also had attention_v3 - 64 queries per wave pair - under switch values 0 / 4: profiles/r06_attention/ab_forms.txt.)"""
 import os
 import sys
 
@@ -17,7 +18,7 @@ g = torch.Generator().manual_seed(0)
 qkv = (torch.randn(B, hw, hw, 3 * C, generator=g) * 1.5).to(torch.float16).to(dev)
 q, k, v = qkv[:4].float().reshape(4, hw * hw, 3, C).unbind(2)
 ref = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
-for att in (0, 2, 3, 4, 0, 2, 3, 4):
+for att in (0, 2, 1, 0, 2, 1):
     with _lib.debug_switch("ATTENTION_V1", att):
         best = 1e9
         for _ in range(8):
