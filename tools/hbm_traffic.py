@@ -32,8 +32,8 @@ def label(name):
         return "conv_igemm bn%d %s k%d s%d%s" % (bn, "8x8x2" if ni == 2 else "8x16", ks, st, " nchw" if nchw else "")
     if "conv_v3_kernel" in name:
         nchw = "<1, true" in name or "ILi1ELb1E" in name
-        # the projection form (PROJ, last template argument): mangled "...Lb1ELb1EEE" = <..., SPL = true, PROJ = true>
-        proj = bool(re.search(r"Lb1ELb1EEEvNS_12ConvV2Params", name)) or bool(re.search(r"true, true>\s*\(", name))
+        # the projection forms (PROJ, last template argument): mangled "...Lb0ELb1EEE" / "...Lb1ELb1EEE" = <..., SPL, PROJ = true>
+        proj = bool(re.search(r"Lb[01]ELb1EEEvNS_12ConvV2Params", name)) or bool(re.search(r"(true|false), true>\s*\(", name))
         return "conv_v3 bn32 8x16 k3 s1 gn+silu nchw" if nchw else ("conv_v3 bn64 8x16 k3 s1 gn+silu" + (" +proj" if proj else ""))
     return None
 
