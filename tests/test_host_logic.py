@@ -612,3 +612,66 @@ def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent
         one = unlane(pk1.w_v2.double())
         tol = (2.0 ** -8 if mode == "bf16" else 2.0 ** -10) * 1.01               # one rounding (the dithered set: up to 7/8 ulp)
         assert float((one[9:] - wantp).abs().max()) <= tol * float(wantp.abs().max()) and float(one[11].abs().max()) == 0.0
+
+
+def test_sam_gate_and_the_continuous_companions_of_the_parity_checks():
+    """The parity helpers the -m gpu chain tests and bench.py gate with (tests/helpers.py; bench.py restates two of them on torch tensors):
+    (1) sam_gate applies north_star's SAM bound to the reference's STRICT index unless at most SAM_MAX_FLIPS pixels flipped their
+    zero-spectrum membership AND each of them has a spectrum norm <= SAM_FLIP_NORM x the cube's rms in both cubes; (2) on a cube with one
+    boundary pixel sam_common_support counts one flip with a tiny relative norm, and a pixel that lost a REAL spectrum shows a large one;
+    (3) sam_continuous = the reference's index (oracle.metrics.sam_degrees) when no spectrum is zero; (4) rel_err_unsaturated ignores
+    the elements the reference clamped; (5) bench.py's torch restatements agree with the numpy ones."""
+    import helpers as H
+    from oracle import metrics
+    bench = _load_bench()
+    assert H.sam_gate(1.4e-3, 0, 9.0, 0.0) == (1.4e-3, True)                          # no flips: the strict index, whatever the other value
+    assert H.sam_gate(1.4e-3, 1, 1.1e-4, 3.9e-4) == (1.1e-4, False)                   # one boundary pixel: the common-support index
+    assert H.sam_gate(1.4e-3, 2, 1.1e-4, 1.0e-3) == (1.1e-4, False)
+    assert H.sam_gate(1.4e-3, 3, 1.1e-4, 3.9e-4) == (1.4e-3, True)                    # too many flips: strict
+    assert H.sam_gate(1.4e-3, 1, 1.1e-4, 2.0e-3) == (1.4e-3, True)                    # a flipped pixel with a real spectrum: strict
+    rng = np.random.default_rng(5)
+    truth = rng.uniform(0.1, 1.0, (16, 16, 31)).astype(np.float32)
+    ref = np.clip(truth + 0.05 * rng.standard_normal(truth.shape).astype(np.float32), 0.0, 1.0)
+    ref[3, 4] = 0.0
+    ref[3, 4, 7] = 1.5e-4                                                               # one band left, at the clamp boundary
+    got = ref + 1e-4 * rng.standard_normal(ref.shape).astype(np.float32)
+    got = np.clip(got, 0.0, 1.0)
+    got[3, 4] = 0.0                                                                     # ... and clamped away in the other cube
+    flips, d_common, worst = H.sam_common_support(truth, got, ref, detail=True)
+    rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    assert flips == 1 and abs(worst - 1.5e-4 / rms) < 1e-6 and worst < H.SAM_FLIP_NORM
+    d_strict = abs(metrics.sam_degrees(truth, got) - metrics.sam_degrees(truth, ref))
+    assert d_strict > 5 * d_common                                                      # the strict index jumps by (angle - mean) / N, the common one does not
+    assert H.sam_gate(d_strict, flips, d_common, worst) == (d_common, False)
+    lost = got.copy()
+    lost[9, 9] = 0.0                                                                    # a pixel that lost a real spectrum: a deviation, not a boundary effect
+    f2, _, w2 = H.sam_common_support(truth, lost, ref, detail=True)
+    assert f2 == 2 and w2 > 1.0 and H.sam_gate(1.0, f2, 0.0, w2) == (1.0, True)
+    dense = np.clip(ref, 1e-3, 1.0)
+    assert abs(H.sam_continuous(truth, dense) - metrics.sam_degrees(truth, dense)) < 1e-4
+    neg = dense - 0.5                                                                   # un-clamped cubes carry negative values: still defined, still continuous
+    assert abs(H.sam_continuous(truth, neg + 1e-6) - H.sam_continuous(truth, neg)) < 1e-3
+    b = np.array([1.0, -1.0, 0.5, -0.25, 1.0, 0.1], dtype=np.float32)
+    a = b + np.array([0.0, 0.0, 1e-3, -1e-3, 0.0, 2e-3], dtype=np.float32)
+    e_un, sat = H.rel_err_unsaturated(a, b)
+    assert abs(sat - 0.5) < 1e-9 and abs(e_un - np.linalg.norm([1e-3, 1e-3, 2e-3]) / np.linalg.norm([0.5, 0.25, 0.1])) < 1e-6
+    assert H.rel_err(a, b) < 0.35 * e_un                                                # the saturated elements flatter the plain figure
+    # bench.py's torch forms ([1, C, H, W] tensors)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)[None]))
+    bf, bd, bw = bench.sam_support(T(truth), T(got), T(ref))
+    assert bf == flips and abs(bd - d_common) < 1e-4 and abs(bw - worst) < 1e-6 and (bench.SAM_MAX_FLIPS, bench.SAM_FLIP_NORM) == (H.SAM_MAX_FLIPS, H.SAM_FLIP_NORM)
+    assert abs(bench.sam_unclamped(T(truth), T(neg)) - H.sam_continuous(truth, neg)) < 1e-4
+
+
+def test_the_oracle_decode_of_a_fixtures_latents_is_the_references_cube_before_the_clamp():
+    """The continuous SAM companion compares UN-CLAMPED cubes; the reference side of it is the oracle's decode of the fixture's reference
+    latents (helpers.reference_unclamped_cube).  Clamped to [0, 1] (sr_gae.py:473-474) it must BE the cube the reference stored - on a
+    CAVE chain and on the Chikusei chain (every fourth band stored)."""
+    import helpers as H
+    from synth import CHAIN_CHIKUSEI
+    g = H.load_npz("chains/orth_n4_T20.npz")
+    raw = H.reference_unclamped_cube("cpu:orth:4:20", "gae_cav_state.npz", 31, g["x0"], 8, 2)
+    assert raw.shape == g["y"][0].shape and float(raw.min()) < -0.5 and H.rel_err(np.clip(raw, 0.0, 1.0), g["y"][0]) < 2e-5
+    gc = H.load_npz("chains/chi_%s_n%d_T%d.npz" % CHAIN_CHIKUSEI)
+    rawc = H.reference_unclamped_cube("cpu:chi", "gae_chi_state.npz", 128, gc["x0"], 16, 4)
+    assert H.rel_err(np.clip(rawc[::4], 0.0, 1.0), gc["y_sub4"][0]) < 2e-5
