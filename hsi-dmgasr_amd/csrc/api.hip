@@ -175,12 +175,11 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
     if (is16(d->prec) && d->w_v2 && d->out_nchw && d->nphase == 1 && d->stride == 1 && d->ksize == 3 && !d->ups &&
         xf == HSIDM_XF_AFFINE_SILU && d->bn == 32 && d->Cout <= 16 && Hout % 16 == 0 && Wout % 16 == 0 && !d->film && !d->res &&
         !d->stats && d->act == HSIDM_ACT_NONE && !debug_get(DBG_NO_V3)) path = PATH_V3;
-    // A fused 1x1 projection (nphase == 2) on a persistent kernel: the sparse-lo form of conv_v3 (fp16 hi + lo layers, 64 couts, whole
-    // 16x16 tiles) walks it as more one-tap chunks; everything else with a projection stays on the split-K or the LDS-tiled kernel
-    // (one-pass weights - bf16, the fp16 policy's dithered sets: the dense form, at most three projection chunks; fp16 hi + lo weights: the sparse-lo form)
-    const bool v3_proj_w = d->w_v2_lo ? (d->prec == HSIDM_F16 && d->w_v2_ls && d->w_v2_li && !debug_get(DBG_NO_SPARSE_LO))
-                                      : (d->ph[1].C0 + d->ph[1].C1 <= 192);
-    const bool v3_proj = d->nphase == 2 && is16(d->prec) && d->w_v2 && v3_proj_w && !d->out_nchw &&
+    // A fused 1x1 projection (nphase == 2) on a persistent kernel: conv_v3's one-pass 64-cout forms (whole 16x16 tiles) walk it as up to
+    // three more one-tap chunks; everything else with a projection stays on the split-K or the LDS-tiled kernel
+    // (one-pass weights only - bf16, the fp16 policy's dithered sets - and at most three projection chunks; a layer with hi + lo weights keeps
+    // its projection a launch of its own: round 4's sparse-lo projection form was retired with the policy that needed it)
+    const bool v3_proj = d->nphase == 2 && is16(d->prec) && d->w_v2 && !d->w_v2_lo && d->ph[1].C0 + d->ph[1].C1 <= 192 && !d->out_nchw &&
                          d->stride == 1 && d->ksize == 3 && !d->ups && xf == HSIDM_XF_AFFINE_SILU && d->bn == 64 && d->Cout == 64 &&
                          Hout % 16 == 0 && Wout % 16 == 0 && !d->res && (d->ph[0].C0 + d->ph[0].C1) % 64 == 0 &&
                          !debug_get(DBG_NO_V3) && !debug_get(DBG_NO_FUSED_PROJ);

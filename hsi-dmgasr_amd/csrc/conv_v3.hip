@@ -56,9 +56,10 @@ static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 // the low halves lose the smaller two of every four values: 20 % of their energy, i.e. of a 2^-12 correction (tests/precision_emul.py,
 // w=x2s: the 20-step chain moves from 5.38e-4 to 5.50e-4).  Sub-steps run in the order (tap, row r, slice q): the tap's four dense
 // weight fragments stay in registers for both rows; two register sets alternate between taps, one tap of lookahead.
-// PROJ (with SPL): the launch also carries a ResnetBlock's 1x1 residual projection (hsidm_conv_desc.ph[1]; reference unet.py:102-103,110) as
-// pchunks more 64-channel chunks of ONE tap accumulated into the same tile - see "PROJ" at issue_all / commit_all / the matrix phase.  In-box
-// A/B and the in-kernel stamps of the projection chunks: profiles/r04_final/ab_fused_proj.txt, stamps_v3_proj.txt.
+// PROJ (one-pass forms: NP = 1, WN = 2): the launch also carries a ResnetBlock's 1x1 residual projection (hsidm_conv_desc.ph[1]; reference
+// unet.py:102-103,110) as up to three more 64-channel chunks of ONE tap accumulated into the same tile - see "PROJ" at issue_all /
+// commit_all and the three static slots behind the 9-tap loop.  (Round 4 built it for the sparse-lo form - the kernel set the benchmark ran then;
+// profiles/r04_final/ab_fused_proj.txt, stamps_v3_proj.txt - round 6 for the one-pass sets and retired the sparse combination.)
 typedef _Float16 f16x16v __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int WN_, bool NCHW_, typename E = bf16, int NP = 1, bool SPL = false, bool PROJ = false>
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
     static_assert(!SPL || (NP == 2 && WN_ == 2 && !NCHW_ && !__is_same(E, bf16)), "sparse low halves: fp16, two passes, the 64-cout form");
-    static_assert(!PROJ || SPL || (NP == 1 && WN_ == 2 && !NCHW_), "fused 1x1 projection: the sparse-lo form and the one-pass 64-cout forms");
+    static_assert(!PROJ || (!SPL && NP == 1 && WN_ == 2 && !NCHW_), "fused 1x1 projection: the one-pass 64-cout forms");
     constexpr bool FRG = NP == 2 && !SPL;
     constexpr int FS = 6, FL = 4;                               // a k-slice pair keeps its two fragments for both row halves: FL <= FS - 2
     constexpr int WN = WN_, WM = 4 / WN_, MR = 8 / WM;          // a wave owns 16 / WM tile rows = MR MFMA tiles of two rows
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         float ep_add[2] = {0.f, 0.f}, ep_bias[2] = {0.f, 0.f};  // FiLM / bias of the lane's couts [16-cout half]: loaded in the last chunk
         f32x4 ep4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // SPL: bias + FiLM of couts 16 nh + 4g .. + 3, loaded in the epilogue
 
-        // (one-pass PROJ forms: the 9-tap loop covers the 3x3 chunks, the projection's chunks follow as three static slots below)
-        const int n_loop = (PROJ && !SPL) ? nch : nct;
+        // (PROJ: the 9-tap loop covers the 3x3 chunks, the projection's chunks follow as three static slots below)
+        const int n_loop = PROJ ? nch : nct;
         for (int chunk = 0; chunk < n_loop; ++chunk) {
             commit_all(chunk >= nch);                           // hreg holds (item, chunk): transform -> LDS
             if (chunk == 0) HSIDM_STAMP(it, 1);
@@ -383,53 +384,6 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) a[w % 2][mr] = *reinterpret_cast<const x8*>(halo + abase[mr] + off);
                 };
-                if constexpr (PROJ) {
-                    // A projection chunk's raw pixels were committed one halo row and column further in (commit_all), so that tap 8 - offset
-                    // (2, 2) - reads the tile's own pixels: the chunk is the LAST tap of this same loop (register set 0, next weights into set 1)
-                    const bool pj = chunk >= nch;
-                    auto tap_run = [&](int tap) __attribute__((always_inline)) {
-                    const int set = tap & 1;
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int w = tap * 4 + kk, r = kk >> 1, q = kk & 1;
-                        if (q == 0) a_fetch(w + 1);
-                        s_issue(tap == 8 ? 1 : set ^ 1, kk);       // the next tap's weights (tap 8: the next chunk's first tap, moved to set 0 below)
-                        if (q == 0 && tap == 0 && chunk == 0) {   // first use of these accumulators: C = 0 as the inline constant (uniform branch)
-                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                                for (int mr = 0; mr < MR; ++mr) acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + nh : 0], a[w % 2][mr], zero);
-                        } else {
-#pragma unroll
-                            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                                for (int mr = 0; mr < MR; ++mr)
-                                    acc[mr][r][nh] = EL::mfma16(whi[SPL ? set * 4 + 2 * q + nh : 0], a[w % 2][mr], acc[mr][r][nh]);
-                        }
-                        if (q == 1) {                             // the tap's 64 channels of row r against the sparse low halves
-#pragma unroll
-                            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                                for (int mr = 0; mr < MR; ++mr) {
-                                    const f16x16v bb = __builtin_shufflevector(a[(w + 1) % 2][mr], a[w % 2][mr], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-                                    if (nh == 0) acc[mr][r][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 : 0], bb, acc[mr][r][0], wli[SPL ? set : 0], 0, 0);
-                                    else         acc[mr][r][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wls[SPL ? set * 2 + 1 : 0], bb, acc[mr][r][1], wli[SPL ? set : 0], 0, 1);
-                                }
-                            if (w + 1 < 36) a_fetch(w + 1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    };
-                    if (!pj) {
-                        a_fetch(0);
-#pragma unroll
-                        for (int tap = 0; tap < 8; ++tap) tap_run(tap);
-                    } else {
-                        a_fetch(32);
-                    }
-                    tap_run(8);
-                } else {            // (the plain form keeps the loop the allocator was tuned on: at 256 registers any change of shape moves the spills)
                 a_fetch(0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -465,7 +419,6 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
                 }
                 // nine taps per chunk: the prefetch of tap 8 went to set 1, where tap 0 of the next chunk expects set 0
 #pragma unroll
@@ -525,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             if (chunk == 0) HSIDM_STAMP(it, 5);
             if (PROJ && chunk == nch) HSIDM_STAMP(it, 10);
         }
-        if constexpr (PROJ && !SPL) {
+        if constexpr (PROJ) {
             // ---- the ResnetBlock's 1x1 projection of a second input (hsidm_conv_desc.ph[1]; reference unet.py:102-103,110) as up to THREE
             // more one-tap chunks accumulated into the same tile.  A projection chunk's raw 16 x 16 pixels are committed one halo row and
             // column further in than their place in the halo tile (commit_all), so the offsets of tap 8 - (2, 2) - read them; its weight
@@ -774,15 +727,10 @@ int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, int spl, hipStream_
     p.stamps = g_stamps;
     int G = (p.total_items < g3_slots ? p.total_items : g3_slots) / 8 * 8;
     if (G == 0) G = p.total_items;
-    if (p.pchunks > 0) {        // fused 1x1 projection (api.hip: v3_proj): the one-pass 64-cout forms and the sparse-lo form
-        if (nchw) return HSIDM_E_UNSUPPORTED;
-        if (np == 1) {
-            if (p.pchunks > 3) return HSIDM_E_UNSUPPORTED;
-            p.steps_per_item = 9 * p.nchunks + 3;               // three projection steps per item in the packed weights, whatever pchunks (zero padded)
-            return elem ? launch_v3<2, false, f16, 1, false, true>(p, G, s) : launch_v3<2, false, bf16, 1, false, true>(p, G, s);
-        }
-        if (elem == 1 && np == 2 && spl) return launch_v3<2, false, f16, 2, true, true>(p, G, s);
-        return HSIDM_E_UNSUPPORTED;
+    if (p.pchunks > 0) {        // fused 1x1 projection (api.hip: v3_proj): the one-pass 64-cout forms
+        if (nchw || np != 1 || p.pchunks > 3) return HSIDM_E_UNSUPPORTED;
+        p.steps_per_item = 9 * p.nchunks + 3;                   // three projection steps per item in the packed weights, whatever pchunks (zero padded)
+        return elem ? launch_v3<2, false, f16, 1, false, true>(p, G, s) : launch_v3<2, false, bf16, 1, false, true>(p, G, s);
     }
     if (elem == 0 && np == 1) return nchw ? launch_v3<1, true, bf16, 1>(p, G, s) : launch_v3<2, false, bf16, 1>(p, G, s);
     if (elem == 1 && np == 1) return nchw ? launch_v3<1, true, f16, 1>(p, G, s) : launch_v3<2, false, f16, 1>(p, G, s);

@@ -58,8 +58,8 @@ def pack_layouts(weight, precision, proj_weight=None, out_nchw=False, fold_ups=F
     # bn == 64 (conv_v3's PROJ forms; proj_scale = log2(e)): the projection steps of the register-streaming order carry log2(e) - the
     # persistent kernels stage log2(e) * silu(.) and undo the factor on the accumulators, i.e. on the projection's products too - and
     # are padded with zero steps to THREE per item (conv_v3.hip: the one-pass form pulls three steps through its 3-step weight ring
-    # whatever the projection's width, so that the ring's phase is the same at every item; the sparse-lo form walks the real ones
-    # only); the "w" order, which the LDS-tiled kernel reads, stays unscaled and unpadded
+    # whatever the projection's width, so that the ring's phase is the same at every item); the "w" order, which the LDS-tiled kernel
+    # reads, stays unscaled and unpadded
     if b16 and proj_weight is not None and kh == 3 and not out_nchw and (bn == 128 or (bn == 64 and proj_scale != 1.0)):
         steps = lay["w"]
         if proj_scale != 1.0:
@@ -127,8 +127,8 @@ class PackedConv:
         dev = weight.device
         cout, cin, ksz = weight.shape[0], weight.shape[1], weight.shape[2]
         wide16 = _lib.prec_id(precision) == _lib.F16 and wide_weights(precision, cout, cin + (-cin) % 8, ksz)
-        # (a fused projection on a 64-cout slice is conv_v3's: its steps carry log2(e), see pack_layouts)
-        v3_proj = proj_weight is not None and _lib.prec_id(precision) != _lib.F32X3 and pick_bn(cout, out_nchw) == 64
+        # (a fused projection on a 64-cout slice of a one-pass layer is conv_v3's: its steps carry log2(e), see pack_layouts)
+        v3_proj = proj_weight is not None and _lib.prec_id(precision) != _lib.F32X3 and pick_bn(cout, out_nchw) == 64 and not wide16
         lay, meta = pack_layouts(weight.detach().float(), precision, None if proj_weight is None else proj_weight.detach().float(),
                                  out_nchw, fold_ups, fold_dn, proj_scale=LOG2E if v3_proj else 1.0)
         self._set_meta(meta, precision, out_nchw)
@@ -233,7 +233,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
 
     sk_only: launch only if the dispatch takes its split-K form (few pixel tiles, long contraction), else return None - how a
     ResnetBlock offers its fused-projection descriptor to the kernels of the throughput modes that accept one; fused_only: likewise
-    for the persistent kernel's projection form (fp16 hi + lo layers: conv_v3.hip, PROJ).
+    for the persistent kernel's projection form (one-pass 64-cout layers: conv_v3.hip, PROJ).
 
     stats=True: the kernel also writes per-(image, tile part, channel) sums of `out`; they ride on the returned
     tensor as ``out._hsidm_stats = (slab [B, nsplit, C, 2], nsplit)`` and feed gn_scale_shift / ca_vector."""
@@ -370,15 +370,14 @@ def set_fused_proj(flag):
     _fused_proj = bool(flag)
 
 
-def use_fused_proj(wide=False):
-    """Is the persistent kernel's projection form on offer (wide: for a layer with fp16 hi + lo weights - the sparse-lo form)?  The
-    host switch AND the library's own switches (hsidm_debug_query: NO_FUSED_PROJ / NO_V3 / NO_SPARSE_LO): asked BEFORE a ResnetBlock
-    computes a GroupNorm table or packs the projection layouts for the offer, so that a refused offer costs nothing (A/B runs through
-    the debug switches stay clean)."""
+def use_fused_proj():
+    """Is the persistent kernel's projection form (conv_v3, PROJ: one-pass 64-cout layers) on offer?  The host switch AND the library's
+    own switches (hsidm_debug_query: NO_FUSED_PROJ / NO_V3): asked BEFORE a ResnetBlock computes a GroupNorm table or packs the
+    projection layouts for the offer, so that a refused offer costs nothing (A/B runs through the debug switches stay clean)."""
     if not _fused_proj:
         return False
     L = _lib.lib()
-    return not any(L.hsidm_debug_query(name) for name in ((b"NO_FUSED_PROJ", b"NO_V3") + ((b"NO_SPARSE_LO",) if wide else ())))
+    return not any(L.hsidm_debug_query(name) for name in (b"NO_FUSED_PROJ", b"NO_V3"))
 
 
 def set_fold_ups(flag):

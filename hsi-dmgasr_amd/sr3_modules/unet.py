@@ -220,14 +220,13 @@ class ResnetBlock(_HipModule):
                         return out
                 # 64-cout layers on whole 16x16 tiles (the 128x128 level): the projection as one-tap chunks of block2's own launch
                 # (conv_v3.hip, PROJ) - no separate GEMM, no round trip of its result through HBM.  One-pass weight sets
-                # (bf16, the fp16 policy's dithered sets): at most three 64-channel chunks, i.e. every projection of the shipped UNet's
-                # 128x128 level (192 -> 64, 128 -> 64); fp16 hi + lo layers: the sparse-lo form.
+                # (bf16, the fp16 policy's dithered sets, fp16x1), at most three 64-channel chunks: every projection of the shipped
+                # UNet's 128x128 level (192 -> 64, 128 -> 64).  A layer with hi + lo weights (the experimental two-pass sets) keeps the GEMM.
                 # (every condition the dispatch checks is checked HERE first - api.hip, v3_proj - so a refused offer never costs a
                 # second GroupNorm table or dead packed layouts)
                 cx = x0.shape[3] + (0 if x1 is None else x1.shape[3])
-                wide = wide_weights(precision, h.shape[3], h.shape[3], 3)
                 if h.dtype in (torch.float16, torch.bfloat16) and h.shape[3] == 64 and H % 16 == 0 and W % 16 == 0 and cx % 8 == 0 and \
-                        (h.dtype == torch.float16 if wide else cx <= 192) and ops.use_fused_proj(wide):
+                        cx <= 192 and not wide_weights(precision, h.shape[3], h.shape[3], 3) and ops.use_fused_proj():
                     out = self.block2._run(h, precision, proj=self.res_conv, proj_x0=x0, proj_x1=x1, fused_only=True)
                     if out is not None:
                         return out

@@ -131,8 +131,8 @@ typedef struct hsidm_conv_desc {
                                  16x16 tiles and no residual, the persistent kernel's projection forms (csrc/conv_v3.hip, PROJ:
                                  hsidm_conv_kernel_id(d) & 15 == 4; the ResnetBlock's res_conv of reference unet.py:102-103,110
                                  inside block2's launch, SURVEY K3): one-pass weights (no w_v2_lo; HSIDM_BF16 | HSIDM_F16) with
-                                 at most 192 projection channels, or HSIDM_F16 with w_v2_lo + w_v2_ls / w_v2_li.  For bn == 64
-                                 the phase-1 steps of w_v2 (/ w_v2_lo / w_v2_ls) carry the projection's weights times log2(e)
+                                 at most 192 projection channels.  For bn == 64 (one-pass layers)
+                                 the phase-1 steps of w_v2 carry the projection's weights times log2(e)
                                  (the kernel removes the factor its SiLU staging leaves on every product) and are padded with
                                  zero steps to THREE per item: w_v2 holds 9 * chunks(phase 0) + 3 steps (the one-pass form pulls
                                  three steps per item through its weight ring, whatever the projection's width; w_hi / w_lo, the

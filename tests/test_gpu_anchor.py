@@ -186,11 +186,11 @@ def test_sparse_second_weight_pass_removes_the_weight_bias(dev, shape):
 def test_projection_fused_into_the_persistent_kernel(dev, shape):
     """ResnetBlock's tail, h2 = conv3x3(silu(GN(h))) + conv1x1(cat(x0, x1)) + biases (reference unet.py:105-111), on the
     64-cout layers: the projection as one-tap chunks of the 3x3 launch (conv_v3.hip, PROJ: raw staging, centre tap, projection
-    weights scaled by log2(e) on the host) against fp32 torch on the host and against the two-launch form (1x1 GEMM, then the 3x3
-    kernel with its result as the residual) - in the ONE-PASS kernel sets the benchmark's chain steps run ("fp16d1": a dithered set of
-    the fp16 policy; "fp16x1"; "bf16": three static projection slots behind the 3-step weight ring, zero-padded steps) and in the
-    hi + lo sets (sparse second pass).  Projection widths: 192 = two tensors (three chunks), 64 (one), 128 = two tensors (two), and 72
-    (a last chunk of 8 live channels: the staging zeroes the rest)."""
+    weights scaled by log2(e) on the host, three static slots behind the 3-step weight ring, zero-padded steps) against fp32 torch on
+    the host and against the two-launch form (1x1 GEMM, then the 3x3 kernel with its result as the residual) - in the ONE-PASS kernel
+    sets the benchmark's chain steps run ("fp16d1": a dithered set of the fp16 policy; "fp16x1"; "bf16").  Layers with hi + lo weights
+    (the experimental two-pass sets) are not offered the form: the caller keeps its two launches.  Projection widths: 192 = two tensors
+    (three chunks), 64 (one), 128 = two tensors (two), and 72 (a last chunk of 8 live channels: the staging zeroes the rest)."""
     from hsi_dmgasr_amd import ops
     Ci, P0, P1, B, H, W = shape
     g = torch.Generator().manual_seed(Ci + P0 + P1)
@@ -210,7 +210,11 @@ def test_projection_fused_into_the_persistent_kernel(dev, shape):
         x1 = None if x116 is None else x116.to(dt).to(dev)
         want = _reference(h, None, ab, True, w, b, None, None) + _reference(x0, x1, None, False, wp, bp, None, None, ksize=1)
         pk = ops.PackedConv(w.to(dev), b.to(dev), mode, proj_weight=wp.to(dev), proj_bias=bp.to(dev))
-        assert (pk.w_v2_lo is None) == (mode in ("fp16d1", "fp16x1", "bf16"))
+        if mode in ("fp16", "fp16x2"):            # hi + lo weights: no persistent projection form, the offer is declined
+            assert pk.wide and pk.w_v2 is None
+            assert ops.conv2d(h, pk, gn_ab=tab, transform=ops.XF_AFFINE_SILU, proj_x0=x0, proj_x1=x1, fused_only=True) is None
+            continue
+        assert pk.w_v2 is not None and pk.w_v2_lo is None
         recs = []
         ops.set_conv_probe(recs)
         try:
@@ -220,7 +224,7 @@ def test_projection_fused_into_the_persistent_kernel(dev, shape):
             ops.set_conv_probe(None)
         assert y is not None and "conv_v3" in recs[-1]["kernel"], recs
         assert_stats(y._hsidm_stats[0], y, "proj_fused")
-        check("anchor_proj_fused_%d_%d" % (Ci, P0 + P1), mode, y, want, tol=TOL["bf16"] if mode == "bf16" else (TOL["fp16x2"] if pk.w_v2_lo is not None else (8e-4 if mode == "fp16d1" else TOL["fp16"])))
+        check("anchor_proj_fused_%d_%d" % (Ci, P0 + P1), mode, y, want, tol=TOL["bf16"] if mode == "bf16" else (8e-4 if mode == "fp16d1" else TOL["fp16"]))
         # the two-launch form on the same operands
         r = ops.conv2d(x0, ops.PackedConv(wp.to(dev), bp.to(dev), mode), x1=x1)
         y2 = ops.conv2d(h, ops.PackedConv(w.to(dev), b.to(dev), mode), gn_ab=tab, transform=ops.XF_AFFINE_SILU, res=r)

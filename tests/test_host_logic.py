@@ -573,45 +573,43 @@ def test_sparse_low_half_packing_matches_the_measured_operand_semantics():
 
 
 def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent_kernel():
-    """A ResnetBlock's block2 conv packed together with its 1x1 res_conv (reference unet.py:102-103,110) for a 64-cout slice (conv_v3's
-    PROJ forms): the register-streaming order gets 9 steps per 64-channel chunk of the 3x3 conv followed by THREE projection steps -
-    one per 64-channel chunk of the projection, zero steps behind them (the one-pass kernel pulls three steps through its 3-step
-    weight ring at every item, whatever the projection's width) - and the projection's steps carry log2(e) (the SiLU staging leaves
-    that factor on every product of the launch and the epilogue removes it from the accumulators); with hi + lo weights, hi + lo + the
-    2:4-sparse low halves describe the same scaled weights; the order the LDS-tiled kernel reads stays unscaled and unpadded; the
-    biases are summed.  One-pass sets (bf16, a dithered fp16 set) get the same steps without low halves."""
+    """A ResnetBlock's block2 conv packed together with its 1x1 res_conv (reference unet.py:102-103,110) for a 64-cout slice of a ONE-PASS
+    kernel set (conv_v3's PROJ forms: bf16, a dithered fp16 set): the register-streaming order gets 9 steps per 64-channel chunk of the 3x3
+    conv followed by THREE projection steps - one per 64-channel chunk of the projection, zero steps behind them (the kernel pulls three
+    steps through its 3-step weight ring at every item, whatever the projection's width) - and the projection's steps carry log2(e)
+    (the SiLU staging leaves that factor on every product of the launch and the epilogue removes it from the accumulators); the order
+    the LDS-tiled kernel reads stays unscaled and unpadded; the biases are summed.  A layer with hi + lo weights packs no
+    register-streaming projection steps (its projection stays a launch of its own)."""
     from hsi_dmgasr_amd import ops
     g = torch.Generator().manual_seed(11)
     co, ci, pc = 64, 64, 72                       # 72 projection channels: two chunks, the second with 8 live channels
     w = torch.randn(co, ci, 3, 3, generator=g) * 0.05
     wp = torch.randn(co, pc, 1, 1, generator=g) * 0.1
     b, bp = torch.randn(co, generator=g), torch.randn(co, generator=g)
-    pk = ops.PackedConv(w, b, "fp16", proj_weight=wp, proj_bias=bp)
-    assert pk.wide and pk.proj_cin == pc and torch.allclose(pk.bias, b + bp)
     nst = 9 * 1 + 3
-    assert pk.w_v2.shape[0] == nst and pk.w_v2_lo.shape == pk.w_v2.shape and pk.w_v2_ls.shape[0] == nst and pk.w_v2_li.shape[0] == nst
     # undo _lanes: [step][cout/32][kk][h][r][8] -> [step][cout][64]
     def unlane(t):
         st = t.shape[0]
         return t.reshape(st, co // 32, 4, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(st, co, 64)
-    both = unlane(pk.w_v2.double() + pk.w_v2_lo.double())
     want3 = w.double().reshape(co, ci, 9).permute(2, 0, 1)                          # [tap][cout][cin]
-    assert float((both[:9] - want3).abs().max()) < 1e-7
     wpad = torch.zeros(co, 192, dtype=torch.float64)
     wpad[:, :pc] = wp.double().reshape(co, pc) * ops.LOG2E
     wantp = wpad.reshape(co, 3, 64).permute(1, 0, 2)                                # [chunk][cout][64]
-    assert float((both[9:] - wantp).abs().max()) < 2e-7
-    assert float(both[10, :, 8:].abs().max()) == 0.0 and float(both[11].abs().max()) == 0.0   # zero weights behind the 72nd channel, a zero third step
-    # the LDS-tiled kernel's order: unscaled
-    raw = pk.w_hi.double() + pk.w_lo.double()                                       # [step][cout_pad][64]
-    assert float((raw[9, :, :64] - wp.double().reshape(co, pc)[:, :64]).abs().max()) < 1e-7
-    assert pk.w_hi.shape[0] == 9 + 2
-    for mode, dt in (("bf16", torch.bfloat16), ("fp16d2", torch.float16)):          # one-pass sets: the same steps, no low halves
-        pk1 = ops.PackedConv(w, b, mode, proj_weight=wp, proj_bias=bp)
-        assert not pk1.wide and pk1.w_v2.dtype == dt and pk1.w_v2.shape[0] == nst and pk1.w_v2_lo is None and pk1.w_v2_ls is None
-        one = unlane(pk1.w_v2.double())
+    for mode, dt in (("bf16", torch.bfloat16), ("fp16d2", torch.float16), ("fp16x1", torch.float16)):
+        pk = ops.PackedConv(w, b, mode, proj_weight=wp, proj_bias=bp)
+        assert not pk.wide and pk.proj_cin == pc and torch.allclose(pk.bias, b + bp)
+        assert pk.w_v2.dtype == dt and pk.w_v2.shape[0] == nst and pk.w_v2_lo is None and pk.w_v2_ls is None
+        one = unlane(pk.w_v2.double())
         tol = (2.0 ** -8 if mode == "bf16" else 2.0 ** -10) * 1.01               # one rounding (the dithered set: up to 7/8 ulp)
-        assert float((one[9:] - wantp).abs().max()) <= tol * float(wantp.abs().max()) and float(one[11].abs().max()) == 0.0
+        assert float((one[:9] - want3).abs().max()) <= tol * float(want3.abs().max())
+        assert float((one[9:] - wantp).abs().max()) <= tol * float(wantp.abs().max())
+        assert float(one[10, :, 8:].abs().max()) == 0.0 and float(one[11].abs().max()) == 0.0   # zero weights behind the 72nd channel, a zero third step
+        # the LDS-tiled kernel's order: unscaled, two projection steps
+        assert pk.w_hi.shape[0] == 9 + 2
+        raw = pk.w_hi.double() + (pk.w_lo.double() if pk.w_lo is not None else 0.0)
+        assert float((raw[9, :, :64] - wp.double().reshape(co, pc)[:, :64]).abs().max()) <= tol * float(wp.abs().max())
+    wide = ops.PackedConv(w, b, "fp16x2", proj_weight=wp, proj_bias=bp)
+    assert wide.wide and wide.w_v2 is None and wide.w_hi.shape[0] == 9 + 2 and torch.allclose(wide.bias, b + bp)
 
 
 def test_sam_gate_and_the_continuous_companions_of_the_parity_checks():
