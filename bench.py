@@ -873,6 +873,34 @@ def main():
                                                note="steady-state fp16-mode steps (behind the chain's warm-up)")
                 del r
         log('small batches done')
+    short = None
+    if solo and args.detail and not args.no_small and args.precision == HEADLINE:
+        # the reference's SHIPPED chain length (config/sr_sr3_16_128.json:98,104: n_timestep 20 for validation) end to end through the product's
+        # entry point: one p_sample_loop_batched call over this GPU's batch = 20 steps, all eight fp32-set steps of the policy among them.
+        # The FIRST call of a process pays five eager steps (weight packing) and five graph captures; every later call on the same shapes
+        # replays the kept slot (diffusion._GraphSlot) from its first step - what a validation loop over images sees.
+        from hsi_dmgasr_amd.sr3_modules import diffusion as _dm
+        with torch.no_grad():
+            gd20 = _dm.GaussianDiffusion(gd.denoise_fn, image_size=128, channels=3, loss_type="l1", conditional=True).to(dev).eval()
+            gd20.set_loss(dev)
+            gd20.set_new_noise_schedule(dict(SCHED, n_timestep=20), dev)
+            gd20.noise, gd20.seed = "philox", 2
+            calls = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                x0 = gd20.p_sample_loop_batched(cond)
+                torch.cuda.synchronize()
+                calls.append((time.perf_counter() - t0) * 1e3)
+            assert torch.isfinite(x0).all()
+            later = sorted(calls[1:])[1]
+            short = dict(chain_steps=20, batch=batch, first_call_ms=calls[0], later_call_ms=later, calls_ms=calls,
+                         value_first_call=20 * batch / (calls[0] * 1e-3), value_later_calls=20 * batch / (later * 1e-3),
+                         unit="denoise-steps*batch/s", note="whole p_sample_loop_batched calls (20 steps, 8 of them on the fp32 kernel set); "
+                         "later calls replay the first call's captured steps")
+            del gd20, x0
+        torch.cuda.empty_cache()
+        log('short chain done')
     gae_rec = gae_chik = None
     if rank == 0 and args.detail and not args.no_gae:
         with torch.no_grad():
@@ -930,7 +958,7 @@ def main():
             "rank_ms_per_step": {"min": _r(dt_min / args.steps * 1e3, 5), "max": _r(dt / args.steps * 1e3, 5)},
         }
         detail = {"line": None, "chain_mix": mix, "roofline": roof, "parity": parity, "bf16_mode": bf16, "fp32_mode": fp32,
-                  "small_batches": small, "gae": gae_rec, "gae_chikusei": gae_chik, "train_step": train_rec, "cpu_baseline": cpu}
+                  "small_batches": small, "short_chain_T20": short, "gae": gae_rec, "gae_chikusei": gae_chik, "train_step": train_rec, "cpu_baseline": cpu}
         dpath = None
         try:
             line = compact_line(head, roof, parity, cpu, args.precision, os.path.relpath(args.detail_out, ROOT))

@@ -650,6 +650,9 @@ def test_bench_detail_legs(tmp_path):
     assert side["bf16_mode"]["value"] > 0 and side["bf16_mode"]["meets_north_star"] is False
     assert side["fp32_mode"]["value"] > 0 and side["fp32_mode"]["roofline"]["mfma_passes_per_product"] == 3
     assert set(side["small_batches"]) == {"40_latents", "5_latents"} and all(v["value"] > 0 for v in side["small_batches"].values())
+    # the shipped 20-step chain through p_sample_loop_batched: later calls replay the first call's captured steps
+    sc = side["short_chain_T20"]
+    assert sc["chain_steps"] == 20 and 0 < sc["later_call_ms"] < sc["first_call_ms"] and sc["value_later_calls"] > sc["value_first_call"]
     for key in ("gae", "gae_chikusei"):
         for mode in ("fp32", "fp16"):
             assert side[key][mode]["encode_ms"] > 0 and "dPSNR_dB_vs_fp32_mode" in side[key][mode]
