@@ -378,7 +378,10 @@ def gae_bytes(bands, n_subs, groups, esz, feats=64, tfeats=32, hw=128 * 128):
     F, S = feats, esz
 
     def branch(cin, f, nblk):            # head + nblk x (ResBlock + ResAttentionBlock), in stored elements per pixel: (unit, launch)
-        return (pad8(cin) + f) + nblk * 4 * f, (pad8(cin) + f) + nblk * 12 * f + f
+        # launch level, per block: ResBlock 5 f (conv: in, out; conv: in, residual, out) + ResAttentionBlock 7 f (1x1: in, out; 1x1: in, out;
+        # scale + residual pass: 3) - or 5 f where the 1x1 pair is ONE launch (64 features: hsidm_conv1x1_pair, round 6)
+        per = 10 if f == 64 else 12
+        return (pad8(cin) + f) + nblk * 4 * f, (pad8(cin) + f) + nblk * per * f + f
     eu, el = branch(n_subs, F, 3)
     enc_unit = groups * hw * (n_subs * 4 + pad8(n_subs) * S + eu * S + F * S + 3 * 4)
     enc_launch = groups * hw * (n_subs * 4 + pad8(n_subs) * S + el * S + F * S + 3 * 4)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSIDM_LIB: diagnostic override (A/B builds, in-kernel stamp builds); the product library is libhsidm.so next to this file
 LIB_PATH = os.environ.get("HSIDM_LIB") or os.path.join(_HERE, "libhsidm.so")
 
-ABI_VERSION = 2          # include/hsidm.h: HSIDM_ABI_VERSION (the ConvDesc below has w_v2_ls / w_v2_li)
+ABI_VERSION = 3          # include/hsidm.h: HSIDM_ABI_VERSION (2: the ConvDesc below has w_v2_ls / w_v2_li; 3: hsidm_conv1x1_pair)
 BF16, F32X3, F16 = 0, 1, 2
 XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
@@ -49,6 +49,7 @@ SIGNATURES = {
     "hsidm_conv_stats_nsplit": [C.POINTER(ConvDesc)],
     "hsidm_conv_kernel_id": [C.POINTER(ConvDesc)],
     "hsidm_conv_workspace_bytes": [C.POINTER(ConvDesc)],
+    "hsidm_conv1x1_pair": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp],
     "hsidm_gn_partial": [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "hsidm_gn_finalize": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "hsidm_noise_film": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],

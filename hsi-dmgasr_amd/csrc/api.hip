@@ -41,6 +41,22 @@ using namespace hsidm;
 
 extern "C" int hsidm_version(void) { return HSIDM_ABI_VERSION; }
 
+namespace hsidm {
+int conv1x1_pair_run(const void* x, const bf16* w, const bf16* w_lo, int elem, const float* bias1, int act, const float* bias2, void* out,
+                     float2* stats, int M, int HW, hipStream_t s);
+}
+
+extern "C" int hsidm_conv1x1_pair(int prec, const void* x, const void* w_pair, const void* w_pair_lo, const float* bias1, int act,
+                                  const float* bias2, void* out, void* stats, int64_t M, int HW, void* stream) {
+    if (!x || !w_pair || !w_pair_lo || !out || M <= 0 || HW <= 0 || M % HW || M > 0x7fffffff) return HSIDM_E_BADARG;
+    if (prec != HSIDM_F16 && prec != HSIDM_F32X3) return HSIDM_E_UNSUPPORTED;
+    if (act != HSIDM_ACT_NONE && act != HSIDM_ACT_LEAKY) return HSIDM_E_BADARG;
+    if (HW % 64) return HSIDM_E_UNSUPPORTED;                    // 64-pixel statistics groups never straddle two images
+    return hsidm::conv1x1_pair_run(x, reinterpret_cast<const hsidm::bf16*>(w_pair), reinterpret_cast<const hsidm::bf16*>(w_pair_lo),
+                                   prec == HSIDM_F32X3 ? 2 : 1, bias1, act, bias2, out, reinterpret_cast<float2*>(stats), (int)M, HW,
+                                   (hipStream_t)stream);
+}
+
 // Diagnostic builds (-DHSIDM_V2_STAMPS): device buffer [blocks][4][8][16] of s_memtime stamps; not part of hsidm.h.
 extern "C" void hsidm_debug_set_stamps(void* p) { conv_v2_set_stamps(reinterpret_cast<unsigned long long*>(p)); }
 

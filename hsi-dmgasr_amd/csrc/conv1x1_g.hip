@@ -48,6 +48,8 @@ struct C1gParams {
     const bf16* w;          // [chunk][Cout_pad/32][kk 4][lane 64][8]
     const bf16* w_lo;       // NP = 2: low halves of the weights, same layout (conv_v2.h, V2Cfg); else null
     const float* bias;
+    const float* bias1;     // PAIR kernels: the FIRST convolution's bias (`bias` is the second's)
+    int pair_act;           // PAIR kernels: activation between the two convolutions (ACT_NONE | ACT_LEAKY)
     const bf16* res;
     float res_scale;
     bf16* out;
@@ -60,8 +62,17 @@ struct C1gParams {
 // F32 (with E = bf16, NP = 2): the fp32 mode on this kernel - fp32 activations in HBM (two 16-byte vectors per staged pixel-vector, fp32
 // GroupNorm pairs, fp32 stores), every staged value split into bf16 hi + lo into TWO tiles per buffer, three MFMAs per product
 // (conv_v2.h, AP = 2); the 4-byte epilogue patches (40 KB) get a region of their own: 112 KB of LDS, one workgroup per CU.
-template <int BN, int XF, int IM = 0, typename E = bf16, int NP = 1, bool F32 = false>
+// PAIR (BN = 64, Cin = Cout = 64, XF_NONE): TWO 1x1 convolutions in one launch, out = W2 act(W1 x + b1) + b2 - the body of the group
+// autoencoder's spectral ResAttentionBlock (common.py:250-271 with kernel_size 1: conv, LeakyReLU, conv; AE.py:102-109).  The item's two
+// 64-channel "chunks" are the two convolutions: chunk 0 multiplies the staged x tile by W1 (weight step 0); its accumulators - plus b1,
+// through the activation, converted to the operand type (fp32 form: split into bf16 hi + lo, exactly what staging a stored fp32 h would
+// have produced) - are written straight into LDS buffer 1 as the A operand of chunk 1, which multiplies by W2 (weight step 1).  h never
+// exists in HBM (2 of the 7 GB a block moved), one launch instead of two, and neither GEMM pays the zero chunk that pads K = 64 to the
+// two-chunk trip of the plain kernel (half of its matrix instructions on these layers).  Epilogue (b2, statistics for the CALayer's
+// global average, store) as before.
+template <int BN, int XF, int IM = 0, typename E = bf16, int NP = 1, bool F32 = false, bool PAIR = false>
 __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gParams p) {
+    static_assert(!PAIR || (BN == 64 && XF == XF_NONE && IM == 0), "the 1x1 pair: 64 -> 64 -> 64, no input transform");
     using EL = Elem<E>;
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
@@ -120,6 +131,11 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
     const int m0_step = (G / p.n_slices) * 128;
     int st_m0 = (item / p.n_slices) * 128, cur_m0 = st_m0;
     auto issue = [&](int S_) __attribute__((always_inline)) {
+        if (PAIR && S_ == 1) {                                  // an item's chunk 1 is made in the kernel (h): nothing to request
+            set_ok[1] = false;
+            if (st_valid) { st_chunk = 0; st_item += G; st_m0 += m0_step; st_valid = st_item < p.total_items; }
+            return;
+        }
         set_ok[S_] = st_valid;
         if (!st_valid) return;
         const int m0 = st_m0;
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 
     const int n_lane = n0 + wn * 32 + lc;                       // couts n_lane, n_lane + 16 (Cout % BN == 0 on this path)
     const float bias[2] = {p.bias ? p.bias[n_lane] : 0.f, p.bias ? p.bias[n_lane + 16] : 0.f};
+    const float bias1[2] = {(PAIR && p.bias1) ? p.bias1[n_lane] : 0.f, (PAIR && p.bias1) ? p.bias1[n_lane + 16] : 0.f};
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         for (int chunk = 0; chunk < p.nch; chunk += 2) {
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                     f_issue((u + 6) % 8, (u + 6) % 4);
                     // first use of these accumulators: C = 0 as the MFMA's inline constant, behind a uniform branch (a select between
                     // the constant and the accumulator costs a v_cndmask per register - and, in the fp32 form, moves through the AGPRs)
-                    if (PAR == 0 && kk < 2 && chunk == 0) {
+                    if ((PAR == 0 || PAIR) && kk < 2 && chunk == 0) {     // (PAIR: the second convolution starts from zero too)
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr)
@@ -317,6 +334,28 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                 if (G1_ABL != 5) lds_barrier();
             };
             body(SlotTag<0>{});
+            if constexpr (PAIR) {
+                // h = act(W1 x + b1) of this wave's 64 pixels x 32 couts -> LDS buffer 1 in the staged layout (pixel rows of PSTR elements):
+                // the lane holds pixels 4 lg .. + 3 of couts 16 nh + lc per (32-pixel group, 16-pixel half).  (Buffer 1 carried the previous
+                // item's epilogue patch: that item ended with a barrier; nothing was committed to it during body 0.)
+                E* hb = xt + BUFE;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float v = acc[mr][r][nh][j] + bias1[nh];
+                                if (p.pair_act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                                const int at = (wm * (128 / WM) + mr * 32 + 16 * r + 4 * lg + j) * PSTR + wn * 32 + 16 * nh + lc;
+                                const E hi = (E)v;
+                                hb[at] = hi;
+                                if constexpr (F32) hb[TILE + at] = (E)(v - (float)hi);
+                            }
+                lds_barrier();
+            }
             body(SlotTag<1>{});
         }
 
@@ -431,11 +470,11 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 }
 
 
-template <int BN, int XF, int IM, typename E, int NP, bool F32 = false>
+template <int BN, int XF, int IM, typename E, int NP, bool F32 = false, bool PAIR = false>
 static int run_g1(C1gParams& p, hipStream_t s) {
     constexpr size_t lds = F32 ? (size_t)2 * 2 * 128 * 80 * 2 + (size_t)4 * 64 * 40 * 4 : (size_t)2 * 128 * 80 * 2 + 2048;
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP, F32>, lds)) return rc;
+    if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP, F32, PAIR>, lds)) return rc;
     const int g1_slots = (F32 ? 1 : 2) * device_cus();
     p.n_slices = p.Cout_pad / BN;
     p.m_tiles = (p.M + 127) / 128;
@@ -445,7 +484,7 @@ static int run_g1(C1gParams& p, hipStream_t s) {
     const int slots = g1_slots;
     int G = (p.total_items < slots ? p.total_items : slots) / lcm * lcm;
     if (G == 0) G = p.total_items;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM, E, NP, F32>), dim3(G), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_g_kernel<BN, XF, IM, E, NP, F32, PAIR>), dim3(G), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -482,11 +521,28 @@ int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, in
     p.src0 = src0; p.src1 = src1; p.C0 = C0; p.C1 = C1;
     p.gn_ab = reinterpret_cast<const f32x4*>(gn_ab);
     p.w = w; p.w_lo = w_lo; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
+    p.bias1 = nullptr; p.pair_act = ACT_NONE;
     p.M = M; p.HW = HW; p.Cout = Cout; p.Cout_pad = Cout; p.nch = nch;
     if (elem == 2) return (w_lo && im_W <= 0) ? dispatch_g1_f32(bn, xf, p, s) : HSIDM_E_UNSUPPORTED;
     if (elem == 0) return w_lo ? HSIDM_E_UNSUPPORTED : dispatch_g1<bf16, 1>(bn, xf, im_W > 0, p, s);
     if (elem == 1) return w_lo ? dispatch_g1<f16, 2>(bn, xf, im_W > 0, p, s) : dispatch_g1<f16, 1>(bn, xf, im_W > 0, p, s);
     return HSIDM_E_UNSUPPORTED;
+}
+
+// out = W2 act(W1 x + b1) + b2 on [M][64] tensors (PAIR kernels above): w / w_lo = the two convolutions' weights as the two steps of the
+// packed order; elem: 1 fp16 (hi + lo weights: w_lo required), 2 the fp32 mode (fp32 tensors, bf16 hi + lo weights)
+int conv1x1_pair_run(const void* x, const bf16* w, const bf16* w_lo, int elem, const float* bias1, int act, const float* bias2, void* out,
+                     float2* stats, int M, int HW, hipStream_t s) {
+    if (!w_lo || (elem != 1 && elem != 2)) return HSIDM_E_UNSUPPORTED;
+    C1gParams p;
+    p.im_H = p.im_W = 0;
+    p.src0 = reinterpret_cast<const bf16*>(x); p.src1 = nullptr; p.C0 = 64; p.C1 = 0;
+    p.gn_ab = nullptr;
+    p.w = w; p.w_lo = w_lo; p.bias = bias2; p.bias1 = bias1; p.pair_act = act;
+    p.res = nullptr; p.res_scale = 1.f; p.out = reinterpret_cast<bf16*>(out); p.stats = stats;
+    p.M = M; p.HW = HW; p.Cout = 64; p.Cout_pad = 64; p.nch = 2;
+    if (elem == 2) return run_g1<64, XF_NONE, 0, bf16, 2, true, true>(p, s);
+    return run_g1<64, XF_NONE, 0, f16, 2, false, true>(p, s);
 }
 
 }  // namespace hsidm

@@ -95,9 +95,20 @@ class ResAttentionBlock(_ConvPair):
     def __init__(self, conv, n_feats, kernel_size, bias=True, bn=False, act=nn.ReLU(True), res_scale=1):
         super().__init__(conv, n_feats, kernel_size, bias, bn, act, res_scale, with_ca=True)
 
+    def _pair(self, precision):
+        c0, c2 = self.body[0], self.body[2]
+        return self._cache.get(("pair", precision), [c0.weight, c0.bias, c2.weight, c2.bias],
+                               lambda: ops.PackedPair(c0.weight, c0.bias, c2.weight, c2.bias, precision))
+
     def _run(self, x, precision, skip2=None):
-        h = ops.conv2d(x, self._pk(0, precision), act=ops.ACT_LEAKY)
-        r = ops.conv2d(h, self._pk(2, precision), stats=True)
+        c0 = self.body[0]
+        B, H, W, Cc = x.shape
+        if c0.kernel_size == (1, 1) and Cc == 64 and c0.out_channels == 64 and (H * W) % 64 == 0:
+            # the spectral block (SSB.spc, AE.py:102-109: kernel_size 1): conv -> LeakyReLU -> conv in ONE launch, h stays on the chip
+            r = ops.conv1x1_pair(x, self._pair(precision), act=ops.ACT_LEAKY, stats=True)
+        else:
+            h = ops.conv2d(x, self._pk(0, precision), act=ops.ACT_LEAKY)
+            r = ops.conv2d(h, self._pk(2, precision), stats=True)
         ca = self.body[3].vector(r, precision)
         return ops.ca_apply(r, ca, x, self.res_scale, precision, skip2=skip2)
 

@@ -331,6 +331,40 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     return out
 
 
+class PackedPair:
+    """Weights of one hsidm_conv1x1_pair launch: two 64 -> 64 1x1 convolutions (W1, b1), (W2, b2) as the two steps of the
+    register-streaming order (include/hsidm.h), high and low halves in the mode's operand type (fp32 mode: bf16; fp16 mode: fp16)."""
+
+    def __init__(self, w1, b1, w2, b2, precision):
+        assert tuple(w1.shape) == (64, 64, 1, 1) and tuple(w2.shape) == (64, 64, 1, 1)
+        self.prec = _lib.prec_id(precision)
+        assert self.prec in (_lib.F32X3, _lib.F16)
+        et = torch.float16 if self.prec == _lib.F16 else torch.bfloat16
+        st = torch.cat([PackedConv._steps(w1.detach().float(), 64, 64), PackedConv._steps(w2.detach().float(), 64, 64)], dim=0)
+        lay = PackedConv._lanes(st.contiguous(), 64)
+        self.w = lay.to(et).contiguous()
+        self.w_lo = (lay - self.w.float()).to(et).contiguous()
+        self.b1 = None if b1 is None else b1.detach().float().contiguous()
+        self.b2 = None if b2 is None else b2.detach().float().contiguous()
+
+
+def conv1x1_pair(x, pp, act=ACT_NONE, stats=False):
+    """out = W2 act(W1 x + b1) + b2 on an NHWC [B, H, W, 64] tensor in one launch (hsidm_conv1x1_pair: the spectral ResAttentionBlock's
+    body, reference common.py:250-271 / AE.py:102-109); stats=True: the output's per-64-pixel-group sums ride on the result like
+    conv2d's (``out._hsidm_stats``)."""
+    B, H, W, Cc = x.shape
+    assert Cc == 64 and (H * W) % 64 == 0 and x.is_contiguous()
+    out = torch.empty_like(x)
+    slab = None
+    if stats:
+        nsplit = H * W // 64
+        slab = torch.empty((B, nsplit, 64, 2), dtype=torch.float32, device=x.device)
+        out._hsidm_stats = (slab, nsplit)
+    _lib.check(_lib.lib().hsidm_conv1x1_pair(pp.prec, _lib.ptr(x), _lib.ptr(pp.w), _lib.ptr(pp.w_lo), _lib.ptr(pp.b1), int(act), _lib.ptr(pp.b2),
+                                             _lib.ptr(out), _lib.ptr(slab), B * H * W, H * W, _lib.stream_ptr()), "conv1x1_pair")
+    return out
+
+
 _sk_ws = {}
 _sk_retired = []
 

@@ -47,7 +47,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever a struct below grows or a prototype changes (2: hsidm_conv_desc gained w_v2_ls /
  * w_v2_li).  hsidm_version() returns the version the LIBRARY was built against; a caller built against another header must refuse
  * to run (a shorter hsidm_conv_desc would be read 16 bytes past its end) - the ctypes binding does (hsi-dmgasr_amd/_lib.py). */
-#define HSIDM_ABI_VERSION 2
+#define HSIDM_ABI_VERSION 3
 int hsidm_version(void);
 const char* hsidm_error_string(int code);
 /* Diagnostic dispatch switches for A/B measurements and tests: "NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1",
@@ -255,7 +255,19 @@ int hsidm_loss_workspace_bytes(void);
 int hsidm_loss_sum(const float* a, const float* b, int64_t n, int kind, void* workspace, float* out, void* stream);
 
 /* ---- group-autoencoder pieces (AE.py / common.py) -----------------------------------------------------
- * CALayer (common.py:231-247): ca[b][c] = sigmoid(W2 relu(W1 mean_b + b1) + b2), mean from `part`.
+ * The body of the spectral ResAttentionBlock (common.py:250-271 with kernel_size 1, as SSB builds it, AE.py:102-109): two 1x1 convolutions
+ * of 64 channels with an activation between them in ONE launch,
+ *     out[m][:] = W2 act(W1 x[m][:] + bias1) + bias2,      x, out: NHWC [M = B * HW][64] in the storage type of `prec`,
+ * the intermediate tensor never leaves the chip.  prec: HSIDM_F16 (fp16 hi + lo weights) | HSIDM_F32X3 (fp32 storage, bf16 hi + lo
+ * operands: the intermediate is split exactly as a stored fp32 tensor would be when staged).  w_pair / w_pair_lo: the two weight
+ * matrices as the two steps of the register-streaming order of hsidm_conv_desc.w_v2 - [2][64/32][kk 4][lane 64][8], step 0 = W1,
+ * step 1 = W2 - high and low halves.  act: HSIDM_ACT_NONE | HSIDM_ACT_LEAKY.  stats (optional): [B][HW / 64][64] (sum, sum of
+ * squares) of `out` per 64-pixel group, the CALayer's global-average partials (hsidm_ca_vector's `part`, nsplit = HW / 64).
+ * HW % 64 == 0.  (ABI version 3.) */
+int hsidm_conv1x1_pair(int prec, const void* x, const void* w_pair, const void* w_pair_lo, const float* bias1, int act,
+                       const float* bias2, void* out, void* stats, int64_t M, int HW, void* stream);
+
+/* CALayer (common.py:231-247): ca[b][c] = sigmoid(W2 relu(W1 mean_b + b1) + b2), mean from `part`.
  */
 int hsidm_ca_vector(const float* part, int nsplit, int B, int C, int HW, int R,
                     const float* w1, const float* b1, const float* w2, const float* b2,

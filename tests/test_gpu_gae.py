@@ -295,3 +295,39 @@ def test_chikusei_full_size_cube_against_the_oracle(dev, prec):
     dsam = abs(metrics.sam_degrees(a, got) - metrics.sam_degrees(a, ref))
     log_err("gae_chikusei_128_dPSNR_dB", prec, dpsnr, {"dsam_deg": dsam, "psnr": metrics.mpsnr(a, got)})
     assert dpsnr < 0.01 and dsam < 0.001, (prec, dpsnr, dsam)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("shape", [(3, 32, 32), (2, 16, 24), (1, 8, 8), (5, 64, 64)], ids=lambda s: "%dx%dx%d" % s)
+def test_spectral_block_pair_in_one_launch(dev, prec, shape):
+    """hsidm_conv1x1_pair - the body of the spectral ResAttentionBlock (reference common.py:250-271 with kernel_size 1, AE.py:102-109):
+    out = W2 leaky(W1 x + b1) + b2 on 64-channel maps in ONE launch, the intermediate tensor never stored - against torch in fp64 on
+    the same stored inputs and against the two-launch form (two hsidm_conv2d calls); the statistics it emits are the sums of what it
+    stored (the CALayer's global average is made of them); shapes with 1, 6, 16 and 320 pixel tiles (the last: more than one item per
+    workgroup is not reached here, test_chikusei_full_size_cube_against_the_oracle covers it)."""
+    from gpu_util import assert_stats
+    from helpers import rel_err
+    from hsi_dmgasr_amd import _lib, ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    w1 = torch.randn(64, 64, 1, 1, generator=g) / 8
+    w2 = torch.randn(64, 64, 1, 1, generator=g) / 8
+    b1, b2 = 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    x = torch.randn(B, H, W, 64, generator=g).to(_lib.act_dtype(prec)).to(dev)
+    pp = ops.PackedPair(w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), prec)
+    y = ops.conv1x1_pair(x, pp, act=ops.ACT_LEAKY, stats=True)
+    torch.cuda.synchronize()
+    xd = x.double().cpu().reshape(-1, 64)
+    hd = torch.nn.functional.leaky_relu(xd @ w1.double().reshape(64, 64).T + b1.double(), 0.01)
+    want = (hd @ w2.double().reshape(64, 64).T + b2.double()).reshape(B, H, W, 64)
+    e = rel_err(y.double().cpu().numpy(), want.numpy())
+    log_err("conv1x1_pair_%dx%dx%d" % shape, prec, e)
+    assert e < (2e-5 if prec == "fp32" else 6e-4), e
+    assert_stats(y._hsidm_stats[0], y, "pair")
+    # the two-launch form on the same operands: the pair is at least as close (fp16: it skips one rounding of h)
+    h = ops.conv2d(x, ops.PackedConv(w1.to(dev), b1.to(dev), prec), act=ops.ACT_LEAKY)
+    y2 = ops.conv2d(h, ops.PackedConv(w2.to(dev), b2.to(dev), prec), stats=True)
+    torch.cuda.synchronize()
+    e2 = rel_err(y2.double().cpu().numpy(), want.numpy())
+    log_err("conv1x1_two_launches_%dx%dx%d" % shape, prec, e2)
+    assert e < 1.1 * e2 + 1e-6, (e, e2)

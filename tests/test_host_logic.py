@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libhsidm.so does not export %s" % name
     assert declared - {"hsidm_error_string"} == set(_lib.SIGNATURES), "ctypes table out of sync with hsidm.h"
-    assert _lib.lib().hsidm_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().hsidm_version() == _lib.ABI_VERSION == 3
     assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32 and _lib.lib().hsidm_conv_bk(_lib.F16) == 64
     assert b"invalid" in _lib.lib().hsidm_error_string(-1)
 
@@ -56,7 +56,7 @@ def test_clean_tree_build_produces_a_loadable_library(tmp_path):
     assert sorted(f[:-4] + ".o" for f in srcs) == sorted(os.listdir(tmp_path / "obj"))     # one fresh object per source, nothing else
     L = ctypes.CDLL(str(out))
     L.hsidm_version.restype = ctypes.c_int
-    assert L.hsidm_version() == 2
+    assert L.hsidm_version() == 3
     for name in _lib.SIGNATURES:
         assert hasattr(L, name), "the clean build does not export %s" % name
     assert L.hsidm_conv_bk(_lib.F16) == 64
