@@ -123,11 +123,10 @@ struct DebugTable {
         v[hsidm::DBG_NO_SPLIT_K] = getenv("HSIDM_NO_SPLIT_K") ? 1 : 0;
         v[hsidm::DBG_NO_SPARSE_LO] = getenv("HSIDM_NO_SPARSE_LO") ? 1 : 0;
         v[hsidm::DBG_NO_FUSED_PROJ] = getenv("HSIDM_NO_FUSED_PROJ") ? 1 : 0;
-        v[hsidm::DBG_SLICES_ON_ONE_XCD] = getenv("HSIDM_SLICES_ON_ONE_XCD") ? 1 : 0;
     }
 };
 DebugTable g_debug;          // constructed when the library is loaded
-const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ", "SLICES_ON_ONE_XCD"};
+const char* const kDebugNames[hsidm::DBG_COUNT] = {"NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1", "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ"};
 }  // namespace
 int hsidm::debug_get(int key) { return g_debug.v[key].load(std::memory_order_relaxed); }
 

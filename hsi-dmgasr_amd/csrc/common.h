@@ -176,7 +176,7 @@ inline int device_cus() {
 // Diagnostic switches (A/B measurements and tests): set once from the environment when the library is loaded
 // (HSIDM_NO_V3, HSIDM_V2_BN256, HSIDM_ATTENTION_V1, HSIDM_NO_XCD_MAP, HSIDM_1X1, HSIDM_V2_ABL, HSIDM_NO_SPLIT_K) and afterwards only through
 // hsidm_debug_switch(); the launch path never reads the environment.
-enum DebugKey { DBG_NO_V3 = 0, DBG_V2_BN256, DBG_ATTENTION_V1, DBG_NO_XCD_MAP, DBG_1X1_V1, DBG_V2_ABL, DBG_SK_MULT, DBG_NO_SPLIT_K, DBG_NO_SPARSE_LO, DBG_NO_FUSED_PROJ, DBG_SLICES_ON_ONE_XCD, DBG_COUNT };
+enum DebugKey { DBG_NO_V3 = 0, DBG_V2_BN256, DBG_ATTENTION_V1, DBG_NO_XCD_MAP, DBG_1X1_V1, DBG_V2_ABL, DBG_SK_MULT, DBG_NO_SPLIT_K, DBG_NO_SPARSE_LO, DBG_NO_FUSED_PROJ, DBG_COUNT };
 int debug_get(int key);
 
 }  // namespace hsidm

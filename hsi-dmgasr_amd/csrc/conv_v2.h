@@ -63,8 +63,6 @@ struct ConvV2Params {
     int m_tiles, n_slices, total_items, steps_per_item;
     int up_m;               // UP4 kernels: XCDs per cout slice when the L2-friendly (tile, parity) order applies, else 0
     int xcd_m;              // other kernels: XCDs per cout slice when each of them walks a contiguous range of pixel tiles, else 0
-    int one_xcd;            // A/B form (HSIDM_SLICES_ON_ONE_XCD): every XCD walks 1/8 of the pixel tiles through ALL cout slices (block b: slice
-                            // (b / 8) % n_slices) - a tile crosses the fabric once, each L2 streams the whole weight tensor; else 0
     int tpi_shift, tx_shift; // log2 of tiles per image / per tile row when those are powers of two, else -1
     int ns_shift, xm_shift;  // conv_v2: log2 of n_slices / of the XCD group count (xcd_m or up_m: 8 / n_slices) when powers of two, else -1
     unsigned long long* stamps;   // diagnostic build (HSIDM_V2_STAMPS): [block][wave][item<8][slot<16] s_memtime
@@ -267,7 +265,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     const int ctot = p.C0 + p.C1;
 
     int item = blockIdx.x;                                     // item = m_tile * n_slices + n_slice
-    const int ns = p.one_xcd ? (item >> 3) % p.n_slices : item % p.n_slices;   // constant for this block (G % n_slices == 0; one_xcd: G % (8 n_slices) == 0)
+    const int ns = item % p.n_slices;                          // constant for this block (G % n_slices == 0)
     const int n0 = ns * BN;
     const int n_items_blk = (p.total_items - item + G - 1) / G;
 
@@ -293,10 +291,6 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
     auto div_tpi = [&](int x) __attribute__((always_inline)) -> int { return p.tpi_shift >= 0 ? x >> p.tpi_shift : x / (p.tiles_x * p.tiles_y); };
     auto div_tx = [&](int x) __attribute__((always_inline)) -> int { return p.tx_shift >= 0 ? x >> p.tx_shift : x / p.tiles_x; };
     auto item_tile = [&](int it, int& par) __attribute__((always_inline)) -> int {
-        if (!UP4 && p.one_xcd) {                               // XCD (it & 7): tiles [x M/8, (x + 1) M/8), each through every slice
-            par = 0;
-            return (it & 7) * (p.m_tiles >> 3) + div_ns(it >> 3);
-        }
         const int mt = div_ns(it);
         // blocks of one XCD (b % 8) that share a cout slice hold tiles mt = x, x + m, x + 2m, ... (m = 8 / n_slices); re-ordered so
         // that each XCD walks a contiguous range, neighbouring tiles - which share halo rows and columns - meet in one L2

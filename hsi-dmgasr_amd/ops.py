@@ -145,7 +145,7 @@ class PackedConv:
         self.wide = (self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)) or self.prec == _lib.F32X3
         # one-pass layouts of a dithered kernel set ("fp16d<k>", precision.py): step k of a chain multiplies by fp16(w + d_k * ulp(w)), the
         # K offsets d_k spread over (-1/2, 1/2) ulp - the mean weight over K steps is w to 1 / (2K) ulp, so the weight rounding stops
-        # being a bias of the chain.  (Layers that carry hi + lo weights are not dithered: the low halves are the correction.)
+        # being a bias of the chain.
         ph = dither_phase(precision)
         dith = ph is not None and not self.wide
 

@@ -181,47 +181,8 @@ def is_16bit(p):
     return p != "fp32"
 
 
-def _policy(exp, cout, cin, ksize):
-    """Evaluates a policy expression such as "cout <= 128 and (cin <= 192 or ksize == 1)": names, integers, comparisons, and / or /
-    not and parentheses only (parsed, never eval'ed)."""
-    import ast
-    import operator as op
-    cmp = {ast.LtE: op.le, ast.Lt: op.lt, ast.GtE: op.ge, ast.Gt: op.gt, ast.Eq: op.eq, ast.NotEq: op.ne}
-    env = {"cout": cout, "cin": cin, "ksize": ksize}
-
-    def ev(n):
-        if isinstance(n, ast.Expression):
-            return ev(n.body)
-        if isinstance(n, ast.BoolOp):
-            vals = [ev(v) for v in n.values]
-            return all(vals) if isinstance(n.op, ast.And) else any(vals)
-        if isinstance(n, ast.UnaryOp) and isinstance(n.op, ast.Not):
-            return not ev(n.operand)
-        if isinstance(n, ast.Compare):
-            left = ev(n.left)
-            for o, c in zip(n.ops, n.comparators):
-                right = ev(c)
-                if type(o) not in cmp or not cmp[type(o)](left, right):
-                    return False
-                left = right
-            return True
-        if isinstance(n, ast.Name) and n.id in env:
-            return env[n.id]
-        if isinstance(n, ast.Constant) and isinstance(n.value, int):
-            return n.value
-        raise ValueError("HSIDM_WIDE_POLICY: unsupported expression element %s" % type(n).__name__)
-    return bool(ev(ast.parse(exp, mode="eval")))
-
-
-DITHER_WIDE_COUT = int(os.environ.get("HSIDM_DITHER_WIDE_COUT", "0"))
-
-
 def wide_weights(p, cout, cin=0, ksize=3):
-    """Does a convolution (cout x cin x ksize x ksize) carry hi + lo weights in mode p (second MFMA pass)?"""
-    exp = os.environ.get("HSIDM_WIDE_POLICY")          # diagnostic (tools/policy_probe.py): comparisons over cout, cin, ksize
-    if exp and p == "fp16":
-        return _policy(exp, cout, cin, ksize)
-    # ("fp16d<k>": the dithered sets carry one-pass weights everywhere unless DITHER_WIDE_COUT keeps hi + lo on the narrowest layers)
-    if dither_phase(p) is not None:
-        return cout <= DITHER_WIDE_COUT
+    """Does a convolution (cout x cin x ksize x ksize) carry hi + lo weights in kernel set p (second MFMA pass)?  Only the experimental
+    two-pass sets: "fp16x2" everywhere a kernel takes them, and the NAME "fp16" taken as a kernel set (kernels_as_named(): round 4's
+    set) on the Cout <= 128 layers; the policy's dithered sets "fp16d<k>", "fp16x1" and bf16 are one-pass."""
     return p == "fp16x2" or (p == "fp16" and cout <= 128)

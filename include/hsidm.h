@@ -51,7 +51,7 @@ extern "C" {
 int hsidm_version(void);
 const char* hsidm_error_string(int code);
 /* Diagnostic dispatch switches for A/B measurements and tests: "NO_V3", "V2_BN256", "ATTENTION_V1", "NO_XCD_MAP", "1X1_V1",
- * "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ", "SLICES_ON_ONE_XCD".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
+ * "V2_ABL", "SK_MULT", "NO_SPLIT_K", "NO_SPARSE_LO", "NO_FUSED_PROJ".  Initialised once from the environment (HSIDM_<name>) when the library is loaded; the launch path never
  * reads the environment.  Returns the previous value (>= 0) or HSIDM_E_BADARG for an unknown name. */
 int hsidm_debug_switch(const char* name, int value);
 /* Current value of a switch (>= 0) without changing it, or HSIDM_E_BADARG. */

@@ -410,7 +410,7 @@ def test_package_installs_under_its_import_name(tmp_path):
 
 def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
     """precision.py: the two public modes and the three experimental kernel sets, which of them are 16-bit, the policy's choice of
-    kernel set per call, which convolutions carry hi + lo weights, and the diagnostic policy hook (a parsed expression, never eval'ed)."""
+    kernel set per call, and which convolutions carry hi + lo weights."""
     from hsi_dmgasr_amd import _lib, precision as P
     import torch
     assert set(P.MODES) == {"fp32", "fp16"} and set(P.EXPERIMENTAL_MODES) == {"bf16", "fp16x1", "fp16x2"}
@@ -446,20 +446,12 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
     assert [_lib.prec_id(m) for m in ("bf16", "fp32", "fp16", "fp16x1", "fp16x2")] == [_lib.BF16, _lib.F32X3, _lib.F16, _lib.F16, _lib.F16]
     assert _lib.act_dtype("fp16") == torch.float16 and _lib.act_dtype("bf16") == torch.bfloat16 and _lib.act_dtype("fp32") == torch.float32
     assert P.is_16bit("fp16x2") and P.is_16bit("bf16") and not P.is_16bit("fp32")
-    monkeypatch.delenv("HSIDM_WIDE_POLICY", raising=False)
     assert P.wide_weights("fp16", 64) and P.wide_weights("fp16", 128) and not P.wide_weights("fp16", 256)
-    assert not P.wide_weights("fp16x1", 64) and P.wide_weights("fp16x2", 512) and not P.wide_weights("bf16", 64)
-    monkeypatch.setenv("HSIDM_WIDE_POLICY", "cout <= 128 and (cin <= 192 or ksize == 1)")
-    assert P.wide_weights("fp16", 128, 192, 3) and not P.wide_weights("fp16", 128, 256, 3) and P.wide_weights("fp16", 128, 256, 1)
-    assert not P.wide_weights("fp16x1", 64, 64, 3)                      # the hook only re-defines the "fp16" mode
-    monkeypatch.setenv("HSIDM_WIDE_POLICY", "__import__('os').system('true')")
-    with pytest.raises(ValueError):
-        P.wide_weights("fp16", 64, 64, 3)
+    assert not P.wide_weights("fp16x1", 64) and P.wide_weights("fp16x2", 512) and not P.wide_weights("bf16", 64) and not P.wide_weights("fp16d2", 64)
     with pytest.raises(ValueError):
         P.resolve_precision("fp8")
     # packing: a wide layer carries the low halves of every register-streaming layout, a narrow one none
     from hsi_dmgasr_amd import ops
-    monkeypatch.delenv("HSIDM_WIDE_POLICY")
     g = torch.Generator().manual_seed(0)
     w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
     pk = ops.PackedConv(w, None, "fp16", fold_ups=True)
@@ -536,7 +528,7 @@ def test_weight_dither_of_the_fp16_kernel_sets():
     rn_err = ((ref.to(torch.float16).double() - ref).abs() / ulp)
     assert float(mean_err[ok].max()) <= 0.125 + 1e-9 and float(rn_err.max()) > 0.49
     assert bool((sets[:, ref == 0] == 0).all())
-    # a layer that keeps hi + lo weights in a dithered set (HSIDM_DITHER_WIDE_COUT) would not be dithered: the low halves are the correction
+    # the LDS-tiled fallback's order (always hi + lo) is not dithered: its low halves are the correction
     assert float((packs[1].w_hi.double() - ops.PackedConv(w, None, "fp16").w_hi.double()).abs().max()) == 0.0    # (the LDS-tiled fallback's hi + lo order)
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # L2-side traffic of ONE tools/conv_bench.py shape from the FETCH_SIZE / WRITE_SIZE passes (gfx950: bytes = (2 * FETCH + WRITE) * 1024):
-#   bash tools/pmc_traffic_conv.sh SHAPE [BATCH] [PRECISION]        (environment switches such as HSIDM_SLICES_ON_ONE_XCD=1 pass through)
+#   bash tools/pmc_traffic_conv.sh SHAPE [BATCH] [PRECISION]        (environment switches such as HSIDM_NO_XCD_MAP=1 pass through)
 shape=$1; batch=${2:-240}; prec=${3:-fp16x1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmct_$shape; rm -rf $out; mkdir -p $out
