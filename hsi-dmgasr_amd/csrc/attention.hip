@@ -227,8 +227,12 @@ static int launch_attention(const void* qkv, void* out, int B, int N, int C, hip
 #define HSIDM_ATT_VRS 80
 #endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <int V> struct AttTag { static constexpr int value = V; };
 
-template <int NKT, int NW, typename E>
+// PF = 2 (the 8-wave form; C % 128 == 0): the K / V chunk stream is requested TWO chunks ahead into two register sets (the V chunks
+// across the softmax: V chunk 0 and 1 are on their way during the last K iterations) - the launch is bound by what its loads take to
+// come back (one workgroup per CU in lockstep bursts), not by the matrix pipe.
+template <int NKT, int NW, typename E, int PF = 1>
 __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) void attention_v2_kernel(const E* __restrict__ qkv, E* __restrict__ out, int C, float scale) {
     using bf16 = E;                                  // (the body below names its element type bf16; E = bf16 | fp16)
     using bf16x8 = typename Elem<E>::x8;
@@ -249,21 +253,28 @@ __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) v
     const bf16* base = qkv + (size_t)b * N * row3;
     const int nch = C >> 6;
 
-    u32x4 hreg[NV];
-    auto issue = [&](int chunk, int third) __attribute__((always_inline)) {
+    u32x4 hregs[PF][NV];
+    u32x4 (&hreg)[NV] = hregs[0];
+    // stream chunk s = 0 .. 2 nch - 1: K chunk s, then V chunk s - nch; register set `set`
+    auto issue_s = [&](auto set_tag, int sidx) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+        const int third = sidx < nch ? 1 : 2, chunk = sidx < nch ? sidx : sidx - nch;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * T;
-            hreg[i] = *reinterpret_cast<const u32x4*>(base + (size_t)(v >> 3) * row3 + third * C + chunk * 64 + (v & 7) * 8);
+            hregs[SET][i] = *reinterpret_cast<const u32x4*>(base + (size_t)(v >> 3) * row3 + third * C + chunk * 64 + (v & 7) * 8);
         }
     };
-    auto commit = [&](int bi, int rs) __attribute__((always_inline)) {
+    auto commit_s = [&](auto set_tag, int bi, int rs) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * T;
-            *reinterpret_cast<u32x4*>(buf + bi * BUFE + (v >> 3) * rs + (v & 7) * 8) = hreg[i];
+            *reinterpret_cast<u32x4*>(buf + bi * BUFE + (v >> 3) * rs + (v & 7) * 8) = hregs[SET][i];
         }
     };
+    auto issue = [&](int chunk, int third) __attribute__((always_inline)) { issue_s(AttTag<0>{}, third == 1 ? chunk : nch + chunk); };
+    auto commit = [&](int bi, int rs) __attribute__((always_inline)) { commit_s(AttTag<0>{}, bi, rs); };
 
     // ---- phase 1: S^T[key][query] = K Q^T, all NKT key tiles of this wave's 32 queries ----------------------------------
     const bf16* qrow = base + (size_t)(q0 + lr) * row3 + 8 * lh;
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) v
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
     issue(0, 1);
+    if constexpr (PF == 2) issue_s(AttTag<PF - 1>{}, 1);
     commit(0, KRS);
     __syncthreads();
     f32x16 sc[NKT];
@@ -278,10 +290,12 @@ __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) v
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int j = 0; j < 16; ++j) sc[kt][j] = 0.f;
-    for (int chunk = 0; chunk < nch; ++chunk) {
+    auto k_body = [&](int chunk, auto par_tag) __attribute__((always_inline)) {        // PF = 2: stream chunk `chunk` lives in set / buffer PAR
+        constexpr int PAR = decltype(par_tag)::value;
         const bool more = chunk + 1 < nch;
+        if constexpr (PF == 2) issue_s(AttTag<PAR>{}, chunk + 2);                     // (set PAR held this chunk: committed an iteration ago)
         if (more) {
-            issue(chunk + 1, 1);
+            if constexpr (PF == 1) issue(chunk + 1, 1);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) qn[kk] = *reinterpret_cast<const bf16x8*>(qrow + (chunk + 1) * 64 + kk * 16);
         }
@@ -293,16 +307,24 @@ __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) v
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * KRS + kk * 16);
                 sc[kt] = Elem<E>::mfma(a, qf[kk], sc[kt]);
             }
+        if constexpr (PF == 2) {
+            // the next stream chunk (K chunk + 1, or V chunk 0 behind the last K chunk: V's row pitch) into the other buffer
+            commit_s(AttTag<PAR ^ (PF - 1)>{}, (chunk + 1) & 1, more ? KRS : VRS);
+        } else if (more) commit((chunk + 1) & 1, KRS);
         if (more) {
-            commit((chunk + 1) & 1, KRS);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
         }
         __syncthreads();
+    };
+    if constexpr (PF == 2) {
+        for (int chunk = 0; chunk < nch; chunk += 2) { k_body(chunk, AttTag<0>{}); k_body(chunk + 1, AttTag<PF - 1>{}); }
+    } else {
+        for (int chunk = 0; chunk < nch; ++chunk) k_body(chunk, AttTag<0>{});
     }
 
     // ---- exact softmax over the keys of this lane's query (fp32); V chunk 0 is on its way meanwhile ---------------------
-    issue(0, 2);
+    if constexpr (PF == 1) issue(0, 2);
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -323,16 +345,20 @@ __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) v
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[kt][st][j] = (bf16)(sc[kt][8 * st + j] * inv);
-    commit(0, VRS);
-    __syncthreads();
+    if constexpr (PF == 1) {
+        commit(0, VRS);
+        __syncthreads();
+    }                       // (PF = 2: V chunk 0 went into its buffer behind the last K iteration, before that iteration's barrier)
 
     // ---- phase 2: O^T[channel][query] = V^T P^T, 64 channels per chunk ------------------------------------------------------
     const int gi = lane & 15;
     const int tr_lane = (4 * lh + (gi >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (gi & 3);   // this lane's address duty in its 16-lane group
     bf16* orow = out + ((size_t)b * N + q0 + lr) * C + 4 * lh;
-    for (int chunk = 0; chunk < nch; ++chunk) {
+    auto v_body = [&](int chunk, auto par_tag) __attribute__((always_inline)) {        // (nch is even in the PF = 2 form: V chunk c in set / buffer c & 1)
+        constexpr int PAR = decltype(par_tag)::value;
         const bool more = chunk + 1 < nch;
-        if (more) issue(chunk + 1, 2);
+        if constexpr (PF == 2) { if (chunk + 2 < nch) issue_s(AttTag<PAR>{}, nch + chunk + 2); }
+        else if (more) issue(chunk + 1, 2);
         const bf16* vb = buf + (chunk & 1) * BUFE + tr_lane;
         f32x16 o[2];
 #pragma unroll
@@ -362,18 +388,26 @@ __global__ __launch_bounds__(64 * NW, (HSIDM_ATT_VRS == 80 && NW < 8) ? 2 : 1) v
                 for (int e = 0; e < 4; ++e) w4[e] = (bf16)Elem<E>::sat(o[c2][4 * jg + e]);
                 *reinterpret_cast<bf16x4*>(orow + chunk * 64 + c2 * 32 + 8 * jg) = w4;
             }
-        if (more) commit((chunk + 1) & 1, VRS);
+        if (more) {
+            if constexpr (PF == 2) commit_s(AttTag<PAR ^ (PF - 1)>{}, (chunk + 1) & 1, VRS);
+            else commit((chunk + 1) & 1, VRS);
+        }
         __syncthreads();
+    };
+    if constexpr (PF == 2) {
+        for (int chunk = 0; chunk < nch; chunk += 2) { v_body(chunk, AttTag<0>{}); v_body(chunk + 1, AttTag<PF - 1>{}); }
+    } else {
+        for (int chunk = 0; chunk < nch; ++chunk) v_body(chunk, AttTag<0>{});
     }
 }
 
-template <int NKT, int NW, typename E>
+template <int NKT, int NW, typename E, int PF = 1>
 static int launch_attention_v2(const void* qkv, void* out, int B, int C, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 32 * NKT * HSIDM_ATT_VRS * 2;
     static PerDeviceOnce once;
-    if (int rc = raise_lds_cap(once, &attention_v2_kernel<NKT, NW, E>, lds)) return rc;
+    if (int rc = raise_lds_cap(once, &attention_v2_kernel<NKT, NW, E, PF>, lds)) return rc;
     dim3 grid(NKT / NW, B);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW, E>), grid, dim3(64 * NW), lds, s, (const E*)qkv, (E*)out, C,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_v2_kernel<NKT, NW, E, PF>), grid, dim3(64 * NW), lds, s, (const E*)qkv, (E*)out, C,
                        1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
@@ -569,17 +603,20 @@ extern "C" int hsidm_attention(int prec, const void* qkv, void* out, int B, int 
     // N = 256: ONE workgroup of 8 waves per image when the batch fills at least half of the CUs with such workgroups - K and V are then
     // read once per image instead of once per 128-query workgroup (-33 % of the launch's bytes, -8 % of its time at 240 images: the launch
     // is HBM-bound, 128 FLOP per byte; profiles/r06_attention/ab_forms.txt) - else two workgroups of 4 waves (more workgroups in flight).
-    // (diagnostic A/B switches: HSIDM_ATTENTION_V1=1 the score-panel kernel, =2 the 4-wave form whatever the batch)
+    // (diagnostic A/B switches: HSIDM_ATTENTION_V1=1 the score-panel kernel, =2 the 4-wave form whatever the batch, =3 the 8-wave form
+    // with the chunk stream requested ONE chunk ahead instead of two)
     const int att = hsidm::debug_get(hsidm::DBG_ATTENTION_V1);
     const bool one_wg = att != 2 && 2 * B >= hsidm::device_cus();
     if (prec == HSIDM_BF16 && (C & 63) == 0 && att != 1) {
-        if (N == 256) return one_wg ? hsidm::launch_attention_v2<8, 8, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream)
-                                    : hsidm::launch_attention_v2<8, 4, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256 && one_wg) return (att != 3 && (C & 127) == 0) ? hsidm::launch_attention_v2<8, 8, hsidm::bf16, 2>(qkv, out, B, C, (hipStream_t)stream)
+                                                                  : hsidm::launch_attention_v2<8, 8, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256) return hsidm::launch_attention_v2<8, 4, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
         if (N == 64) return hsidm::launch_attention_v2<2, 2, hsidm::bf16>(qkv, out, B, C, (hipStream_t)stream);
     }
     if (prec == HSIDM_F16 && (C & 63) == 0 && att != 1) {
-        if (N == 256) return one_wg ? hsidm::launch_attention_v2<8, 8, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream)
-                                    : hsidm::launch_attention_v2<8, 4, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256 && one_wg) return (att != 3 && (C & 127) == 0) ? hsidm::launch_attention_v2<8, 8, hsidm::f16, 2>(qkv, out, B, C, (hipStream_t)stream)
+                                                                  : hsidm::launch_attention_v2<8, 8, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
+        if (N == 256) return hsidm::launch_attention_v2<8, 4, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
         if (N == 64) return hsidm::launch_attention_v2<2, 2, hsidm::f16>(qkv, out, B, C, (hipStream_t)stream);
     }
     if (prec == HSIDM_F16) return hsidm::launch_attention<hsidm::f16, false, hsidm::f16>(qkv, out, B, N, C, (hipStream_t)stream);

@@ -18,7 +18,7 @@ g = torch.Generator().manual_seed(0)
 qkv = (torch.randn(B, hw, hw, 3 * C, generator=g) * 1.5).to(torch.float16).to(dev)
 q, k, v = qkv[:4].float().reshape(4, hw * hw, 3, C).unbind(2)
 ref = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
-for att in (0, 2, 1, 0, 2, 1):
+for att in (0, 3, 2, 0, 3, 2):
     with _lib.debug_switch("ATTENTION_V1", att):
         best = 1e9
         for _ in range(8):
