@@ -179,8 +179,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         }
     };
     // A chunk's staging request: issue_begin (channel slice, source pointer, the GroupNorm pairs) and issue_one(i), the load of halo
-    // vector i - eleven back to back ahead of the matrix phase.  (Round 6 spread them over the phase's taps, conv_v2's schedule: neutral
-    // to 1 % slower in-box, profiles/r06_ab/ab_spread_issue.txt - not kept.)
+    // vector i - eleven back to back ahead of the matrix phase.  (Round 6 measured two other placements, neither kept: spread over the
+    // phase's taps, conv_v2's schedule - neutral to 1 % slower, profiles/r06_ab/ab_spread_issue.txt; behind the weight request of tap 6, so
+    // that none of the phase's in-order weight waits depends on them - plain forms 1 % faster, the projection form spills,
+    // profiles/r06_ab/ab_late_issue.txt.)
     const E* is_src = reinterpret_cast<const E*>(p.src0);
     int is_cs = 0;
     auto issue_begin = [&](int chunk) __attribute__((always_inline)) {
