@@ -44,8 +44,8 @@ extern "C" {
 #define HSIDM_ACT_NONE  0
 #define HSIDM_ACT_LEAKY 1        /* LeakyReLU(0.01)                                                  */
 
-/* ABI version of this header: bumped whenever a struct below grows or a prototype changes (2: hsidm_conv_desc gained w_v2_ls /
- * w_v2_li).  hsidm_version() returns the version the LIBRARY was built against; a caller built against another header must refuse
+/* ABI version of this header: bumped whenever a struct below grows, a prototype changes or an entry point is added (2: hsidm_conv_desc
+ * gained w_v2_ls / w_v2_li; 3: hsidm_conv1x1_pair, and the bn == 64 projection steps of w_v2 are padded to three).  hsidm_version() returns the version the LIBRARY was built against; a caller built against another header must refuse
  * to run (a shorter hsidm_conv_desc would be read 16 bytes past its end) - the ctypes binding does (hsi-dmgasr_amd/_lib.py). */
 #define HSIDM_ABI_VERSION 3
 int hsidm_version(void);
