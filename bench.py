@@ -647,6 +647,29 @@ def compact_line(head, roof=None, parity=None, cpu=None, mode=HEADLINE, detail_p
     return line
 
 
+def chain_mix(window_ms, steps, n_other, t_other_ms, T, per_chain_other, total_batch):
+    """The per-chain mix of the two measured step times.  window_ms: the timed window (`steps` steps, `n_other` of them on the other -
+    fp32 - kernel set); t_other_ms: one step on that set (timed separately); a chain has T steps, per_chain_other of them on the other
+    set.  Returns the dict bench.py puts into `chain_mix` / `config`, or None when the window held nothing but other-set steps."""
+    if t_other_ms is None or steps <= n_other:
+        return None
+    t_base = (window_ms - n_other * t_other_ms) / (steps - n_other)
+    ms_mix = ((T - per_chain_other) * t_base + per_chain_other * t_other_ms) / T
+    n20 = min(per_chain_other, 20)
+    return dict(ms_per_step_base_mode=t_base, ms_per_step_other_mode=t_other_ms, steps_per_chain_other_mode=per_chain_other, chain_steps=T,
+                ms_per_step_chain_mix=ms_mix, value_chain_mix=total_batch / (ms_mix * 1e-3),
+                # the same policy on the chain length the reference SHIPS (config/sr_sr3_16_128.json:98,104: n_timestep 20 for validation):
+                # the high-gain steps are the first ones of a chain whatever its length, so a 20-step chain pays all of them in 20 steps
+                # (steady-state step times; a chain's graph captures are not in it)
+                value_T20=total_batch * 20 / ((n20 * t_other_ms + (20 - n20) * t_base) * 1e-3))
+
+
+def value_is_mix(mix, n_other, steps, T, per_chain_other):
+    """Is `value` the per-chain mix?  Yes when the window held fewer other-set steps than their share of a chain (the driver's 20 steps
+    hold none of the eight); a window that is a whole chain IS the mix and is reported as measured."""
+    return mix is not None and n_other * T < per_chain_other * steps
+
+
 def timed_mode_replays(run, mode, n):
     """Average ms of `n` replays of the run's captured graph of `mode` (after the timed region; the state just keeps walking)."""
     g = run.graphs.get(mode)
@@ -776,16 +799,9 @@ def main():
         if per_chain_other and rank == 0:
             other = next(m for m in run.modes if family(m) != base_mode)
             t_other = timed_mode_replays(run, other, 8)
-            if t_other is not None and args.steps > n_other:
-                t_base = (dt * 1e3 - n_other * t_other) / (args.steps - n_other)
-                ms_mix = ((T - per_chain_other) * t_base + per_chain_other * t_other) / T
-                mix = dict(ms_per_step_base_mode=t_base, ms_per_step_other_mode=t_other, other_mode=other,
-                           steps_per_chain_other_mode=per_chain_other, chain_steps=T, ms_per_step_chain_mix=ms_mix,
-                           value_chain_mix=total_patches * GROUPS / (ms_mix * 1e-3),
-                           # the same policy on the chain length the reference SHIPS (config/sr_sr3_16_128.json:98,104: n_timestep 20 for
-                           # validation): the high-gain steps are the first ones of a chain whatever its length, so a 20-step chain pays
-                           # all of them in 20 steps (steady-state step times; a chain's graph captures are not in it)
-                           value_T20=total_patches * GROUPS * 20 / ((min(per_chain_other, 20) * t_other + max(20 - per_chain_other, 0) * t_base) * 1e-3))
+            mix = chain_mix(dt * 1e3, args.steps, n_other, t_other, T, per_chain_other, total_patches * GROUPS)
+            if mix is not None:
+                mix["other_mode"] = other
         if use_dist:
             # the path's one data collective: every rank ends with all SR cubes (here: cube-sized stand-ins for the decoded
             # patches, 31 x 128 x 128 fp32 each = 2.0 MB per patch)
@@ -931,7 +947,7 @@ def main():
         # two measured step times - (T - n) x window step + n x fp32-set step, the latter timed right behind the window - and the raw
         # window figures stay in `config`.  A window that is a whole chain (the default 1000 steps) IS the mix and is reported as measured.
         win_value, win_ms = args.steps * total_batch / dt, dt / args.steps * 1e3
-        use_mix = mix is not None and n_other * run_T < per_chain_other * args.steps
+        use_mix = value_is_mix(mix, n_other, args.steps, run_T, per_chain_other)
         value, ms_step = (mix["value_chain_mix"], mix["ms_per_step_chain_mix"]) if use_mix else (win_value, win_ms)
         head = {
             "metric": "UNet denoise-steps/sec x batch, CAVE 31-band 16->128, 1000-step p_sample_loop",

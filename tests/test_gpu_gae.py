@@ -331,3 +331,37 @@ def test_spectral_block_pair_in_one_launch(dev, prec, shape):
     e2 = rel_err(y2.double().cpu().numpy(), want.numpy())
     log_err("conv1x1_two_launches_%dx%dx%d" % shape, prec, e2)
     assert e < 1.1 * e2 + 1e-6, (e, e2)
+
+
+def test_spectral_block_pair_refuses_what_it_cannot_run(dev):
+    """hsidm_conv1x1_pair's argument checks (include/hsidm.h): null pointers and sizes that do not divide are HSIDM_E_BADARG, element types
+    without a pair form and pixel counts that are not whole 64-pixel groups HSIDM_E_UNSUPPORTED - and the module falls back to its two
+    launches for such maps (a 10 x 10 map) with the same result as the oracle's block."""
+    from hsi_dmgasr_amd import _lib, gae, ops
+    from oracle import gae as ogae
+    L = _lib.lib()
+    x = torch.zeros(1, 8, 8, 64, device=dev)
+    w = torch.zeros(2 * 2 * 4 * 64 * 8, dtype=torch.bfloat16, device=dev)
+    out = torch.empty_like(x)
+    st = _lib.stream_ptr()
+    call = lambda prec, xp, wp, wl, M, HW: L.hsidm_conv1x1_pair(prec, xp, wp, wl, None, 0, None, _lib.ptr(out), None, M, HW, st)
+    assert call(_lib.F32X3, _lib.ptr(x), _lib.ptr(w), _lib.ptr(w), 64, 64) == 0
+    assert call(_lib.F32X3, None, _lib.ptr(w), _lib.ptr(w), 64, 64) < 0                 # no input
+    assert call(_lib.F32X3, _lib.ptr(x), _lib.ptr(w), None, 64, 64) < 0                 # the pair forms multiply by hi + lo weights
+    assert call(_lib.F32X3, _lib.ptr(x), _lib.ptr(w), _lib.ptr(w), 65, 64) < 0          # M is not a whole number of images
+    assert call(_lib.BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(w), 64, 64) < 0           # no bf16 form (the autoencoder has none either)
+    assert call(_lib.F32X3, _lib.ptr(x), _lib.ptr(w), _lib.ptr(w), 100, 100) < 0        # 100 pixels: not whole 64-pixel groups
+    torch.cuda.synchronize()
+    # the module on such a map: two launches, same arithmetic
+    blk = gae.ResAttentionBlock(gae.default_conv, 64, 1, act=torch.nn.LeakyReLU(), res_scale=0.1).to(dev).eval()
+    sd = fill_synth(blk, "pair_fallback.")
+    xr = torch.randn(2, 64, 10, 10, generator=torch.Generator().manual_seed(3))
+    got = ops.to_nchw(blk._run(ops.to_nhwc(xr.to(dev), "fp32"), "fp32"), "fp32")
+    with torch.no_grad():
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xr, sd["body.0.weight"], sd["body.0.bias"]), 0.01)
+        r = torch.nn.functional.conv2d(h, sd["body.2.weight"], sd["body.2.bias"])
+        y = r.mean(dim=(2, 3), keepdim=True)
+        y = torch.sigmoid(torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(y, sd["body.3.conv_du.0.weight"], sd["body.3.conv_du.0.bias"])),
+                                                     sd["body.3.conv_du.2.weight"], sd["body.3.conv_du.2.bias"]))
+        want = (r * y) * 0.1 + xr
+    check("res_attention_block_10x10_two_launches", "fp32", got, want, tol=1e-4)

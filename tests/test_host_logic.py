@@ -665,3 +665,28 @@ def test_the_oracle_decode_of_a_fixtures_latents_is_the_references_cube_before_t
     gc = H.load_npz("chains/chi_%s_n%d_T%d.npz" % CHAIN_CHIKUSEI)
     rawc = H.reference_unclamped_cube("cpu:chi", "gae_chi_state.npz", 128, gc["x0"], 16, 4)
     assert H.rel_err(np.clip(rawc[::4], 0.0, 1.0), gc["y_sub4"][0]) < 2e-5
+
+
+def test_bench_value_is_the_per_chain_mix_of_the_two_step_times():
+    """bench.py: `value` for a window that held fewer fp32-set steps than their share of a 1000-step chain is the per-chain mix of the
+    two measured step times; a window that is a whole chain is reported as measured; value_T20 puts the same two times on the
+    reference's shipped 20-step chain (all eight fp32-set steps in 20)."""
+    bench = _load_bench()
+    T, n_hi, batch = 1000, 8, 240
+    # the driver's form: 20 window steps at 22.0 ms, none on the fp32 set (60 ms, timed separately)
+    mix = bench.chain_mix(20 * 22.0, 20, 0, 60.0, T, n_hi, batch)
+    assert abs(mix["ms_per_step_base_mode"] - 22.0) < 1e-9 and abs(mix["ms_per_step_chain_mix"] - (992 * 22.0 + 8 * 60.0) / 1000) < 1e-9
+    assert abs(mix["value_chain_mix"] - batch / (mix["ms_per_step_chain_mix"] * 1e-3)) < 1e-6
+    assert abs(mix["value_T20"] - batch * 20 / ((8 * 60.0 + 12 * 22.0) * 1e-3)) < 1e-6
+    assert bench.value_is_mix(mix, 0, 20, T, n_hi)
+    # the default run: 1000 steps = one whole chain with its eight fp32-set steps inside -> the window IS the mix
+    whole = 992 * 22.0 + 8 * 60.0
+    mix2 = bench.chain_mix(whole, 1000, 8, 60.0, T, n_hi, batch)
+    assert abs(mix2["ms_per_step_base_mode"] - 22.0) < 1e-9 and abs(mix2["ms_per_step_chain_mix"] - whole / 1000) < 1e-9
+    assert not bench.value_is_mix(mix2, 8, 1000, T, n_hi)
+    # a window with MORE than its share (e.g. 100 steps holding all eight) is reported as measured too; no fp32-set time: no mix
+    assert not bench.value_is_mix(bench.chain_mix(92 * 22.0 + 8 * 60.0, 100, 8, 60.0, T, n_hi, batch), 8, 100, T, n_hi)
+    assert bench.chain_mix(20 * 22.0, 20, 0, None, T, n_hi, batch) is None and not bench.value_is_mix(None, 0, 20, T, n_hi)
+    # a policy with twelve such steps on a 20-step chain: all twelve count, eight others
+    m12 = bench.chain_mix(20 * 22.0, 20, 0, 60.0, T, 12, batch)
+    assert abs(m12["value_T20"] - batch * 20 / ((12 * 60.0 + 8 * 22.0) * 1e-3)) < 1e-6
