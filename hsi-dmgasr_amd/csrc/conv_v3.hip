@@ -339,17 +339,14 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
         for (int chunk = 0; chunk < n_loop; ++chunk) {
             commit_all(chunk >= nch);                           // hreg holds (item, chunk): transform -> LDS
             if (chunk == 0) HSIDM_STAMP(it, 1);
-            if (PROJ && chunk == nch) HSIDM_STAMP(it, 6);
             stage_advance();
             if (st_valid) {                                     // request the next chunk's raw vectors; they fly during the MFMAs
                 if (st_chunk == 0) describe(st_item);
                 issue_all(st_chunk);
             }
             if (chunk == 0) HSIDM_STAMP(it, 2);
-            if (PROJ && chunk == nch) HSIDM_STAMP(it, 7);
             lds_barrier();
             if (chunk == 0) HSIDM_STAMP(it, 3);
-            if (PROJ && chunk == nch) HSIDM_STAMP(it, 8);
             if (chunk == nch - 1) {
                 // FiLM + bias of the lane's two couts, needed by the epilogue: ordinary (compiler-tracked) loads issued HERE, ahead of
                 // the last chunk's MFMA phase.  vmcnt retires in order and the phase issues 36+ weight loads behind them, so the
@@ -475,10 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
             }
             HSIDM_SETPRIO(0);
             if (chunk == 0) HSIDM_STAMP(it, 4);
-            if (PROJ && chunk == nch) HSIDM_STAMP(it, 9);
             lds_barrier();                                      // every wave is done reading: the tile may be overwritten
             if (chunk == 0) HSIDM_STAMP(it, 5);
-            if (PROJ && chunk == nch) HSIDM_STAMP(it, 10);
         }
         if constexpr (PROJ) {
             // ---- the ResnetBlock's 1x1 projection of a second input (hsidm_conv_desc.ph[1]; reference unet.py:102-103,110) as up to THREE
@@ -492,13 +487,15 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                 const bool live = j < p.pchunks;                // workgroup-uniform
                 if (live) {
                     commit_all(true);
-                    HSIDM_STAMP(it, 6 + j);
+                    if (j == 0) HSIDM_STAMP(it, 6);             // (diagnostic builds: slots 6 .. 10 = the first projection chunk's phases)
                     stage_advance();
                     if (st_valid) {
                         if (st_chunk == 0) describe(st_item);
                         issue_all(st_chunk);
                     }
+                    if (j == 0) HSIDM_STAMP(it, 7);
                     lds_barrier();
+                    if (j == 0) HSIDM_STAMP(it, 8);
                 }
                 b_issue(ring[(j + 2) % 3]);
                 if (live) {
@@ -523,7 +520,9 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvV2Params p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     HSIDM_SETPRIO(0);
+                    if (j == 0) HSIDM_STAMP(it, 9);
                     lds_barrier();                              // every wave is done reading: the tile may be overwritten
+                    if (j == 0) HSIDM_STAMP(it, 10);
                 }
             }
         }
