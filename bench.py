@@ -21,11 +21,12 @@ roofline row, and with --detail the other precision modes, small batches, the gr
 
 The headline precision mode is "fp16" (precision.py: fp16 storage and MFMA operands, ONE weight pass with the weights dithered
 over the chain's steps so that their rounding averages out instead of biasing the chain; the eight steps of a chain whose update
-has an error gain >= 1/4 run on the fp32 kernel set).  Those eight steps are the FIRST eight of a chain: the warm-up (>= 16 steps:
-every kernel set's eager step and graph capture) consumes them, so a timed window shorter than the rest of the chain (`--steps`
-< ~980, e.g. the driver's --steps 20) contains NONE of them.  The line says how many it contained
-(`config.fp32_mode_steps_in_window`), times the fp32-set graph separately and reports the per-chain mix (992 fp16-set + 8
-fp32-set steps) as `config.value_chain_mix` beside the measured `value`.
+has an error gain >= 1/4 run on the policy's wide kernel sets: the first on "fp32", the next seven on "fp32h" - fp32 storage, fp16
+operands, two weight passes).  Those eight steps are the FIRST eight of a chain: the warm-up (>= 16 steps: every kernel set's eager
+step and graph capture) consumes them, so a timed window shorter than the rest of the chain (`--steps` < ~980, e.g. the driver's
+--steps 20) contains NONE of them.  The line says how many it contained (`config.wide_set_steps_in_window`), times each wide set's
+graph separately (`config.ms_per_step_wide_sets`) and, for such a window, reports the per-chain mix (992 fp16-set + 7 fp32h-set +
+1 fp32-set steps) as `value`, the raw window rate as `config.value_window`.
 """
 import argparse
 import json
@@ -647,34 +648,50 @@ def compact_line(head, roof=None, parity=None, cpu=None, mode=HEADLINE, detail_p
     return line
 
 
-def chain_mix(window_ms, steps, n_other, t_other_ms, T, per_chain_other, total_batch):
-    """The per-chain mix of the two measured step times.  window_ms: the timed window (`steps` steps, `n_other` of them on the other -
-    fp32 - kernel set); t_other_ms: one step on that set (timed separately); a chain has T steps, per_chain_other of them on the other
-    set.  Returns the dict bench.py puts into `chain_mix` / `config`, or None when the window held nothing but other-set steps."""
-    if t_other_ms is None or steps <= n_other:
+def chain_mix(window_ms, steps, others, T, total_batch):
+    """The per-chain mix of the measured step times.  window_ms: the timed window of `steps` steps; others: one dict per kernel set of the
+    chain other than its base set - {"mode", "per_chain" (steps of a chain on it), "in_window" (steps of the window on it), "ms" (one step
+    on it, timed separately)} - for the "fp16" policy the fp32 set (the first step of a chain) and the fp32h set (the next seven).
+    Returns the dict bench.py puts into `chain_mix` / `config`, or None when a set could not be timed or the window held no base-set step."""
+    n_in = sum(o["in_window"] for o in others)
+    if any(o["ms"] is None for o in others) or steps <= n_in:
         return None
-    t_base = (window_ms - n_other * t_other_ms) / (steps - n_other)
-    ms_mix = ((T - per_chain_other) * t_base + per_chain_other * t_other_ms) / T
-    n20 = min(per_chain_other, 20)
-    return dict(ms_per_step_base_mode=t_base, ms_per_step_other_mode=t_other_ms, steps_per_chain_other_mode=per_chain_other, chain_steps=T,
+    t_base = (window_ms - sum(o["in_window"] * o["ms"] for o in others)) / (steps - n_in)
+    n_pc = sum(o["per_chain"] for o in others)
+    t_pc = sum(o["per_chain"] * o["ms"] for o in others)
+    ms_mix = ((T - n_pc) * t_base + t_pc) / T
+    # the same policy on the chain length the reference SHIPS (config/sr_sr3_16_128.json:98,104: n_timestep 20 for validation): the
+    # high-gain steps are the first ones of a chain whatever its length, so a 20-step chain pays all of them in 20 steps (steady-state
+    # step times; a chain's graph captures are not in it)
+    t20 = t_pc + (20 - n_pc) * t_base if n_pc <= 20 else None
+    return dict(ms_per_step_base_mode=t_base, chain_steps=T, steps_per_chain_other_modes=n_pc,
+                other_modes=[dict(mode=o["mode"], steps_per_chain=o["per_chain"], steps_in_window=o["in_window"], ms_per_step=o["ms"]) for o in others],
                 ms_per_step_chain_mix=ms_mix, value_chain_mix=total_batch / (ms_mix * 1e-3),
-                # the same policy on the chain length the reference SHIPS (config/sr_sr3_16_128.json:98,104: n_timestep 20 for validation):
-                # the high-gain steps are the first ones of a chain whatever its length, so a 20-step chain pays all of them in 20 steps
-                # (steady-state step times; a chain's graph captures are not in it)
-                value_T20=total_batch * 20 / ((n20 * t_other_ms + (20 - n20) * t_base) * 1e-3))
+                value_T20=None if t20 is None else total_batch * 20 / (t20 * 1e-3))
 
 
-def value_is_mix(mix, n_other, steps, T, per_chain_other):
-    """Is `value` the per-chain mix?  Yes when the window held fewer other-set steps than their share of a chain (the driver's 20 steps
-    hold none of the eight); a window that is a whole chain IS the mix and is reported as measured."""
-    return mix is not None and n_other * T < per_chain_other * steps
+def value_is_mix(mix, others, steps, T):
+    """Is `value` the per-chain mix?  Yes when the window held fewer steps of some other set than that set's share of a chain (the
+    driver's 20 steps hold none of the eight); a window that is a whole chain IS the mix and is reported as measured."""
+    return mix is not None and any(o["in_window"] * T < o["per_chain"] * steps for o in others)
 
 
 def timed_mode_replays(run, mode, n):
     """Average ms of `n` replays of the run's captured graph of `mode` (after the timed region; the state just keeps walking)."""
     g = run.graphs.get(mode)
     if g is None:
-        return None
+        # a set the window and the warm-up ran at most once (the fp32 set is ONE step per chain): captured here, the way ReverseRun.step does
+        if not (run.fused and run.gd.use_graph):
+            return None
+        if mode not in run._eager_done:
+            run._enqueue(mode)
+            run._eager_done.add(mode)
+        torch.cuda.synchronize()
+        g = run.graphs[mode] = torch.cuda.CUDAGraph()
+        if run._pool is None:
+            run._pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=run._pool):
+            run._enqueue(mode)
     g.replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -794,14 +811,15 @@ def main():
         T = run_T = run.T
         base_mode = family(run.modes[-1])
         n_other = sum(1 for k in range(n_warm, n_warm + args.steps) if family(run.modes[k % T]) != base_mode)
-        per_chain_other = n_hi
+        others = []
+        for om in dict.fromkeys(m for m in run.modes if family(m) != base_mode):      # (in chain order: "fp32", then "fp32h")
+            others.append(dict(mode=om, per_chain=sum(1 for m in run.modes if m == om),
+                               in_window=sum(1 for k in range(n_warm, n_warm + args.steps) if run.modes[k % T] == om), ms=None))
         mix = None
-        if per_chain_other and rank == 0:
-            other = next(m for m in run.modes if family(m) != base_mode)
-            t_other = timed_mode_replays(run, other, 8)
-            mix = chain_mix(dt * 1e3, args.steps, n_other, t_other, T, per_chain_other, total_patches * GROUPS)
-            if mix is not None:
-                mix["other_mode"] = other
+        if others and rank == 0:
+            for o in others:
+                o["ms"] = timed_mode_replays(run, o["mode"], 8)
+            mix = chain_mix(dt * 1e3, args.steps, others, T, total_patches * GROUPS)
         if use_dist:
             # the path's one data collective: every rank ends with all SR cubes (here: cube-sized stand-ins for the decoded
             # patches, 31 x 128 x 128 fp32 each = 2.0 MB per patch)
@@ -947,7 +965,7 @@ def main():
         # two measured step times - (T - n) x window step + n x fp32-set step, the latter timed right behind the window - and the raw
         # window figures stay in `config`.  A window that is a whole chain (the default 1000 steps) IS the mix and is reported as measured.
         win_value, win_ms = args.steps * total_batch / dt, dt / args.steps * 1e3
-        use_mix = value_is_mix(mix, n_other, args.steps, run_T, per_chain_other)
+        use_mix = value_is_mix(mix, others, args.steps, run_T)
         value, ms_step = (mix["value_chain_mix"], mix["ms_per_step_chain_mix"]) if use_mix else (win_value, win_ms)
         head = {
             "metric": "UNet denoise-steps/sec x batch, CAVE 31-band 16->128, 1000-step p_sample_loop",
@@ -964,12 +982,14 @@ def main():
                        "batch_per_gpu": batch, "global_batch": total_batch, "parallelism": "dp%d" % world,
                        "precision_mode": DTYPE[args.precision],
                        "warmup_steps_run": n_warm,       # >= --warmup: every kernel set's eager step and capture lie before the clock starts
-                       "fp32_mode_steps_in_window": n_other,
+                       "wide_set_steps_in_window": n_other,
                        "value_is": "per-chain mix of the measured step times" if use_mix else "the timed window as measured",
                        "value_window": _r(win_value, 5), "ms_per_step_window": _r(win_ms, 5),
                        "ms_per_step_chain_mix": None if mix is None else _r(mix["ms_per_step_chain_mix"], 5),
                        "value_chain_mix": None if mix is None else _r(mix["value_chain_mix"], 5),
-                       "ms_per_step_fp32_set": None if mix is None else _r(mix["ms_per_step_other_mode"], 5),
+                       # one step on each of the policy's wide kernel sets (fp32: the first step of a chain; fp32h: the next seven)
+                       "ms_per_step_wide_sets": None if mix is None else {o["mode"]: _r(o["ms_per_step"], 5) for o in mix["other_modes"]},
+                       "steps_per_chain_wide_sets": None if mix is None else {o["mode"]: o["steps_per_chain"] for o in mix["other_modes"]},
                        # the reference's shipped validation chain length (T = 20): all of the policy's fp32-set steps in 20 steps
                        "value_T20": None if mix is None else _r(mix["value_T20"], 5)},
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": _r(allgather_ms),

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HSIDM_LIB") or os.path.join(_HERE, "libhsidm.so")
 
 ABI_VERSION = 3          # include/hsidm.h: HSIDM_ABI_VERSION (2: the ConvDesc below has w_v2_ls / w_v2_li; 3: hsidm_conv1x1_pair)
-BF16, F32X3, F16 = 0, 1, 2
+BF16, F32X3, F16, F32H = 0, 1, 2, 3      # (F32H: hsidm_conv2d only - ops.PackedConv sets it; as a STORAGE type "fp32h" is F32X3)
 XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 
@@ -168,8 +168,8 @@ def ptr(t):
 def prec_id(precision):
     if precision == "bf16":
         return BF16
-    if precision in ("fp32", "f32x3"):
-        return F32X3
+    if precision in ("fp32", "f32x3", "fp32h"):
+        return F32X3            # ("fp32h": fp32 tensors everywhere; only its convolutions differ - include/hsidm.h, HSIDM_F32H)
     if precision in ("fp16", "fp16x1", "fp16x2") or (isinstance(precision, str) and precision.startswith("fp16d") and precision[5:].isdigit()):
         return F16              # ("fp16d<k>": the dithered one-pass sets of the "fp16" policy; precision.dither_phase validates k)
     raise ValueError("precision must be 'bf16', 'fp16' or 'fp32', got %r" % (precision,))

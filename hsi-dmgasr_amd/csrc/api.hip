@@ -23,6 +23,7 @@ int conv_v2_run_bf16(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t
 int conv_v2_run_f16(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_run_f16w(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_run_f32x3(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
+int conv_v2_run_f32h(int tile_kind, int bn, int xf, ConvV2Params& p, hipStream_t s);
 int conv_v2_subs(int tile_kind, int bn);
 int conv_v2_slots();
 int conv_v3_run(ConvV2Params& p, int nchw, int elem, int np, int spl, hipStream_t s);
@@ -69,13 +70,17 @@ extern "C" const char* hsidm_error_string(int code) {
     }
 }
 
-extern "C" int hsidm_conv_bk(int prec) { return (prec == HSIDM_BF16 || prec == HSIDM_F16) ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG); }
+extern "C" int hsidm_conv_bk(int prec) {
+    return (prec == HSIDM_BF16 || prec == HSIDM_F16 || prec == HSIDM_F32H) ? 64 : (prec == HSIDM_F32X3 ? 32 : HSIDM_E_BADARG);
+}
 
 // the 16-bit throughput modes share every kernel (templates over the element type, common.h: Elem)
 static inline bool is16(int prec) { return prec == HSIDM_BF16 || prec == HSIDM_F16; }
 // ... and the persistent 3x3 kernel also has an fp32 form (fp32 storage, bf16 hi + lo operands: conv_v2.h, AP = 2), taken when the
 // descriptor carries both halves of the weights in the register-streaming order
-static inline bool v2_mode(const hsidm_conv_desc* d) { return is16(d->prec) || (d->prec == HSIDM_F32X3 && d->w_v2 && d->w_v2_lo); }
+// (HSIDM_F32H: fp32 storage, one fp16 activation operand, fp16 hi + lo weights - only the persistent forms exist)
+static inline bool f32s(int prec) { return prec == HSIDM_F32X3 || prec == HSIDM_F32H; }
+static inline bool v2_mode(const hsidm_conv_desc* d) { return is16(d->prec) || (f32s(d->prec) && d->w_v2 && d->w_v2_lo); }
 
 enum { PATH_V1 = 0, PATH_V2 = 1, PATH_G1 = 3, PATH_V3 = 4, PATH_SK = 5 };
 
@@ -151,7 +156,8 @@ static bool force_v1_1x1() { return debug_get(DBG_1X1_V1) == 1; }
 
 static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& tile_kind, int& path) {
     if (!d) return HSIDM_E_BADARG;
-    if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3 && d->prec != HSIDM_F16) return HSIDM_E_BADARG;
+    if (d->prec != HSIDM_BF16 && d->prec != HSIDM_F32X3 && d->prec != HSIDM_F16 && d->prec != HSIDM_F32H) return HSIDM_E_BADARG;
+    if (d->prec == HSIDM_F32H && (!d->w_v2 || !d->w_v2_lo)) return HSIDM_E_BADARG;
     if (d->w_v2_lo && (d->prec == HSIDM_BF16 || !d->w_v2)) return HSIDM_E_BADARG;
     if ((d->w_v2_ls || d->w_v2_li) && (!d->w_v2_lo || !d->w_v2_ls || !d->w_v2_li || d->prec != HSIDM_F16)) return HSIDM_E_BADARG;
     if (d->nphase < 1 || d->nphase > 2) return HSIDM_E_BADARG;
@@ -222,6 +228,10 @@ static int conv_validate(const hsidm_conv_desc* d, int& Hout, int& Wout, int& ti
         if (d->ksize == 1 && (xf == HSIDM_XF_NONE || xf == HSIDM_XF_AFFINE) && d->act == HSIDM_ACT_NONE && !d->film &&
             (d->bn == 64 || d->bn == 128) && d->Cout % d->bn == 0 && (Hout * Wout) % 64 == 0 && !force_v1_1x1()) path = PATH_G1;
     }
+    // HSIDM_F32H has the 8x16-tile forms of the persistent 3x3 kernel and the plain GEMM, nothing else (two-image tiles and the GEMM's
+    // GroupNorm prologue spill at two workgroups per CU with 8-byte staging registers): the caller runs every other shape with
+    // HSIDM_F32X3 weights - same tensors in, same tensors out
+    if (d->prec == HSIDM_F32H && !((path == PATH_V2 && tile_kind == 0) || (path == PATH_G1 && xf == HSIDM_XF_NONE))) return HSIDM_E_UNSUPPORTED;
     if ((path == PATH_V2 || d->nphase == 2) && d->workspace) {
         const int parts = sk_parts(d, Hout, Wout);
         if (parts > 0 && d->workspace_bytes >= (int64_t)parts * d->B * Hout * Wout * d->Cout * 4) path = PATH_SK;
@@ -301,7 +311,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
     const int rc = conv_validate(d, Hout, Wout, tile_kind, path);
     if (rc != HSIDM_OK) return rc;
     const bool use_v2 = path == PATH_V2 || path == PATH_V3;
-    if (!d->out || !d->w_hi) return HSIDM_E_BADARG;
+    if (!d->out || (!d->w_hi && d->prec != HSIDM_F32H)) return HSIDM_E_BADARG;       // (HSIDM_F32H: only w_v2 / w_v2_lo are read)
     if (d->prec == HSIDM_F32X3 && !use_v2 && path != PATH_G1 && !d->w_lo) return HSIDM_E_BADARG;      // (the persistent forms read w_v2 / w_v2_lo)
     const int elem = d->prec == HSIDM_F16 ? 1 : 0;
     const int bk = (use_v2 || path == PATH_G1) ? 64 : hsidm_conv_bk(d->prec);        // (the persistent kernels walk 64-channel chunks in every mode)
@@ -333,7 +343,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         const hsidm_conv_phase& s0 = d->ph[0];
         return conv1x1_g_run(d->bn, s0.transform, reinterpret_cast<const bf16*>(s0.src0), reinterpret_cast<const bf16*>(s0.C1 > 0 ? s0.src1 : nullptr),
                              s0.C0, s0.C1, s0.gn_ab, reinterpret_cast<const bf16*>(d->w_v2), reinterpret_cast<const bf16*>(d->w_v2_lo),
-                             d->prec == HSIDM_F32X3 ? 2 : elem,
+                             d->prec == HSIDM_F32X3 ? 2 : (d->prec == HSIDM_F32H ? 3 : elem),
                              d->bias, reinterpret_cast<const bf16*>(d->res),
                              d->res_scale, reinterpret_cast<bf16*>(d->out), reinterpret_cast<float2*>(d->stats), d->B * Hout * Wout,
                              Hout * Wout, d->Cout, d->ksize == 3 ? 2 : (s0.C0 + s0.C1 + 127) / 128 * 2, d->ksize == 3 ? Hout : 0,
@@ -363,6 +373,7 @@ extern "C" int hsidm_conv2d(const hsidm_conv_desc* d, void* stream) {
         const int np = d->w_v2_lo ? 2 : 1;
         auto v2_run = [&](int tk, int bn_, int xf_) {
             if (d->prec == HSIDM_F32X3) return conv_v2_run_f32x3(tk, bn_, xf_, v, s);
+            if (d->prec == HSIDM_F32H) return conv_v2_run_f32h(tk, bn_, xf_, v, s);
             if (!elem) return conv_v2_run_bf16(tk, bn_, xf_, v, s);
             return np == 2 ? conv_v2_run_f16w(tk, bn_, xf_, v, s) : conv_v2_run_f16(tk, bn_, xf_, v, s);
         };

@@ -62,6 +62,9 @@ struct C1gParams {
 // F32 (with E = bf16, NP = 2): the fp32 mode on this kernel - fp32 activations in HBM (two 16-byte vectors per staged pixel-vector, fp32
 // GroupNorm pairs, fp32 stores), every staged value split into bf16 hi + lo into TWO tiles per buffer, three MFMAs per product
 // (conv_v2.h, AP = 2); the 4-byte epilogue patches (40 KB) get a region of their own: 112 KB of LDS, one workgroup per CU.
+// F32 with E = f16, NP = 2: the "fp32h" kernel set (precision.py) - fp32 storage, fp32 GroupNorm pairs and stores, but ONE fp16 activation
+// operand (the staged value rounded once) against fp16 hi + lo weights: two MFMAs per product, one tile per buffer, 80 KB of LDS - two
+// workgroups per CU again.
 // PAIR (BN = 64, Cin = Cout = 64, XF_NONE): TWO 1x1 convolutions in one launch, out = W2 act(W1 x + b1) + b2 - the body of the group
 // autoencoder's spectral ResAttentionBlock (common.py:250-271 with kernel_size 1: conv, LeakyReLU, conv; AE.py:102-109).  The item's two
 // 64-channel "chunks" are the two convolutions: chunk 0 multiplies the staged x tile by W1 (weight step 0); its accumulators - plus b1,
@@ -71,14 +74,14 @@ struct C1gParams {
 // two-chunk trip of the plain kernel (half of its matrix instructions on these layers).  Epilogue (b2, statistics for the CALayer's
 // global average, store) as before.
 template <int BN, int XF, int IM = 0, typename E = bf16, int NP = 1, bool F32 = false, bool PAIR = false>
-__global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gParams p) {
+__global__ __launch_bounds__(256, (F32 && __is_same(E, bf16)) ? 1 : 2) void conv1x1_g_kernel(const C1gParams p) {
     static_assert(!PAIR || (BN == 64 && XF == XF_NONE && IM == 0), "the 1x1 pair: 64 -> 64 -> 64, no input transform");
     using EL = Elem<E>;
     using x8 = typename EL::x8;
     using x2 = typename EL::x2;
     using S = typename std::conditional<F32, float, E>::type;      // storage type of activations in HBM
     static_assert(!F32 || (NP == 2 && IM == 0), "the fp32 form: hi + lo weights, plain 1x1");
-    constexpr int SV = F32 ? 2 : 1, AP = F32 ? 2 : 1;
+    constexpr int SV = F32 ? 2 : 1, AP = (F32 && __is_same(E, bf16)) ? 2 : 1;      // (activation operands per staged value: hi [+ lo])
     constexpr int WN = BN / 32, WM = 4 / WN, MR = 128 / WM / 32;
     constexpr int PSTR = 80, TILE = 128 * PSTR, BUFE = AP * TILE;
     constexpr int SCR_STR = 40;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 #pragma unroll
             for (int k = 0; k < 8; ++k) { o[k] = (E)v[k]; ol[k] = (E)(v[k] - (float)o[k]); }
             *reinterpret_cast<x8*>(xt + buf * BUFE + hv0 + i * 32 * PSTR) = o;
-            *reinterpret_cast<x8*>(xt + buf * BUFE + TILE + hv0 + i * 32 * PSTR) = ol;
+            if constexpr (AP == 2) *reinterpret_cast<x8*>(xt + buf * BUFE + TILE + hv0 + i * 32 * PSTR) = ol;
             return;
         }
         u32x4 raw = hreg[S_][i][0];
@@ -281,13 +284,13 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                 const E* hb = xt + PAR * BUFE;
                 params_fetch(PAR ^ 1);                          // before the data requests: a later wait for the parameters then
                 issue(PAR);                                     // leaves those (and the weight ring) in flight
-                x8 a[3][MR], a_lo[F32 ? 3 : 1][MR];
+                x8 a[3][MR], a_lo[AP == 2 ? 3 : 1][MR];
                 auto a_fetch = [&](int u) __attribute__((always_inline)) {          // sub-step u = 2 q + r: 32-channel slice q, pixel half r
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
                         if (G1_ABL != 4) {
                             a[u % 3][mr] = *reinterpret_cast<const x8*>(hb + abase[mr] + (u >> 1) * 32 + (u & 1) * 16 * PSTR);
-                            if constexpr (F32) a_lo[u % 3][mr] = *reinterpret_cast<const x8*>(hb + TILE + abase[mr] + (u >> 1) * 32 + (u & 1) * 16 * PSTR);
+                            if constexpr (AP == 2) a_lo[u % 3][mr] = *reinterpret_cast<const x8*>(hb + TILE + abase[mr] + (u >> 1) * 32 + (u & 1) * 16 * PSTR);
                         }
                 };
                 a_fetch(0);
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                             for (int nh = 0; nh < 2; ++nh)
                                 acc[mr][r][nh] = EL::mfma16(a[kk % 3][mr], fring_lo[NP == 2 ? (PAR * 4 + q * 2 + nh) % 8 : 0], acc[mr][r][nh]);
                     }
-                    if constexpr (F32) {                        // third pass: the activations' low halves on the weights' high halves
+                    if constexpr (AP == 2) {                    // third pass: the activations' low halves on the weights' high halves
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
                                 const int at = (wm * (128 / WM) + mr * 32 + 16 * r + 4 * lg + j) * PSTR + wn * 32 + 16 * nh + lc;
                                 const E hi = (E)v;
                                 hb[at] = hi;
-                                if constexpr (F32) hb[TILE + at] = (E)(v - (float)hi);
+                                if constexpr (AP == 2) hb[TILE + at] = (E)(v - (float)hi);
                             }
                 lds_barrier();
             }
@@ -472,10 +475,12 @@ __global__ __launch_bounds__(256, F32 ? 1 : 2) void conv1x1_g_kernel(const C1gPa
 
 template <int BN, int XF, int IM, typename E, int NP, bool F32 = false, bool PAIR = false>
 static int run_g1(C1gParams& p, hipStream_t s) {
-    constexpr size_t lds = F32 ? (size_t)2 * 2 * 128 * 80 * 2 + (size_t)4 * 64 * 40 * 4 : (size_t)2 * 128 * 80 * 2 + 2048;
+    constexpr int AP = (F32 && __is_same(E, bf16)) ? 2 : 1;
+    constexpr size_t lds = F32 ? (size_t)2 * AP * 128 * 80 * 2 + (size_t)4 * 64 * 40 * 4 : (size_t)2 * 128 * 80 * 2 + 2048;
+    static_assert(AP == 2 || lds <= 80 * 1024, "two workgroups per CU");
     static PerDeviceOnce once;
     if (int rc = raise_lds_cap(once, &conv1x1_g_kernel<BN, XF, IM, E, NP, F32, PAIR>, lds)) return rc;
-    const int g1_slots = (F32 ? 1 : 2) * device_cus();
+    const int g1_slots = (AP == 2 ? 1 : 2) * device_cus();
     p.n_slices = p.Cout_pad / BN;
     p.m_tiles = (p.M + 127) / 128;
     p.total_items = p.m_tiles * p.n_slices;
@@ -488,9 +493,10 @@ static int run_g1(C1gParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <typename E>
 static int dispatch_g1_f32(int bn, int xf, C1gParams& p, hipStream_t s) {
-    if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE, 0, bf16, 2, true>(p, s) : run_g1<128, XF_AFFINE, 0, bf16, 2, true>(p, s);
-    if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE, 0, bf16, 2, true>(p, s) : run_g1<64, XF_AFFINE, 0, bf16, 2, true>(p, s);
+    if (bn == 128) return xf == XF_NONE ? run_g1<128, XF_NONE, 0, E, 2, true>(p, s) : run_g1<128, XF_AFFINE, 0, E, 2, true>(p, s);
+    if (bn == 64) return xf == XF_NONE ? run_g1<64, XF_NONE, 0, E, 2, true>(p, s) : run_g1<64, XF_AFFINE, 0, E, 2, true>(p, s);
     return HSIDM_E_UNSUPPORTED;
 }
 
@@ -508,7 +514,8 @@ static int dispatch_g1(int bn, int xf, int im, C1gParams& p, hipStream_t s) {
 
 // bn: 64 or 128 (Cout % bn == 0); xf: XF_NONE or XF_AFFINE; HW % 64 == 0; nch even.
 // im_W > 0: 3x3 conv of an 8-channel input as a tap-major GEMM (C0 = 8, C1 = 0, xf = XF_NONE, nch = 2).
-// elem: 0 bf16, 1 fp16 (the bf16-typed pointers are then fp16 data), 2 the fp32 mode (fp32 tensors, bf16 hi + lo weights: w_lo required);
+// elem: 0 bf16, 1 fp16 (the bf16-typed pointers are then fp16 data), 2 the fp32 mode (fp32 tensors, bf16 hi + lo weights: w_lo required),
+// 3 the "fp32h" set (fp32 tensors, one fp16 activation operand, fp16 hi + lo weights: w_lo required);
 // w_lo != null (fp16): second pass on the weights' low halves
 int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, int C1, const void* gn_ab, const bf16* w, const bf16* w_lo,
                   int elem, const float* bias, const bf16* res, float res_scale, bf16* out, float2* stats, int M, int HW, int Cout,
@@ -523,7 +530,8 @@ int conv1x1_g_run(int bn, int xf, const bf16* src0, const bf16* src1, int C0, in
     p.w = w; p.w_lo = w_lo; p.bias = bias; p.res = res; p.res_scale = res_scale; p.out = out; p.stats = stats;
     p.bias1 = nullptr; p.pair_act = ACT_NONE;
     p.M = M; p.HW = HW; p.Cout = Cout; p.Cout_pad = Cout; p.nch = nch;
-    if (elem == 2) return (w_lo && im_W <= 0) ? dispatch_g1_f32(bn, xf, p, s) : HSIDM_E_UNSUPPORTED;
+    if (elem == 2) return (w_lo && im_W <= 0) ? dispatch_g1_f32<bf16>(bn, xf, p, s) : HSIDM_E_UNSUPPORTED;
+    if (elem == 3) return (w_lo && im_W <= 0) ? dispatch_g1_f32<f16>(bn, xf, p, s) : HSIDM_E_UNSUPPORTED;
     if (elem == 0) return w_lo ? HSIDM_E_UNSUPPORTED : dispatch_g1<bf16, 1>(bn, xf, im_W > 0, p, s);
     if (elem == 1) return w_lo ? dispatch_g1<f16, 2>(bn, xf, im_W > 0, p, s) : dispatch_g1<f16, 1>(bn, xf, im_W > 0, p, s);
     return HSIDM_E_UNSUPPORTED;

@@ -146,7 +146,11 @@ struct V2Cfg {
     // item has just freed - unless that buffer is too small for them (the one-image 8x8 tile: 16.6 KB per tile against 20 KB of
     // patches, which used to run over the position table behind the buffers; the fp32 form of that tile: 33 KB against 40 KB) or
     // the workgroup has 8 waves: then they get a region of their own behind the position table.
-    static constexpr size_t PATCH_BYTES = (size_t)NW * 64 * 40 * sizeof(S_);
+    // (EP = 32-pixel MFMA row groups per epilogue pass: two - except in the fp32-storage form with ONE activation operand (AP = 1, the
+    // "fp32h" kernel set), whose 4-byte patches of 64 pixels would not fit the freed halo buffer, and a region of their own would not
+    // leave room for two workgroups per CU: it transposes 32 pixels per pass, 20 KB for the four waves)
+    static constexpr int EP = (F32 && AP_ == 1) ? 1 : 2;
+    static constexpr size_t PATCH_BYTES = (size_t)NW * (32 * EP) * 40 * sizeof(S_);
     static constexpr bool OWN_PATCH = NW == 8 || PATCH_BYTES > (size_t)AP * HALO_ELEMS * 2;
     static constexpr size_t LDS_BYTES = (size_t)2 * AP * HALO_ELEMS * 2 + POS_BYTES + (OWN_PATCH ? PATCH_BYTES : 0);
     // depth of the A-operand ring in sub-steps (kernel: a_fetch).  Two where a sub-step carries twice the MFMAs (NP = 2) and on the
@@ -794,8 +798,9 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
             constexpr int SCR_STR = 40;                                       // bf16 per pixel row: 32 couts + 16 B pad
             constexpr int NV = 2 * MR;                                        // 16-B vectors per lane and item
             // (fp32 mode: 4-byte patch elements, 10 KB per wave, in the free buffer's 56 KB)
+            constexpr int EP = C::EP;                                         // 32-pixel row groups per pass (V2Cfg)
             S* scr = reinterpret_cast<S*>(C::OWN_PATCH ? reinterpret_cast<E*>(smem_raw + (size_t)2 * BUFE * 2 + C::POS_BYTES) : halo + (cur ^ 1) * BUFE) +
-                        wave * (64 * SCR_STR);
+                        wave * (32 * EP * SCR_STR);
             // vector v of a pass covers pixel pl = lane/4 + 16*v: offset = (lane part, one VGPR) + (uniform part, SALU).  The lane
             // constants are rebuilt from the hardware lane id at the top of every pass: kept across the passes they were
             // spilled, and each reload was an s_waitcnt vmcnt(0) behind the previous pass's output stores.
@@ -813,8 +818,8 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                 f32x4 rvf[(RES && F32) ? 4 : 1][2];
                 float vs1[8], vs2[8];
 #pragma unroll
-                for (int g = 0; g < MR; g += 2) {
-                    const int nm = (MR - g) < 2 ? (MR - g) : 2;                // 32-row MFMA tiles in this pass
+                for (int g = 0; g < MR; g += EP) {
+                    const int nm = (MR - g) < EP ? (MR - g) : EP;              // 32-row MFMA tiles in this pass
                     const int pbase = wm * (C::BM / WM) + g * 32;
                     const int img = pbase / (TH * TW);                         // a pass never straddles two images
                     const int b = b0 + img;
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                                 }
                     }
                     HSIDM_STAMP(it, 9);
-                    if (NI == 2 || g == 0) {
+                    if (NI == 2 ? g % 2 == 0 : g == 0) {                       // (NI = 2: an image is two row groups)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) vs1[k] = vs2[k] = 0.f;
                     }
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(C::NTHR, (C::NW == 8 || C::AP == 2) ? 1 : 2) void c
                         }
                     }
                     HSIDM_STAMP(it, 11);
-                    if ((RES || SPL) && p.stats && (NI == 2 || g + 2 >= MR)) {
+                    if ((RES || SPL) && p.stats && (NI == 2 ? (g + EP) % 2 == 0 : g + EP >= MR)) {
                         // Lanes with equal (lane & 3) hold the same 8 couts: fold the 16 of them together with a halving
                         // butterfly -- at every level a lane hands the half of its values its partner keeps and receives
                         // the half it keeps itself: 8+4+2+1 = 15 cross-lane moves instead of 4*16, and every lane ends

@@ -126,23 +126,35 @@ class PackedConv:
     def __init__(self, weight, bias, precision, proj_weight=None, proj_bias=None, out_nchw=False, fold_ups=False, fold_dn=False):
         dev = weight.device
         cout, cin, ksz = weight.shape[0], weight.shape[1], weight.shape[2]
+        # the "fp32h" kernel set (precision.py; include/hsidm.h, HSIDM_F32H): fp32 tensors; a layer the persistent kernels take multiplies
+        # ONE fp16 activation operand by fp16 hi + lo weights; every other layer (fused projection, NCHW output, odd slices) and every
+        # SHAPE the dispatch refuses (conv2d asks) is the fp32 set's own - same tensors in and out
+        self._fallback, self._fallback_src = None, None
+        if precision == "fp32h":
+            self._fallback_src = (weight, bias, proj_weight, proj_bias, out_nchw, fold_ups, fold_dn)
         wide16 = _lib.prec_id(precision) == _lib.F16 and wide_weights(precision, cout, cin + (-cin) % 8, ksz)
         # (a fused projection on a 64-cout slice of a one-pass layer is conv_v3's: its steps carry log2(e), see pack_layouts)
         v3_proj = proj_weight is not None and _lib.prec_id(precision) != _lib.F32X3 and pick_bn(cout, out_nchw) == 64 and not wide16
         lay, meta = pack_layouts(weight.detach().float(), precision, None if proj_weight is None else proj_weight.detach().float(),
                                  out_nchw, fold_ups, fold_dn, proj_scale=LOG2E if v3_proj else 1.0)
         self._set_meta(meta, precision, out_nchw)
+        half = precision == "fp32h" and lay["w_v2"] is not None and proj_weight is None
+        if precision == "fp32h" and not half:
+            self.precision = "fp32"
+        if half:
+            self.prec = _lib.F32H
         b = None if bias is None else bias.detach().float().clone()
         if proj_weight is not None and proj_bias is not None:
             b = proj_bias.detach().float().clone() if b is None else b + proj_bias.detach().float()
         w = lay["w"]
-        et = torch.float16 if self.prec == _lib.F16 else torch.bfloat16            # element type of the packed weights (fp32 mode: bf16 hi + lo)
-        self.w_hi = w.to(et).contiguous()
+        et = torch.float16 if self.prec in (_lib.F16, _lib.F32H) else torch.bfloat16    # element type of the packed weights (fp32 mode: bf16 hi + lo)
+        # (F32H: the LDS-tiled kernel has no form of it - its layout is not packed)
+        self.w_hi = None if half else w.to(et).contiguous()
         # low halves: fp32 mode (three MFMAs per product) and the generic kernel's fp16 form (always hi + lo weights)
-        self.w_lo = (w - self.w_hi.float()).to(et).contiguous() if self.prec != _lib.BF16 else None
+        self.w_lo = (w - self.w_hi.float()).to(et).contiguous() if (self.prec != _lib.BF16 and not half) else None
         self.bias = None if b is None else b.to(dev).contiguous()
         # fp16 mode: does this layer multiply by hi + lo weights on the persistent kernels too (precision.wide_weights)?
-        self.wide = (self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)) or self.prec == _lib.F32X3
+        self.wide = (self.prec == _lib.F16 and wide_weights(precision, self.cout, self.cin, self.ksize)) or self.prec in (_lib.F32X3, _lib.F32H)
         # one-pass layouts of a dithered kernel set ("fp16d<k>", precision.py): step k of a chain multiplies by fp16(w + d_k * ulp(w)), the
         # K offsets d_k spread over (-1/2, 1/2) ulp - the mean weight over K steps is w to 1 / (2K) ulp, so the weight rounding stops
         # being a bias of the chain.
@@ -172,6 +184,14 @@ class PackedConv:
                     ls, li = PackedConv._sparse_lo(st - st.to(et).float(), meta["cpad"])
                     setattr(self, name + "_ls", ls)
                     setattr(self, name + "_li", li)
+
+    def fallback(self):
+        """The fp32 set's packed weights of an "fp32h" layer (built on first use: a shape the HSIDM_F32H forms refuse)."""
+        if self._fallback is None:
+            weight, bias, proj_weight, proj_bias, out_nchw, fold_ups, fold_dn = self._fallback_src
+            self._fallback = PackedConv(weight, bias, "fp32", proj_weight=proj_weight, proj_bias=proj_bias, out_nchw=out_nchw,
+                                        fold_ups=fold_ups, fold_dn=fold_dn)
+        return self._fallback
 
     def _set_meta(self, meta, precision, out_nchw):
         self.ksize, self.cin, self.cout, self.bn = meta["ksize"], meta["cin"], meta["cout"], meta["bn"]
@@ -285,6 +305,10 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, pw.cout
     d.ksize, d.stride, d.ups, d.act = pw.ksize, stride, (UPS_FOLDED if folded else int(bool(ups))), act
     d.out_nchw, d.prec, d.bn = int(pw.out_nchw), pw.prec, pw.bn
+    if pw.prec == _lib.F32H and _lib.lib().hsidm_conv_kernel_id(C.byref(d)) < 0:
+        # a shape the "fp32h" forms do not take (two-image tiles of narrow maps, the GEMM's GroupNorm prologue): the fp32 set's kernels
+        return conv2d(x0, pw.fallback(), x1=x1, gn_ab=gn_ab, transform=transform, film=film, res=res, res_scale=res_scale, act=act,
+                      stride=stride, ups=ups, proj_x0=proj_x0, proj_x1=proj_x1, stats=stats, sk_only=sk_only, fused_only=fused_only)
     nb = 0
     if d.w_v2 and not pw.out_nchw and pw.ksize == 3 and not ups and pw.bn == 128 and pw.cin >= 200:
         # few pixel tiles x a long contraction (the 8x8 / 16x16 levels at small batches): the split-K form needs scratch
@@ -325,7 +349,7 @@ def conv2d(x0, pw, *, x1=None, gn_ab=None, transform=XF_NONE, film=None, res=Non
                                             (" up4" if folded else (" ups" if ups else (" dn4" if planes else ""))),
                                             (" nchw" if pw.out_nchw else "") + (" +proj" if pw.proj_cin else ""))
         _conv_probe.append(dict(e0=e0, e1=e1, flops=2.0 * B * Ho * Wo * pw.cout * k_total, bn=pw.bn, ksize=pw.ksize, kernel=label,
-                                bytes=(B * H * W * (C0 + C1) + B * Ho * Wo * pw.cout) * x0.element_size() + pw.w_hi.numel() * 2,
+                                bytes=(B * H * W * (C0 + C1) + B * Ho * Wo * pw.cout) * x0.element_size() + (pw.w_hi if pw.w_hi is not None else pw.w_v2).numel() * 2,
                                 stride=stride, ups=bool(ups), cin=pw.cin, cout=pw.cout, hw=(Ho, Wo),
                                 out_nchw=pw.out_nchw, tile=0 if Wo >= 16 else 1))
     return out

@@ -12,8 +12,12 @@ PUBLIC modes (both meet the reference's tolerance - 1e-3 relative, 0.01 dB, 0.00
                that is the same in every step of a chain, i.e. a bias, not noise - DESIGN.md section 5, tests/precision_emul.py; the
                dither turns it into noise that averages out over four steps, without the second weight pass rounds 3-4 paid for it)
                where the gain is below WIDE_STEP_GAIN;
-             - the "fp32" kernel set otherwise: the steps of a reverse chain whose update feeds the denoiser's error into the
-               state with a gain >= WIDE_STEP_GAIN (step_precision: eight steps per chain on the reference's cosine schedule), and
+             - the "fp32h" kernel set (fp32 activations and GroupNorm pairs; every convolution rounds its staged operand ONCE to fp16
+               and multiplies by fp16 hi + lo weights: two MFMA passes instead of three, include/hsidm.h HSIDM_F32H) on the steps whose
+               gain lies in [WIDE_STEP_GAIN, FULL_STEP_GAIN): steps 2 .. 8 of a chain on the reference's cosine schedule (gains
+               1.50 ... 0.27).  What has to go at those gains is the 11-bit STORAGE of the activations and the rounding of the
+               weights - not the operand's 11 bits (DESIGN.md section 5: emulated before it was built);
+             - the "fp32" kernel set otherwise: the steps with a gain >= FULL_STEP_GAIN (the first step of every chain, gain 31.6), and
                every BARE module call - UNet.forward, Block.forward, ResnetBlock.forward ... outside a sampler: the output is the
                result, gain 1 (forward_precision).  One forward of the UNet on an fp16 kernel set measures 1.1e-3 ... 1.4e-3 against
                the reference, i.e. outside the tolerance; the reverse chain multiplies it by 0.24 or less wherever such a set runs.
@@ -58,8 +62,8 @@ _internal = False            # inside the sampler's per-step dispatch (internal_
 def _known(p):
     if p in MODES:
         return True
-    if dither_phase(p) is not None:
-        # "fp16d<k>" names ONE kernel set of the "fp16" policy.  Only the sampler's per-step choice (step_precision) produces it:
+    if dither_phase(p) is not None or p == "fp32h":
+        # "fp16d<k>" / "fp32h" name ONE kernel set of the "fp16" policy.  Only the sampler's per-step choice (step_precision) produces it:
         # a module or a run built on it by name would skip the policy's fp32-set steps and the gain-1 widening of bare forwards -
         # a single forward on such a set measures 1.1e-3 ... 1.4e-3 - so by name it is an experimental set like the others
         if _internal or _experimental:
@@ -103,6 +107,10 @@ def resolve_precision(p):
 # 2.8e-4 ... 3.0e-4 instead of 4.9e-4 ... 5.5e-4 on the 20-step reference chains, nothing on the 1000-step ones (3.0e-4 either way) nor on
 # the SAM index, for -0.5 % on the 1000-step benchmark (10 217 against 10 268 in one box) and +19 % time on a 20-step chain)
 WIDE_STEP_GAIN = float(os.environ.get("HSIDM_WIDE_STEP_GAIN", "0.25"))
+# ... and of those, the steps below FULL_STEP_GAIN run on the "fp32h" set (two MFMA passes) instead of "fp32" (three): with the default
+# only the first step of a chain (gain 31.6; the next is 1.50) keeps the full set.  HSIDM_FULL_STEP_GAIN=0 (or HSIDM_NO_FP32H=1): every
+# wide step on "fp32" (round 5's policy, A/B).
+FULL_STEP_GAIN = 0.0 if os.environ.get("HSIDM_NO_FP32H") else float(os.environ.get("HSIDM_FULL_STEP_GAIN", "2.0"))
 
 # Weight dither of the "fp16" policy's chain steps.  The fp16 rounding of a WEIGHT is the one error of a 16-bit pipeline that repeats
 # in every step of a chain - a bias, which is what moves the quality indices.  The fp16 kernel set of chain
@@ -130,7 +138,7 @@ def dither_offset(phase, K):
 
 
 def family(p):
-    """Mode a kernel-set name belongs to ("fp16d2" -> "fp16")."""
+    """Kernel-set family of a name: the dither phases are one set ("fp16d2" -> "fp16"); "fp32" and "fp32h" are their own."""
     return "fp16" if dither_phase(p) is not None else p
 
 
@@ -138,7 +146,7 @@ def step_precision(p, eps_gain, step=0):
     """Kernel set of ONE reverse step (the step-th of its chain) of a chain run in mode p, given the step's gain on the denoiser's
     output (see the module docstring)."""
     if p in ("fp16", "fp16x1", "fp16x2") and eps_gain >= WIDE_STEP_GAIN and not os.environ.get("HSIDM_NO_STEP_SCHEDULE"):
-        return "fp32"
+        return "fp32h" if eps_gain < FULL_STEP_GAIN else "fp32"
     if p == "fp16":
         # (HSIDM_DITHER_K <= 1: the A/B form without the dither is the plainly rounded one-pass set, "fp16x1" - NOT the name "fp16",
         # which as a kernel-set name is round 4's hi + lo set on Cout <= 128)
@@ -178,7 +186,7 @@ def kernels_as_named():
 
 def is_16bit(p):
     """bf16 / fp16 family: the throughput modes (2-byte activations, the persistent kernels)."""
-    return p != "fp32"
+    return p not in ("fp32", "fp32h")
 
 
 def wide_weights(p, cout, cin=0, ksize=3):

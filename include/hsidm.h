@@ -30,6 +30,12 @@ extern "C" {
 #define HSIDM_F16   2   /* fp16 storage + fp16 MFMA operands (11-bit significands, |x| <= 65504: stores saturate), fp32
                            accumulate / statistics / softmax; same kernels, layouts and rate as HSIDM_BF16.  A convolution whose
                            descriptor carries w_v2_lo / w_lo runs a second MFMA pass on the low halves of its weights */
+#define HSIDM_F32H  3   /* hsidm_conv2d only: fp32 storage like HSIDM_F32X3 (same tensors in and out, fp32 GroupNorm pairs), but ONE
+                           fp16 activation operand - the staged value, rounded once behind the fp32 transform - against fp16 hi + lo
+                           weights (w_v2 AND w_v2_lo required, fp16; w_hi / w_lo are not read): two MFMA passes instead of three.  Forms:
+                           the persistent 3x3 kernel on 8x16 tiles (output maps >= 16 wide; stride 1 | 2, folded upsample) and the
+                           plain 1x1 GEMM; every other shape returns HSIDM_E_UNSUPPORTED and runs with HSIDM_F32X3 weights instead.
+                           The kernel set of a reverse chain's steps 2 .. 8 in the host's "fp16" policy (precision.py) */
 
 /* error codes */
 #define HSIDM_OK             0

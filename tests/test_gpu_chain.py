@@ -275,9 +275,9 @@ def test_benchmark_batch_chain_against_the_reference_run(dev):
     try:
         run = gd.make_run(z, x_T=x_T, noise=noise, precision="fp16")
         with torch.no_grad():
-            n_hi = sum(1 for m in run.modes if m == "fp32")
-            assert n_hi == 8 and run.modes[n_hi + 1] == "fp16d1"
-            for _ in range(n_hi + 1):                                                     # the eight fp32-set steps and the first fp16-set one
+            n_hi = sum(1 for m in run.modes if m in ("fp32", "fp32h"))
+            assert n_hi == 8 and run.modes[:2] == ["fp32", "fp32h"] and run.modes[n_hi + 1] == "fp16d1"
+            for _ in range(n_hi + 1):                                                     # the eight wide-set steps and the first fp16-set one
                 run.step()
             torch.cuda.synchronize()
             del recs[:]
@@ -408,11 +408,11 @@ def test_graph_replayed_philox_chain_at_batch_40_with_wrap(dev):
 
 
 def test_precision_schedule_runs_the_high_gain_steps_on_the_fp32_kernels(dev):
-    """precision.step_precision in the reverse loop: a chain in the "fp16" policy runs its first eight steps (update gain 31.6, 1.5, 0.83,
-    0.58, 0.45, 0.37, 0.31, 0.27 on the cosine schedule) on the fp32 kernel set - after those eight steps its state is BIT-IDENTICAL to a chain run in
-    the fp32 mode on the same Philox noise - and the rest on the fp16 kernels with the weight dither of phase (step % 4) (the states
-    then differ); one captured graph per kernel set, all in one memory pool; the schedule is a property of the chain's position, so
-    it repeats after a wrap."""
+    """precision.step_precision in the reverse loop: a chain in the "fp16" policy runs its first step (update gain 31.6 on the cosine
+    schedule) on the fp32 kernel set - after it its state is BIT-IDENTICAL to a chain run in the fp32 mode on the same Philox noise -
+    the next seven (1.5, 0.83, 0.58, 0.45, 0.37, 0.31, 0.27) on the fp32h set (fp32 storage, fp16 operands: the states differ by the
+    operands' rounding, ~1e-4) and the rest on the fp16 kernels with the weight dither of phase (step % 4); one captured graph per kernel
+    set, all in one memory pool; the schedule is a property of the chain's position, so it repeats after a wrap."""
     from hsi_dmgasr_amd.sr3_modules import diffusion, unet
     u = unet.UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=[1, 2], attn_res=[8], res_blocks=1,
                   image_size=16, precision="fp16").to(dev).eval()
@@ -425,20 +425,26 @@ def test_precision_schedule_runs_the_high_gain_steps_on_the_fp32_kernels(dev):
     cond = G(synth_tensor("sched.cond", (3, 3, 16, 16)), dev)
     a = gd.make_run(cond, wrap=True)                            # the module's mode: the "fp16" policy
     b = gd.make_run(cond, wrap=True, precision="fp32")
-    assert a.modes == ["fp32"] * 8 + ["fp16d%d" % (k % 4) for k in range(8, T)] and b.modes == ["fp32"] * T
+    assert a.modes == ["fp32"] + ["fp32h"] * 7 + ["fp16d%d" % (k % 4) for k in range(8, T)] and b.modes == ["fp32"] * T
     with torch.no_grad():
-        for _ in range(8):
-            a.step(); b.step()
+        a.step(); b.step()
         torch.cuda.synchronize()
         assert torch.equal(a.x, b.x)
+        for _ in range(7):
+            a.step(); b.step()
+        torch.cuda.synchronize()
+        e8 = rel_err(a.x.cpu().numpy(), b.x.cpu().numpy())
+        assert not torch.equal(a.x, b.x) and e8 < 3e-4, e8
         for _ in range(T - 8):
             a.step(); b.step()
         torch.cuda.synchronize()
         assert not torch.equal(a.x, b.x) and rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 2e-3
-        assert set(a.graphs) == {"fp16d0", "fp16d1", "fp16d2", "fp16d3", "fp32"} and a.graph is a.graphs["fp16d3"] and int(a.t_ptr.item()) == T - 1      # wrapped
+        # (the fp32 set has run ONE step so far - eagerly; its capture is the first step of the second lap)
+        assert set(a.graphs) == {"fp16d0", "fp16d1", "fp16d2", "fp16d3", "fp32h"} and a.graph is a.graphs["fp16d3"] and int(a.t_ptr.item()) == T - 1      # wrapped
         for _ in range(8):                                      # second lap: the eight high-gain steps again on the fp32 kernels (graph replays)
             a.step(); b.step()
         torch.cuda.synchronize()
+        assert "fp32" in a.graphs
     assert torch.isfinite(a.x).all() and a.steps_done == T + 8
 
 
@@ -454,8 +460,9 @@ def _tiny_gd(dev, T, prec="fp16", seed_prefix="unet_tiny."):
 
 
 def test_captured_steps_are_reused_by_the_next_p_sample_loop_call(dev):
-    """The reference's validation loop calls p_sample_loop once per image and group (sr_gae.py:458-465); a fresh ReverseRun pays five
-    eager steps and five graph captures (fp32 set + four dither phases), half of the shipped 20-step chain.  GaussianDiffusion keeps
+    """The reference's validation loop calls p_sample_loop once per image and group (sr_gae.py:458-465); a fresh ReverseRun pays six
+    eager steps (fp32, fp32h, four dither phases) and five graph captures (the fp32 set runs one step per chain: captured by the second
+    call), more than half of the shipped 20-step chain.  GaussianDiffusion keeps
     the finished call's slot (static buffers + graphs + pool): the next call on the same shapes copies its inputs in and replays from
     its FIRST step - same graphs, results bit-identical to an eager (graph-free) run of the same inputs; a call with other inputs in
     between does not leak into it; changed weights drop the slot; the results handed out are copies, not the slot's buffers."""
@@ -471,12 +478,13 @@ def test_captured_steps_are_reused_by_the_next_p_sample_loop_call(dev):
     assert len(gd._graph_cache) == 1 and not gd._graph_cache[0].busy
     slot = gd._graph_cache[0]
     graphs = dict(slot.graphs)
-    assert set(graphs) == {"fp32", "fp16d0", "fp16d1", "fp16d2", "fp16d3"}
+    assert set(graphs) == {"fp32h", "fp16d0", "fp16d1", "fp16d2", "fp16d3"}
     keep = a0.clone()
     b1 = gd.p_sample_loop_batched(cond[1], x_T=x_T[1], noise=noise[1])        # other inputs through the SAME slot: replays only
     a2 = gd.p_sample_loop_batched(cond[0], x_T=x_T[0], noise=noise[0])
     torch.cuda.synchronize()
     assert len(gd._graph_cache) == 1 and gd._graph_cache[0] is slot and all(slot.graphs[k] is g for k, g in graphs.items())
+    assert set(slot.graphs) == set(graphs) | {"fp32"}                           # (the chain's one fp32-set step: captured by the second call)
     assert torch.equal(a0, keep) and a0.data_ptr() != slot.x.data_ptr()         # the first call's result was a copy: the later calls did not touch it
     assert torch.equal(a0, want[0]) and torch.equal(b1, want[1]) and torch.equal(a2, want[0])
     # the stock entry points go through the same slots (continous: the snapshots are copied out too)
@@ -499,11 +507,11 @@ def test_captured_steps_are_reused_by_the_next_p_sample_loop_call(dev):
 
 
 def test_graphs_of_one_pool_replay_in_another_order_than_they_were_captured(dev):
-    """The kernel sets of a chain (fp32 + four dither phases) are captured into ONE memory pool: each replay may overwrite what the
+    """The kernel sets of a chain (fp32, fp32h, four dither phases) are captured into ONE memory pool: each replay may overwrite what the
     others left behind, which is safe only while nothing allocated inside a capture outlives it except through the static buffers.
-    A 22-step chain with wrap captures in the order fp32, d0, d1, d2, d3 and, from the second lap on, replays ... d0, d1 | fp32 x 8, d0
-    ... - d1 followed by fp32, an order no capture saw; three laps against the same chain run eagerly (graph-free) on the same Philox
-    noise must be bit-identical."""
+    A 22-step chain with wrap captures in the order fp32h, d0, d1, d2, d3, then fp32 (the second lap's first step) and replays ... d0,
+    d1 | fp32, fp32h x 7, d0 ... - d1 followed by fp32, an order no capture saw; three laps against the same chain run eagerly
+    (graph-free) on the same Philox noise must be bit-identical."""
     T, B = 22, 4
     gd, eager = _tiny_gd(dev, T), _tiny_gd(dev, T)
     eager.use_graph = False
@@ -518,7 +526,7 @@ def test_graphs_of_one_pool_replay_in_another_order_than_they_were_captured(dev)
                 a.step(); b.step()
             torch.cuda.synchronize()
             assert torch.equal(a.x, b.x), lap
-    assert len(a.graphs) == 5 and not b.graphs
+    assert len(a.graphs) == 6 and not b.graphs
 
 
 def test_sharded_driver_under_an_rccl_group_of_one(dev):
@@ -610,9 +618,11 @@ def test_bench_line_is_the_compact_contract_object(tmp_path):
     # the policy's eight fp32-set steps of a chain sit in the warm-up of a 20-step window: the line says so, and `value` IS the per-chain
     # mix (992 window steps + 8 fp32-set steps per 1000), not the optimistic window rate, which stays in config; the same policy on the
     # reference's shipped 20-step chain is reported beside it
-    assert cfg["fp32_mode_steps_in_window"] == 0 and cfg["value_is"].startswith("per-chain mix")
+    assert cfg["wide_set_steps_in_window"] == 0 and cfg["value_is"].startswith("per-chain mix")
     assert d["value"] == cfg["value_chain_mix"] and d["ms_per_step"] == cfg["ms_per_step_chain_mix"]
-    assert cfg["value_window"] > d["value"] and cfg["ms_per_step_window"] < d["ms_per_step"] < cfg["ms_per_step_fp32_set"]
+    wide = cfg["ms_per_step_wide_sets"]
+    assert cfg["steps_per_chain_wide_sets"] == {"fp32": 1, "fp32h": 7}
+    assert cfg["value_window"] > d["value"] and cfg["ms_per_step_window"] < d["ms_per_step"] < wide["fp32h"] < wide["fp32"]
     assert 0.3 * d["value"] < cfg["value_T20"] < d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3

@@ -318,9 +318,9 @@ def test_bench_contract_line_stays_compact():
             "config": {"workload": "SR3 UNet 97.8M (6->3 ch, inner 64, mults 1-2-4-8-8, attn@16) p_sample step on GAE latents 3x128x128, "
                                    "cosine T=1000, BASELINE configs[3]", "patches_per_gpu": 48, "total_patches": 384, "groups_per_patch": 5,
                        "batch_per_gpu": 240, "global_batch": 1920, "parallelism": "dp8", "precision_mode": max(bench.DTYPE.values(), key=len),
-                       "warmup_steps_run": 16, "fp32_mode_steps_in_window": 4, "value_is": "per-chain mix of the measured step times",
+                       "warmup_steps_run": 16, "wide_set_steps_in_window": 4, "value_is": "per-chain mix of the measured step times",
                        "value_window": big, "ms_per_step_window": big, "ms_per_step_chain_mix": big, "value_chain_mix": big,
-                       "ms_per_step_fp32_set": big, "value_T20": big},
+                       "ms_per_step_wide_sets": {"fp32": big, "fp32h": big}, "steps_per_chain_wide_sets": {"fp32": 1, "fp32h": 7}, "value_T20": big},
             "rccl_ranks": 8, "allgather_ms": big, "rank_ms_per_step": {"min": big, "max": big}}
     row = dict(kernel=kern, launches=20, ms_per_step=big, avg_launch_us=big, tflops=big, frac=0.123456789)
     roof = dict(bound="mfma", kernel=kern, launches=20, avg_launch_us=big, algorithmic_flops_per_launch=big * 1e7,
@@ -437,7 +437,10 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
     assert P.resolve_precision("fp16d1") == "fp16d1"                   # (experimental sets allowed: by name, like the others)
     assert P.resolve_precision("bf16") == "bf16"                       # (conftest.py: the suite measures them as regression gates)
     # the "fp16" policy: a chain step by its gain, a bare forward (gain 1) on the fp32 kernel set; named sets stay as named
-    assert P.step_precision("fp16", 0.24, 7) == "fp16d3" and P.step_precision("fp16", 0.26) == "fp32" and P.step_precision("fp32", 9.0) == "fp32"
+    assert P.step_precision("fp16", 0.24, 7) == "fp16d3" and P.step_precision("fp16", 0.26) == "fp32h" and P.step_precision("fp32", 9.0) == "fp32"
+    assert P.step_precision("fp16", 1.99) == "fp32h" and P.step_precision("fp16", 2.0) == "fp32" and P.step_precision("fp16x1", 0.26) == "fp32h"
+    assert P.family("fp32h") == "fp32h" and not P.is_16bit("fp32h") and P.is_16bit("fp16d1") and _lib.prec_id("fp32h") == _lib.F32X3
+    assert _lib.act_dtype("fp32h") == torch.float32 and _lib.F32H == 3
     assert P.forward_precision("fp16") == "fp32" and P.forward_precision("fp32") == "fp32" and P.forward_precision("bf16") == "bf16"
     assert P.forward_precision("fp16x1") == "fp16x1"
     with P.kernels_as_named():
@@ -468,15 +471,16 @@ def test_precision_modes_and_the_wide_weight_rule(monkeypatch):
 
 def test_precision_schedule_along_the_chain():
     """precision.step_precision: in the "fp16" policy the steps whose update multiplies the denoiser's output error by a quarter or more run on
-    the fp32 kernel set - with the reference's cosine schedule the first EIGHT steps of a chain of any length (gains 31.6 - beta clamped
-    at 0.999, reference diffusion.py:46 - then 1.50, 0.83, 0.58, 0.45, 0.37, 0.31, 0.27 | 0.24: near t = T the schedule's alpha-bar is ~ (T - t)^2,
-    whatever T) - and every other step on the fp16 set with the weight dither of phase (step % K); bf16 and fp32 chains are uniform,
-    the experimental one- / two-pass forms keep their own kernels behind the same eight steps."""
+    the policy's wide kernel sets - with the reference's cosine schedule the first EIGHT steps of a chain of any length (gains 31.6 - beta
+    clamped at 0.999, reference diffusion.py:46 - then 1.50, 0.83, 0.58, 0.45, 0.37, 0.31, 0.27 | 0.24: near t = T the schedule's alpha-bar is
+    ~ (T - t)^2, whatever T): the first on "fp32" (gain >= FULL_STEP_GAIN = 2), the other seven on "fp32h" - and every other step on the
+    fp16 set with the weight dither of phase (step % K); bf16 and fp32 chains are uniform, the experimental one- / two-pass forms keep
+    their own kernels behind the same eight steps."""
     from hsi_dmgasr_amd import precision
     from hsi_dmgasr_amd.sr3_modules import diffusion
     gd = diffusion.GaussianDiffusion(torch.nn.Identity(), image_size=16, channels=3, conditional=True)
     K = precision.DITHER_K
-    assert K == 4 and precision.WIDE_STEP_GAIN == 0.25
+    assert K == 4 and precision.WIDE_STEP_GAIN == 0.25 and precision.FULL_STEP_GAIN == 2.0
     for T in (20, 1000, 100):
         wide = [T - 1 - k for k in range(8)]
         gd.set_new_noise_schedule(dict(schedule="cosine", n_timestep=T, linear_start=1e-6, linear_end=1e-2), "cpu")
@@ -484,7 +488,8 @@ def test_precision_schedule_along_the_chain():
         assert gain.shape == (T,) and abs(gain[T - 1] - 31.59) < 0.01 and gain[T - 8] > 0.25 > gain[T - 9]
         np.testing.assert_allclose(gain, np.abs(gd.posterior_mean_coef1.double().numpy() * gd.sqrt_recipm1_alphas_cumprod.double().numpy()), rtol=1e-5)
         for mode in ("fp16", "fp16x1", "fp16x2"):
-            assert [t for t in reversed(range(T)) if precision.step_precision(mode, gain[t], T - 1 - t) == "fp32"] == wide, (T, mode)
+            assert [t for t in reversed(range(T)) if precision.step_precision(mode, gain[t], T - 1 - t) in ("fp32", "fp32h")] == wide, (T, mode)
+            assert [precision.step_precision(mode, gain[T - 1 - k], k) for k in range(8)] == ["fp32"] + ["fp32h"] * 7, (T, mode)
         assert [precision.step_precision("fp16", gain[T - 1 - k], k) for k in range(8, 16)] == ["fp16d%d" % (k % K) for k in range(8, 16)]
         assert all(precision.step_precision("fp16x1", gain[T - 1 - k], k) == "fp16x1" for k in range(8, T))
         for mode in ("bf16", "fp32"):
@@ -667,26 +672,34 @@ def test_the_oracle_decode_of_a_fixtures_latents_is_the_references_cube_before_t
     assert H.rel_err(np.clip(rawc[::4], 0.0, 1.0), gc["y_sub4"][0]) < 2e-5
 
 
-def test_bench_value_is_the_per_chain_mix_of_the_two_step_times():
-    """bench.py: `value` for a window that held fewer fp32-set steps than their share of a 1000-step chain is the per-chain mix of the
-    two measured step times; a window that is a whole chain is reported as measured; value_T20 puts the same two times on the
-    reference's shipped 20-step chain (all eight fp32-set steps in 20)."""
+def test_bench_value_is_the_per_chain_mix_of_the_measured_step_times():
+    """bench.py: `value` for a window that held fewer wide-set steps than their share of a 1000-step chain is the per-chain mix of the
+    measured step times (base set from the window, each wide set timed separately); a window that is a whole chain is reported as
+    measured; value_T20 puts the same times on the reference's shipped 20-step chain (all eight wide-set steps in 20)."""
     bench = _load_bench()
-    T, n_hi, batch = 1000, 8, 240
-    # the driver's form: 20 window steps at 22.0 ms, none on the fp32 set (60 ms, timed separately)
-    mix = bench.chain_mix(20 * 22.0, 20, 0, 60.0, T, n_hi, batch)
-    assert abs(mix["ms_per_step_base_mode"] - 22.0) < 1e-9 and abs(mix["ms_per_step_chain_mix"] - (992 * 22.0 + 8 * 60.0) / 1000) < 1e-9
+    T, batch = 1000, 240
+
+    def sets(in32, in32h, ms32=60.0, ms32h=40.0):
+        return [dict(mode="fp32", per_chain=1, in_window=in32, ms=ms32), dict(mode="fp32h", per_chain=7, in_window=in32h, ms=ms32h)]
+    wide = 1 * 60.0 + 7 * 40.0
+    # the driver's form: 20 window steps at 22.0 ms, none on a wide set
+    o = sets(0, 0)
+    mix = bench.chain_mix(20 * 22.0, 20, o, T, batch)
+    assert abs(mix["ms_per_step_base_mode"] - 22.0) < 1e-9 and abs(mix["ms_per_step_chain_mix"] - (992 * 22.0 + wide) / 1000) < 1e-9
     assert abs(mix["value_chain_mix"] - batch / (mix["ms_per_step_chain_mix"] * 1e-3)) < 1e-6
-    assert abs(mix["value_T20"] - batch * 20 / ((8 * 60.0 + 12 * 22.0) * 1e-3)) < 1e-6
-    assert bench.value_is_mix(mix, 0, 20, T, n_hi)
-    # the default run: 1000 steps = one whole chain with its eight fp32-set steps inside -> the window IS the mix
-    whole = 992 * 22.0 + 8 * 60.0
-    mix2 = bench.chain_mix(whole, 1000, 8, 60.0, T, n_hi, batch)
+    assert abs(mix["value_T20"] - batch * 20 / ((wide + 12 * 22.0) * 1e-3)) < 1e-6
+    assert [m["mode"] for m in mix["other_modes"]] == ["fp32", "fp32h"] and mix["steps_per_chain_other_modes"] == 8
+    assert bench.value_is_mix(mix, o, 20, T)
+    # the default run: 1000 steps = one whole chain with its eight wide-set steps inside -> the window IS the mix
+    whole = 992 * 22.0 + wide
+    o2 = sets(1, 7)
+    mix2 = bench.chain_mix(whole, 1000, o2, T, batch)
     assert abs(mix2["ms_per_step_base_mode"] - 22.0) < 1e-9 and abs(mix2["ms_per_step_chain_mix"] - whole / 1000) < 1e-9
-    assert not bench.value_is_mix(mix2, 8, 1000, T, n_hi)
-    # a window with MORE than its share (e.g. 100 steps holding all eight) is reported as measured too; no fp32-set time: no mix
-    assert not bench.value_is_mix(bench.chain_mix(92 * 22.0 + 8 * 60.0, 100, 8, 60.0, T, n_hi, batch), 8, 100, T, n_hi)
-    assert bench.chain_mix(20 * 22.0, 20, 0, None, T, n_hi, batch) is None and not bench.value_is_mix(None, 0, 20, T, n_hi)
-    # a policy with twelve such steps on a 20-step chain: all twelve count, eight others
-    m12 = bench.chain_mix(20 * 22.0, 20, 0, 60.0, T, 12, batch)
+    assert not bench.value_is_mix(mix2, o2, 1000, T)
+    # a window with MORE than its share (100 steps holding all eight) is reported as measured too; a set without a time: no mix
+    assert not bench.value_is_mix(bench.chain_mix(92 * 22.0 + wide, 100, o2, T, batch), o2, 100, T)
+    o3 = sets(0, 0, ms32=None)
+    assert bench.chain_mix(20 * 22.0, 20, o3, T, batch) is None and not bench.value_is_mix(None, o3, 20, T)
+    # one wide set of twelve steps (HSIDM_NO_FP32H=1 with HSIDM_WIDE_STEP_GAIN=1/6): all twelve count on a 20-step chain
+    m12 = bench.chain_mix(20 * 22.0, 20, [dict(mode="fp32", per_chain=12, in_window=0, ms=60.0)], T, batch)
     assert abs(m12["value_T20"] - batch * 20 / ((12 * 60.0 + 8 * 22.0) * 1e-3)) < 1e-6
