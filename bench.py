@@ -897,7 +897,7 @@ def main():
             for pp in (8, 1):
                 b = pp * GROUPS
                 r = gd.make_run(cond[:b].contiguous(), wrap=True)
-                for _ in range(n_warm):                         # the fp32-set steps of the chain's start, then the fp16 set's eager steps and captures
+                for _ in range(n_warm):                         # the wide-set steps of the chain's start, then the fp16 set's eager steps and captures
                     r.step()
                 torch.cuda.synchronize()
                 n = max(50, min(300, args.steps))
@@ -913,7 +913,7 @@ def main():
     short = None
     if solo and args.detail and not args.no_small and args.precision == HEADLINE:
         # the reference's SHIPPED chain length (config/sr_sr3_16_128.json:98,104: n_timestep 20 for validation) end to end through the product's
-        # entry point: one p_sample_loop_batched call over this GPU's batch = 20 steps, all eight fp32-set steps of the policy among them.
+        # entry point: one p_sample_loop_batched call over this GPU's batch = 20 steps, all eight wide-set steps of the policy (1 fp32 + 7 fp32h) among them.
         # The FIRST call of a process pays five eager steps (weight packing) and five graph captures; every later call on the same shapes
         # replays the kept slot (diffusion._GraphSlot) from its first step - what a validation loop over images sees.
         from hsi_dmgasr_amd.sr3_modules import diffusion as _dm
@@ -933,7 +933,7 @@ def main():
             later = sorted(calls[1:])[1]
             short = dict(chain_steps=20, batch=batch, first_call_ms=calls[0], later_call_ms=later, calls_ms=calls,
                          value_first_call=20 * batch / (calls[0] * 1e-3), value_later_calls=20 * batch / (later * 1e-3),
-                         unit="denoise-steps*batch/s", note="whole p_sample_loop_batched calls (20 steps, 8 of them on the fp32 kernel set); "
+                         unit="denoise-steps*batch/s", note="whole p_sample_loop_batched calls (20 steps: 1 on the fp32 kernel set, 7 on fp32h, 12 on the dithered fp16 sets); "
                          "later calls replay the first call's captured steps")
             del gd20, x0
         torch.cuda.empty_cache()
@@ -960,9 +960,9 @@ def main():
     if rank == 0:
         total_batch = total_patches * GROUPS
         # The metric is the 1000-step p_sample_loop: `value` is the rate of a WHOLE chain under the precision policy.  A timed window that
-        # holds fewer of the policy's fp32-set steps than their share of a chain (the driver's 20 steps hold none: they are the first eight
+        # holds fewer of the policy's wide-set steps (fp32, fp32h) than their share of a chain (the driver's 20 steps hold none: they are the first eight
         # of a chain and the warm-up consumed them) would read optimistic, so `value` / `ms_per_step` are then the per-chain mix of the
-        # two measured step times - (T - n) x window step + n x fp32-set step, the latter timed right behind the window - and the raw
+        # measured step times - (T - n) x window step + the n wide-set steps, each set's graph timed right behind the window - and the raw
         # window figures stay in `config`.  A window that is a whole chain (the default 1000 steps) IS the mix and is reported as measured.
         win_value, win_ms = args.steps * total_batch / dt, dt / args.steps * 1e3
         use_mix = value_is_mix(mix, others, args.steps, run_T)
@@ -990,7 +990,7 @@ def main():
                        # one step on each of the policy's wide kernel sets (fp32: the first step of a chain; fp32h: the next seven)
                        "ms_per_step_wide_sets": None if mix is None else {o["mode"]: _r(o["ms_per_step"], 5) for o in mix["other_modes"]},
                        "steps_per_chain_wide_sets": None if mix is None else {o["mode"]: o["steps_per_chain"] for o in mix["other_modes"]},
-                       # the reference's shipped validation chain length (T = 20): all of the policy's fp32-set steps in 20 steps
+                       # the reference's shipped validation chain length (T = 20): all of the policy's wide-set steps in 20 steps
                        "value_T20": None if mix is None else _r(mix["value_T20"], 5)},
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "allgather_ms": _r(allgather_ms),
             # (the timed window, min / max over the ranks)
