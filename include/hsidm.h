@@ -126,7 +126,7 @@ typedef struct hsidm_conv_desc {
     int32_t ups;              /* HSIDM_UPS_*: nearest x2 upsample folded in (Hout = 2*Hin)          */
     int32_t act;              /* HSIDM_ACT_*                                                        */
     int32_t out_nchw;         /* 1: write NCHW fp32 (network outputs)                               */
-    int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3 | HSIDM_F16                               */
+    int32_t prec;             /* HSIDM_BF16 | HSIDM_F32X3 | HSIDM_F16 | HSIDM_F32H                  */
     int32_t bn;               /* cout slice the weights were packed for: 32, 64 or 128             */
     void*   workspace;        /* optional scratch of hsidm_conv_workspace_bytes(d) bytes: enables the split-K form
                                  (csrc/conv_sk.hip) for launches with few pixel tiles and a long contraction -
@@ -144,7 +144,7 @@ typedef struct hsidm_conv_desc {
                                  three steps per item through its weight ring, whatever the projection's width; w_hi / w_lo, the
                                  LDS-tiled kernel's order, stay unscaled and unpadded).  Neither: launch the projection separately */
     int64_t workspace_bytes;
-    const void*  w_v2_lo;     /* optional (HSIDM_F16 with w_v2): fp16(W - fp16(W)) in the layout of w_v2 - the weights then carry
+    const void*  w_v2_lo;     /* required for HSIDM_F32H (fp16) and for the persistent forms of HSIDM_F32X3 (bf16); optional (HSIDM_F16 with w_v2): fp16(W - fp16(W)) in the layout of w_v2 - the weights then carry
                                  ~18-19 significant bits (the low halves are fp16 subnormals for |w| < 0.125: absolute granularity 6e-8) for twice the matrix instructions (the weight rounding
                                  is the one systematic error of a 16-bit mode; the pass is nearly free on layers bound by the
                                  staging transform).  Not taken by the split-K form and the 256-cout items                        */

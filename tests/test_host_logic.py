@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libhsidm.so does not export %s" % name
     assert declared - {"hsidm_error_string"} == set(_lib.SIGNATURES), "ctypes table out of sync with hsidm.h"
     assert _lib.lib().hsidm_version() == _lib.ABI_VERSION == 3
-    assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32 and _lib.lib().hsidm_conv_bk(_lib.F16) == 64
+    assert _lib.lib().hsidm_conv_bk(_lib.BF16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32X3) == 32 and _lib.lib().hsidm_conv_bk(_lib.F16) == 64 and _lib.lib().hsidm_conv_bk(_lib.F32H) == 64
     assert b"invalid" in _lib.lib().hsidm_error_string(-1)
 
 
