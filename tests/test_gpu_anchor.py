@@ -369,6 +369,70 @@ def test_fp32_form_of_the_persistent_kernel_matches_the_lds_tiled_kernel(dev, ca
     check("fp32_v2_vs_torch%s" % (case,), "fp32", outs[1], want, tol=1e-4)
 
 
+F32H_CASES = F32_CASES + [
+    (3, 19, 37, 128, 64, 128, 1, False, True, True, True, 1.0, False),     # ragged 128-cout map with concat, FiLM and residual: partial tiles on the native form
+    (2, 20, 24, 64, 0, 128, 1, True, False, False, False, 1.0, False),     # folded nearest-x2 on a ragged input grid
+    (2, 22, 38, 128, 0, 64, 2, False, False, False, True, 1.0, False),     # stride 2, even ragged map, residual
+]
+
+
+@pytest.mark.parametrize("case", F32H_CASES)
+def test_fp32h_forms_on_ragged_and_odd_shapes(dev, case):
+    """The "fp32h" kernel set (fp32 storage, one fp16 activation operand, fp16 hi + lo weights: HSIDM_F32H) on the shapes the benchmark-size
+    anchors do not reach - odd batches, partial tiles (the scalar epilogue), LeakyReLU + scaled residual, concat inputs off the chunk
+    grid, 8x8 maps, 32-cout slices: whatever the dispatch does with the shape - its own two-pass form, or the fp32 set's kernel on the
+    layer's fp32-set weights (ops.PackedConv.fallback) - the result is the fp32 set's to the operand rounding (native) or bit for bit
+    (fall-back), the statistics slab describes the stored tensor, and torch's fp32 convolution is 3.5e-4 away at most."""
+    from hsi_dmgasr_amd import ops
+    B, H, W, C0, C1, Co, stride, ups, xf, with_film, with_res, res_scale, leaky = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:6]) + 1)
+    cin = C0 + C1
+    w = torch.randn(Co, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = 0.1 * torch.randn(Co, generator=g)
+    x0 = torch.randn(B, H, W, C0, generator=g).to(dev)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dev) if C1 else None
+    ab = torch.stack([1 + 0.1 * torch.randn(B, cin, generator=g), 0.2 * torch.randn(B, cin, generator=g)], 2).contiguous().to(dev) if xf else None
+    Ho, Wo = (2 * H, 2 * W) if ups else (((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+    film = torch.randn(B, Co, generator=g).to(dev) if with_film else None
+    res = torch.randn(B, Ho, Wo, Co, generator=g).to(dev) if with_res else None
+    kw = dict(x1=x1, gn_ab=None if ab is None else ops.gn_table(ab), transform=ops.XF_AFFINE_SILU if xf else ops.XF_NONE, film=film, res=res,
+              res_scale=res_scale, act=ops.ACT_LEAKY if leaky else ops.ACT_NONE, stride=stride, ups=ups, stats=True)
+    pk = ops.PackedConv(w.to(dev), b.to(dev), "fp32h", fold_ups=ups, fold_dn=stride == 2)
+    pk32 = ops.PackedConv(w.to(dev), b.to(dev), "fp32", fold_ups=ups, fold_dn=stride == 2)
+    y = ops.conv2d(x0, pk, **kw)
+    y32 = ops.conv2d(x0, pk32, **kw)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float32 and y.shape == y32.shape
+    assert_stats(y._hsidm_stats[0], y, case)
+    native = pk.prec == _lib.F32H and pk._fallback is None
+    d = rel_err(y.cpu().numpy(), y32.cpu().numpy())
+    log_err("fp32h_vs_fp32%s" % (case,), "fp32h", d, {"native": native})
+    if native:
+        assert 5e-6 < d < 3.5e-4, (case, d)          # (0.1 * conv + x: the residual carries most of the norm)
+    else:
+        assert torch.equal(y, y32), (case, d)
+    # the shapes of this list the two-pass forms take: output maps >= 16 wide, cout slices of 64 / 128 (Cout > 32)
+    assert native == ((W if ups else Wo) >= 16 and Co > 32), (case, native, pk.prec)
+    xr = x0 if x1 is None else torch.cat([x0, x1], dim=3)
+    xr = xr.float().cpu()
+    if ab is not None:
+        a = ab.float().cpu()
+        xr = xr * a[:, None, None, :, 0] + a[:, None, None, :, 1]
+        xr = xr * torch.sigmoid(xr)
+    xr = xr.permute(0, 3, 1, 2)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    want = F.conv2d(xr, w, b, stride=stride, padding=1)
+    if film is not None:
+        want = want + film.cpu()[:, :, None, None]
+    if leaky:
+        want = F.leaky_relu(want, 0.01)
+    want = res_scale * want.permute(0, 2, 3, 1)
+    if res is not None:
+        want = want + res.cpu()
+    check("fp32h_vs_torch%s" % (case,), "fp32h", y, want, tol=3.5e-4)
+
+
 def test_fp16_stores_saturate_instead_of_overflowing(dev):
     """fp16's range ends at 65 504: a convolution whose result exceeds it must store +-65504, not inf (an inf would turn the next
     GroupNorm's statistics, and with them the rest of the chain, into NaN).  Every store path: the vector epilogue (with and without a
