@@ -272,8 +272,12 @@ __global__ __launch_bounds__(256, (F32 && __is_same(E, bf16)) ? 1 : 2) void conv
     lds_barrier();
 
     const int n_lane = n0 + wn * 32 + lc;                       // couts n_lane, n_lane + 16 (Cout % BN == 0 on this path)
-    const float bias[2] = {p.bias ? p.bias[n_lane] : 0.f, p.bias ? p.bias[n_lane + 16] : 0.f};
-    const float bias1[2] = {(PAIR && p.bias1) ? p.bias1[n_lane] : 0.f, (PAIR && p.bias1) ? p.bias1[n_lane + 16] : 0.f};
+    float bias[2] = {p.bias ? p.bias[n_lane] : 0.f, p.bias ? p.bias[n_lane + 16] : 0.f};
+    float bias1[2] = {(PAIR && p.bias1) ? p.bias1[n_lane] : 0.f, (PAIR && p.bias1) ? p.bias1[n_lane + 16] : 0.f};
+    // The bias registers are USED here, once: left pending, their loads kept the compiler's in-order memory counter "unknown" at the loop
+    // head, and the first instruction of every epilogue that read them waited s_waitcnt vmcnt(0) - for the weight ring and the next item's
+    // staged chunks, i.e. a full round trip exposed per item (found in the ISA; round 2's ablation saw it as "the epilogue is 20-40 % of a launch")
+    asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias1[0]), "+v"(bias1[1]));
 
     for (int it = 0; it < n_items_blk; ++it, item += G) {
         for (int chunk = 0; chunk < p.nch; chunk += 2) {
@@ -446,8 +450,10 @@ __global__ __launch_bounds__(256, (F32 && __is_same(E, bf16)) ? 1 : 2) void conv
                     }
                     if (G1_ABL != 6) *reinterpret_cast<x8*>(reinterpret_cast<E*>(p.out) + obase + (size_t)16 * v4 * p.Cout + lane_el) = o;
                     }
+                    if (p.stats) {          // (uniform: 22 of a step's 28 GEMM launches - projections, qkv - emit no statistics: no unpack, no sums)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                        for (int k = 0; k < 8; ++k) { vs1[k] += f[k]; vs2[k] = fmaf(f[k], f[k], vs2[k]); }
+                    }
                 }
                 if (p.stats && G1_ABL != 8) {
                     // halving butterfly over the 16 lanes that hold the same 8 couts (see conv_v2.h)
