@@ -1,7 +1,7 @@
 """Precision mode of the HIP path.
 
 PUBLIC modes.  Both are held to the reference's tolerance - 1e-3 relative on latents and cube, 0.01 dB, 0.001 deg - on every entry point.
-"fp32" meets every bound by two orders of magnitude.  "fp16" meets every CONTINUOUS quantity on the nine reference chains (tightest: 9.3e-4
+"fp32" meets every bound by two orders of magnitude.  "fp16" meets every CONTINUOUS quantity on the eleven reference chains (tightest: 9.3e-4
 on the latents the reference did not clamp); the reference's SAM INDEX (eval_hsi.py:47-65), which skips all-zero spectra and is therefore
 discontinuous where a spectrum crosses the clamp at zero, is missed strictly on one hold-out chain (one pixel, 1.9e-3 deg; 3.9e-4 on the
 common support): bench.py reports `meets_north_star` strictly (false) and tests/test_gpu_chain.py carries the miss as a named XFAIL.

@@ -33,7 +33,7 @@ FULL = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, chann
 #   fp16  : meets every continuous bound - 11-bit significands, the weight rounding (the one error that is the same in every step
 #           of the chain: a bias, not noise) dithered over the steps, the high-gain steps on the fp32 kernel set;
 #           tests/precision_emul.py reproduces the device numbers on the host and shows which rounding contributes what.  The
-#           reference's SAM index is met strictly on eight of the nine chains; on orth:4:20 ONE pixel sits at the index's
+#           reference's SAM index is met strictly on ten of the eleven chains; on orth:4:20 ONE pixel sits at the index's
 #           discontinuity (see below and test_strict_sam_index_of_the_headline_mode).
 #   bf16  : meets the PSNR bound (0.0012 dB) but neither the latent bound (7.7e-3) nor the SAM bound (0.012 degrees): 8-bit
 #           significands on every MFMA operand and stored activation.  Its gate is the measured value with 2.5x head-room - a
@@ -632,7 +632,7 @@ def test_bench_line_is_the_compact_contract_object(tmp_path):
     assert rf["fused_resnetblock_hbm_frac"] < rf["resnetblock_launch_hbm_frac"]
     par = d["parity"]
     # (orth:4:20 - a hold-out - sits at the SAM index's discontinuity: one pixel's zero-spectrum membership differs, see helpers.sam_gate)
-    assert par["mode"] == "fp16" and par["meets_north_star_with_sam_on_common_support"] is True and par["n_fixtures"] == 9
+    assert par["mode"] == "fp16" and par["meets_north_star_with_sam_on_common_support"] is True and par["n_fixtures"] == 11
     assert par["meets_north_star"] is (par["dSAM_deg"] <= 1e-3) and par["meets_north_star"] is (par["strict_sam_misses"] == [])
     assert par["latents_rel_err"] <= par["latents_rel_err_unsaturated"] < 1e-3 and par["dSAM_unclamped_deg"] <= 1e-3
     assert any("T1000" in k for k in par["worst_of"])
