@@ -609,6 +609,38 @@ def test_fused_projection_packing_scales_the_projection_steps_for_the_persistent
     assert wide.wide and wide.w_v2 is None and wide.w_hi.shape[0] == 9 + 2 and torch.allclose(wide.bias, b + bp)
 
 
+def test_fp32h_layers_pack_fp16_hi_lo_weights_and_fall_back_to_the_fp32_set():
+    """ops.PackedConv in the "fp32h" kernel set (fp32 storage, one fp16 activation operand, fp16 hi + lo weights; HSIDM_F32H): a layer the
+    persistent kernels take carries its register-streaming layouts as fp16 hi + lo (hi + lo = w to ~2^-22 |w|; nothing in the LDS-tiled
+    kernel's order, which has no form of the set) under prec = F32H; a layer they do not take (NCHW output, 32-cout slices) IS an fp32-set
+    layer; fallback() builds the fp32 set's weights of an F32H layer once, for the shapes the dispatch refuses (ops.conv2d asks)."""
+    from hsi_dmgasr_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(128, generator=g)
+    pk = ops.PackedConv(w, b, "fp32h", fold_dn=True)
+    assert pk.prec == _lib.F32H and pk.precision == "fp32h" and pk.wide and pk.w_hi is None and pk.w_lo is None
+    for name in ("w_v2", "w_dn4"):
+        hi, lo = getattr(pk, name), getattr(pk, name + "_lo")
+        assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == lo.shape
+    ref = ops.PackedConv(w, b, "fp32", fold_dn=True)                  # same layouts, bf16 hi + lo
+    assert ref.prec == _lib.F32X3 and ref.w_v2.dtype == torch.bfloat16 and ref.w_v2.shape == pk.w_v2.shape
+    exact = ref.w_v2.double() + ref.w_v2_lo.double()                  # (bf16 hi + lo: ~2^-16 |w|)
+    mine = pk.w_v2.double() + pk.w_v2_lo.double()
+    assert float((mine - exact).abs().max()) <= 2.0 ** -15 * float(w.abs().max())
+    full = ops.PackedConv._lanes(ops.PackedConv._steps(w, 128, 64), 128).double()
+    assert float((mine - full).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+    fb = pk.fallback()
+    assert fb is pk.fallback() and fb.prec == _lib.F32X3 and fb.precision == "fp32" and fb.w_hi is not None and torch.equal(fb.w_v2, ref.w_v2)
+    # no persistent form: the layer is the fp32 set's own
+    for kw, wt in ((dict(out_nchw=True), torch.randn(3, 64, 3, 3, generator=g)), (dict(), torch.randn(24, 40, 3, 3, generator=g))):
+        q = ops.PackedConv(wt, None, "fp32h", **kw)
+        assert q.prec == _lib.F32X3 and q.precision == "fp32" and q.w_hi is not None and q.w_hi.dtype == torch.bfloat16
+    # a 1x1 layer: the GEMM's order, K padded to a multiple of 128
+    p1 = ops.PackedConv(torch.randn(128, 192, 1, 1, generator=g), None, "fp32h")
+    assert p1.prec == _lib.F32H and p1.w_v2.dtype == torch.float16 and p1.w_v2.shape[0] == 4 and p1.w_v2_lo is not None
+
+
 def test_sam_gate_and_the_continuous_companions_of_the_parity_checks():
     """The parity helpers the -m gpu chain tests and bench.py gate with (tests/helpers.py; bench.py restates two of them on torch tensors):
     (1) sam_gate applies north_star's SAM bound to the reference's STRICT index unless at most SAM_MAX_FLIPS pixels flipped their
